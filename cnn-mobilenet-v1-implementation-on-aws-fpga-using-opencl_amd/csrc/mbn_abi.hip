@@ -1,0 +1,362 @@
+// mbn_abi.hip — the C-ABI of include/mbn.h: context lifecycle, buffers, and the four layer entry points
+// that replace the reference's clSetKernelArg + clEnqueueNDRangeKernel protocol
+// (MobileNet.c:272-292 convolute, :363-382 depthwise, :453-470 pointwise, :2640-2656 pool).
+//
+// No CPU fallback exists: without a HIP device mbn_init returns MBN_ENODEVICE and nothing computes.
+#include "mbn_internal.h"
+
+#include <new>
+
+extern "C" {
+
+const char *mbn_version(void) { return "mbn-mi355x 0.1 (gfx950)"; }
+
+const char *mbn_strerror(int code)
+{
+    switch (code) {
+    case MBN_OK: return "ok";
+    case MBN_EINVAL: return "invalid argument";
+    case MBN_ENOMEM: return "out of memory";
+    case MBN_EDEVICE: return "HIP runtime error";
+    case MBN_EIO: return "I/O error";
+    case MBN_EFORMAT: return "bad file format";
+    case MBN_ENOTFOUND: return "object not found";
+    case MBN_ESHAPE: return "shape mismatch";
+    case MBN_EUNSUPPORTED: return "unsupported";
+    case MBN_ENODEVICE: return "no HIP device";
+    default: return "unknown error";
+    }
+}
+
+int mbn_device_count(int *count)
+{
+    if (!count) return MBN_EINVAL;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) n = 0;
+    *count = n;
+    return MBN_OK;
+}
+
+int mbn_init(int device_ordinal, mbn_context **out)
+{
+    if (!out) return MBN_EINVAL;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return MBN_ENODEVICE;
+    if (device_ordinal < 0 || device_ordinal >= n) return MBN_ENODEVICE;
+    mbn_context *ctx = new (std::nothrow) mbn_context();
+    if (!ctx) return MBN_ENOMEM;
+    ctx->device = device_ordinal;
+    hipError_t e = hipSetDevice(device_ordinal);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev_start);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev_stop);
+    if (e != hipSuccess) {
+        if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
+        if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return MBN_EDEVICE;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess) {
+        snprintf(ctx->name, sizeof(ctx->name), "%s (%s)", prop.name, prop.gcnArchName);
+        ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    *out = ctx;
+    return MBN_OK;
+}
+
+int mbn_shutdown(mbn_context *ctx)
+{
+    if (!ctx) return MBN_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &kv : ctx->allocs) (void)hipFree(kv.first);
+    ctx->allocs.clear();
+    (void)hipEventDestroy(ctx->ev_start);
+    (void)hipEventDestroy(ctx->ev_stop);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return MBN_OK;
+}
+
+int mbn_device_name(mbn_context *ctx, char *buf, size_t buflen)
+{
+    if (!ctx || !buf || buflen == 0) return MBN_EINVAL;
+    snprintf(buf, buflen, "%s", ctx->name);
+    return MBN_OK;
+}
+
+const char *mbn_last_device_error(mbn_context *ctx) { return ctx ? ctx->last_error : "no context"; }
+
+int mbn_set_literal_quirks(mbn_context *ctx, uint32_t quirks)
+{
+    if (!ctx || (quirks & ~MBN_QUIRKS_KERNEL_CL)) return MBN_EINVAL;
+    ctx->literal_quirks = quirks;
+    return MBN_OK;
+}
+
+int mbn_get_stream(mbn_context *ctx, void **stream)
+{
+    if (!ctx || !stream) return MBN_EINVAL;
+    *stream = (void *)ctx->stream;
+    return MBN_OK;
+}
+
+int mbn_alloc(mbn_context *ctx, size_t bytes, void **dptr)
+{
+    if (!ctx || !dptr || bytes == 0) return MBN_EINVAL;
+    *dptr = nullptr;
+    (void)hipSetDevice(ctx->device);
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e == hipErrorOutOfMemory) return MBN_ENOMEM;
+    if (e != hipSuccess) return mbn_record_hip_error(ctx, e, "hipMalloc");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->allocs[p] = bytes;
+    *dptr = p;
+    return MBN_OK;
+}
+
+int mbn_free(mbn_context *ctx, void *dptr)
+{
+    if (!ctx) return MBN_EINVAL;
+    if (!dptr) return MBN_OK;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        auto it = ctx->allocs.find(dptr);
+        if (it == ctx->allocs.end()) return MBN_EINVAL;   // not ours: caller-owned memory is never freed here
+        ctx->allocs.erase(it);
+    }
+    (void)hipSetDevice(ctx->device);
+    MBN_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    MBN_HIP_TRY(ctx, hipFree(dptr));
+    return MBN_OK;
+}
+
+int mbn_upload(mbn_context *ctx, void *dst, const void *src, size_t bytes)
+{
+    if (!ctx || !dst || !src) return MBN_EINVAL;
+    if (bytes == 0) return MBN_OK;
+    (void)hipSetDevice(ctx->device);
+    MBN_HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    MBN_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // blocking like CL_TRUE, MobileNet.c:350
+    return MBN_OK;
+}
+
+int mbn_download(mbn_context *ctx, void *dst, const void *src, size_t bytes)
+{
+    if (!ctx || !dst || !src) return MBN_EINVAL;
+    if (bytes == 0) return MBN_OK;
+    (void)hipSetDevice(ctx->device);
+    MBN_HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    MBN_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // blocking like CL_TRUE, MobileNet.c:395
+    return MBN_OK;
+}
+
+int mbn_memset(mbn_context *ctx, void *dst, int byte, size_t bytes)
+{
+    if (!ctx || !dst) return MBN_EINVAL;
+    if (bytes == 0) return MBN_OK;
+    (void)hipSetDevice(ctx->device);
+    MBN_HIP_TRY(ctx, hipMemsetAsync(dst, byte, bytes, ctx->stream));
+    return MBN_OK;
+}
+
+int mbn_sync(mbn_context *ctx)
+{
+    if (!ctx) return MBN_EINVAL;
+    (void)hipSetDevice(ctx->device);
+    MBN_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MBN_OK;
+}
+
+int mbn_set_profiling(mbn_context *ctx, int enabled)
+{
+    if (!ctx) return MBN_EINVAL;
+    ctx->profiling = enabled != 0;
+    ctx->ev_valid = false;
+    return MBN_OK;
+}
+
+int mbn_last_kernel_ms(mbn_context *ctx, float *ms)
+{
+    if (!ctx || !ms) return MBN_EINVAL;
+    if (!ctx->ev_valid) return MBN_EINVAL;
+    MBN_HIP_TRY(ctx, hipEventSynchronize(ctx->ev_stop));
+    MBN_HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev_start, ctx->ev_stop));
+    return MBN_OK;
+}
+
+}   // extern "C"
+
+// --------------------------------------------------------------------------- call resolution
+
+namespace {
+
+struct Scope {   // hipEvent pair around one layer call when profiling is on (MobileNet.c:301-305 analogue)
+    mbn_context *ctx;
+    hipStream_t s;
+    Scope(mbn_context *c, hipStream_t st) : ctx(c), s(st)
+    {
+        (void)hipSetDevice(ctx->device);
+        if (ctx->profiling) (void)hipEventRecord(ctx->ev_start, s);
+    }
+    int finish(int rc)
+    {
+        if (ctx->profiling) {
+            (void)hipEventRecord(ctx->ev_stop, s);
+            ctx->ev_valid = true;
+        }
+        if (rc != MBN_OK) return rc;
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return mbn_record_hip_error(ctx, e, "kernel launch");
+        return MBN_OK;
+    }
+};
+
+int resolve(mbn_context *ctx, const mbn_layer_ext *ext, mbn_call *c, int *dtype)
+{
+    if (!ctx) return MBN_EINVAL;
+    memset(c, 0, sizeof(*c));
+    c->ctx = ctx;
+    c->stream = ctx->stream;
+    c->batch = 1;
+    c->act = MBN_ACT_RELU;
+    c->pad_top = c->pad_left = -1;
+    c->quirks = ctx->literal_quirks;
+    *dtype = MBN_DT_U8;
+    if (!ext) return MBN_OK;
+    if (ext->struct_size != sizeof(mbn_layer_ext)) return MBN_EINVAL;
+    *dtype = ext->dtype;
+    if (ext->dtype == MBN_DT_BF16) return MBN_EUNSUPPORTED;
+    if (ext->dtype != MBN_DT_U8 && ext->dtype != MBN_DT_F32) return MBN_EINVAL;
+    if (ext->dtype == MBN_DT_U8 && ext->layout != MBN_LAYOUT_NCHW_PLANAR) return MBN_EUNSUPPORTED;
+    if (ext->dtype == MBN_DT_F32 && ext->layout != MBN_LAYOUT_NHWC) return MBN_EUNSUPPORTED;
+    if (ext->batch < 0) return MBN_EINVAL;
+    c->batch = ext->batch > 0 ? ext->batch : 1;
+    if (ext->act < MBN_ACT_NONE || ext->act > MBN_ACT_RELU6) return MBN_EINVAL;
+    c->act = ext->act;
+    c->pad_top = ext->pad_top;
+    c->pad_left = ext->pad_left;
+    c->in_rows = ext->in_rows;
+    c->in_cols = ext->in_cols;
+    c->cin = ext->cin;
+    c->g0 = ext->gsize0;
+    c->g1 = ext->gsize1;
+    if (ext->quirks_valid) {
+        if (ext->quirks & ~MBN_QUIRKS_KERNEL_CL) return MBN_EINVAL;
+        c->quirks = ext->quirks;
+    }
+    c->scale = (const float *)ext->scale;
+    c->shift = (const float *)ext->shift;
+    if (ext->stream) c->stream = (hipStream_t)ext->stream;
+    return MBN_OK;
+}
+
+}   // namespace
+
+extern "C" {
+
+int mbn_convolute(mbn_context *ctx, void *output, const void *inp_r, const void *inp_g, const void *inp_b,
+                  const void *filter_k, int rows, int cols, int filtersize, int stride, int op_size,
+                  const mbn_layer_ext *ext)
+{
+    mbn_call c;
+    int dtype;
+    int rc = resolve(ctx, ext, &c, &dtype);
+    if (rc != MBN_OK) return rc;
+    if (!output || !inp_r || !filter_k) return MBN_EINVAL;
+    if (rows <= 0 || cols <= 0 || op_size <= 0 || stride <= 0 || filtersize <= 0 || !(filtersize & 1))
+        return MBN_EINVAL;
+    Scope sc(ctx, c.stream);
+    if (dtype == MBN_DT_U8) {
+        if (!inp_g || !inp_b) return MBN_EINVAL;
+        if (rows / stride <= 0 || cols / stride <= 0) return MBN_EINVAL;
+        return sc.finish(mbn_launch_lit_convolute(c, (uint8_t *)output, (const uint8_t *)inp_r, (const uint8_t *)inp_g,
+                                                  (const uint8_t *)inp_b, (const int32_t *)filter_k, rows, cols,
+                                                  filtersize, stride, op_size));
+    }
+    if (c.cin <= 0) c.cin = 3;
+    return sc.finish(mbn_launch_f32_conv(c, (float *)output, (const float *)inp_r, (const float *)filter_k, rows, cols,
+                                         filtersize, stride, op_size));
+}
+
+int mbn_depthwise(mbn_context *ctx, void *output, const void *inp_image, const void *filter_k, int rows, int cols,
+                  int filtersize, int stride, int op_size, const mbn_layer_ext *ext)
+{
+    mbn_call c;
+    int dtype;
+    int rc = resolve(ctx, ext, &c, &dtype);
+    if (rc != MBN_OK) return rc;
+    if (!output || !inp_image || !filter_k) return MBN_EINVAL;
+    if (rows <= 0 || cols <= 0 || op_size <= 0 || stride <= 0 || filtersize <= 0 || !(filtersize & 1))
+        return MBN_EINVAL;
+    if (c.in_rows <= 0) c.in_rows = rows * stride;
+    if (c.in_cols <= 0) c.in_cols = cols * stride;
+    Scope sc(ctx, c.stream);
+    if (dtype == MBN_DT_U8)
+        return sc.finish(mbn_launch_lit_depthwise(c, (uint8_t *)output, (const uint8_t *)inp_image,
+                                                  (const int32_t *)filter_k, rows, cols, filtersize, stride, op_size));
+    return sc.finish(mbn_launch_f32_depthwise(c, (float *)output, (const float *)inp_image, (const float *)filter_k,
+                                              rows, cols, filtersize, stride, op_size));
+}
+
+int mbn_pointwise(mbn_context *ctx, void *output, const void *inp_image, const void *filter_k, int rows, int cols,
+                  int filtersize, int op_size, const mbn_layer_ext *ext)
+{
+    mbn_call c;
+    int dtype;
+    int rc = resolve(ctx, ext, &c, &dtype);
+    if (rc != MBN_OK) return rc;
+    if (!output || !inp_image || !filter_k) return MBN_EINVAL;
+    if (rows <= 0 || cols <= 0 || op_size <= 0 || filtersize <= 0) return MBN_EINVAL;
+    Scope sc(ctx, c.stream);
+    if (dtype == MBN_DT_U8)
+        return sc.finish(mbn_launch_lit_pointwise(c, (uint8_t *)output, (const uint8_t *)inp_image,
+                                                  (const int32_t *)filter_k, rows, cols, filtersize, op_size));
+    long m = (long)c.batch * rows * cols;
+    return sc.finish(mbn_launch_f32_pointwise(c, (float *)output, (const float *)inp_image, (const float *)filter_k, m,
+                                              filtersize, op_size));
+}
+
+int mbn_pool(mbn_context *ctx, void *output, const void *inp_image, int rows, int cols, int filtersize, int op_size,
+             const mbn_layer_ext *ext)
+{
+    mbn_call c;
+    int dtype;
+    int rc = resolve(ctx, ext, &c, &dtype);
+    if (rc != MBN_OK) return rc;
+    if (!output || !inp_image) return MBN_EINVAL;
+    if (rows <= 0 || cols <= 0 || op_size <= 0 || filtersize <= 0) return MBN_EINVAL;
+    Scope sc(ctx, c.stream);
+    if (dtype == MBN_DT_U8) {
+        if ((long)filtersize * filtersize > (long)rows * cols) return MBN_EINVAL;   // kernel.cl:126 would run past the plane
+        return sc.finish(mbn_launch_lit_pool(c, (uint8_t *)output, (const uint8_t *)inp_image, rows, cols, filtersize,
+                                             op_size));
+    }
+    return sc.finish(mbn_launch_f32_pool(c, (float *)output, (const float *)inp_image, rows, cols, filtersize, op_size));
+}
+
+int mbn_softmax_f32(mbn_context *ctx, void *probs, void *argmax_i32, const void *logits, int batch, int classes,
+                    void *stream)
+{
+    if (!ctx || !logits || batch <= 0 || classes <= 0 || (!probs && !argmax_i32)) return MBN_EINVAL;
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    Scope sc(ctx, s);
+    return sc.finish(mbn_launch_f32_softmax(ctx, s, (float *)probs, (int32_t *)argmax_i32, (const float *)logits, batch,
+                                            classes));
+}
+
+int mbn_normalize_u8_to_f32(mbn_context *ctx, void *out_f32, const void *in_u8, size_t count, float scale, float bias,
+                            void *stream)
+{
+    if (!ctx || !out_f32 || !in_u8) return MBN_EINVAL;
+    if (count == 0) return MBN_OK;
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    Scope sc(ctx, s);
+    return sc.finish(mbn_launch_normalize(ctx, s, (float *)out_f32, (const uint8_t *)in_u8, count, scale, bias));
+}
+
+}   // extern "C"

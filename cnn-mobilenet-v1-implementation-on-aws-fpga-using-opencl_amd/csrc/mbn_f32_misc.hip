@@ -1,0 +1,217 @@
+// mbn_f32_misc.hip — the remaining fp32 NHWC stages of the path for gfx950:
+//   conv1   (kernel.cl:2-60  `convolute`, 3x3xCin -> Cout, stride 2)      HBM-bound (AI 9.8 flop/B)
+//   pool    (kernel.cl:116-132 `pool`, global average)                    HBM-bound
+//   softmax (MobileNet.c:2771-2792, host loop in the reference)           classifier tail on device
+//   u8->f32 normalise (front-end for MobileNet.c:215-238's uint8 image)   HBM-bound
+#include "mbn_internal.h"
+
+namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+struct ConvArgs {
+    float *out;
+    const float *in, *filt, *scale, *shift;
+    int batch, rows, cols, cin, fs, stride, orow, ocol, cout, pad_top, pad_left, act;
+    long total;   // batch*orow*ocol*(cout/4)
+};
+
+// One lane = 4 consecutive output channels of one output pixel; the cout/4 lanes of a pixel are adjacent, so a
+// wave's store is one contiguous span of the NHWC output (the 73 % of this stage's traffic). Input taps of a pixel
+// are shared by those lanes (same-address loads, one request); the whole filter (fs*fs*cin*cout floats) sits in LDS
+// and is read as wave-broadcast float4s.
+__global__ __launch_bounds__(256) void conv_f32_nhwc(ConvArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float wlds[];
+    const int wcount = a.fs * a.fs * a.cin * a.cout;
+    for (int i = threadIdx.x * 4; i < wcount; i += blockDim.x * 4)
+        *reinterpret_cast<f4 *>(wlds + i) = *reinterpret_cast<const f4 *>(a.filt + i);
+    __syncthreads();
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.total) return;
+    const int c4n = a.cout >> 2;
+    const int oc = (int)(t % c4n) << 2;
+    long q = t / c4n;
+    const int ox = (int)(q % a.ocol);
+    q /= a.ocol;
+    const int oy = (int)(q % a.orow);
+    const int n = (int)(q / a.orow);
+    const float *img = a.in + (long)n * a.rows * a.cols * a.cin;
+    f4 acc = f4{ 0.f, 0.f, 0.f, 0.f };
+    for (int ky = 0; ky < a.fs; ky++) {
+        const int iy = oy * a.stride + ky - a.pad_top;
+        if (iy < 0 || iy >= a.rows) continue;
+        for (int kx = 0; kx < a.fs; kx++) {
+            const int ix = ox * a.stride + kx - a.pad_left;
+            if (ix < 0 || ix >= a.cols) continue;
+            const float *ip = img + ((long)iy * a.cols + ix) * a.cin;
+            const float *wp = wlds + (long)((ky * a.fs + kx) * a.cin) * a.cout + oc;
+            for (int ci = 0; ci < a.cin; ci++) {
+                const float v = ip[ci];
+                const f4 w = *reinterpret_cast<const f4 *>(wp + (long)ci * a.cout);
+                acc.x = fmaf(v, w.x, acc.x); acc.y = fmaf(v, w.y, acc.y);
+                acc.z = fmaf(v, w.z, acc.z); acc.w = fmaf(v, w.w, acc.w);
+            }
+        }
+    }
+    const f4 sc = a.scale ? *reinterpret_cast<const f4 *>(a.scale + oc) : f4{ 1.f, 1.f, 1.f, 1.f };
+    const f4 sh = a.shift ? *reinterpret_cast<const f4 *>(a.shift + oc) : f4{ 0.f, 0.f, 0.f, 0.f };
+    f4 v = f4{ fmaf(acc.x, sc.x, sh.x), fmaf(acc.y, sc.y, sh.y), fmaf(acc.z, sc.z, sh.z), fmaf(acc.w, sc.w, sh.w) };
+    if (a.act == MBN_ACT_RELU6) {
+        v.x = fminf(fmaxf(v.x, 0.f), 6.f); v.y = fminf(fmaxf(v.y, 0.f), 6.f);
+        v.z = fminf(fmaxf(v.z, 0.f), 6.f); v.w = fminf(fmaxf(v.w, 0.f), 6.f);
+    } else if (a.act == MBN_ACT_RELU) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    }
+    *reinterpret_cast<f4 *>(a.out + t * 4) = v;
+}
+
+// any cout / unaligned: one lane per output element, filter from global memory
+__global__ __launch_bounds__(256) void conv_generic_f32_nhwc(ConvArgs a)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)a.batch * a.orow * a.ocol * a.cout;
+    if (t >= total) return;
+    const int oc = (int)(t % a.cout);
+    long q = t / a.cout;
+    const int ox = (int)(q % a.ocol);
+    q /= a.ocol;
+    const int oy = (int)(q % a.orow);
+    const int n = (int)(q / a.orow);
+    const float *img = a.in + (long)n * a.rows * a.cols * a.cin;
+    float acc = 0.f;
+    for (int ky = 0; ky < a.fs; ky++) {
+        const int iy = oy * a.stride + ky - a.pad_top;
+        if (iy < 0 || iy >= a.rows) continue;
+        for (int kx = 0; kx < a.fs; kx++) {
+            const int ix = ox * a.stride + kx - a.pad_left;
+            if (ix < 0 || ix >= a.cols) continue;
+            for (int ci = 0; ci < a.cin; ci++)
+                acc = fmaf(img[((long)iy * a.cols + ix) * a.cin + ci],
+                           a.filt[((long)(ky * a.fs + kx) * a.cin + ci) * a.cout + oc], acc);
+        }
+    }
+    float v = fmaf(acc, a.scale ? a.scale[oc] : 1.f, a.shift ? a.shift[oc] : 0.f);
+    if (a.act == MBN_ACT_RELU6) v = fminf(fmaxf(v, 0.f), 6.f);
+    else if (a.act == MBN_ACT_RELU) v = fmaxf(v, 0.f);
+    a.out[t] = v;
+}
+
+// global average pool: one lane per (image, channel); lanes run along channels (coalesced NHWC reads).
+__global__ __launch_bounds__(256) void pool_f32_nhwc(float *__restrict__ out, const float *__restrict__ in, int batch,
+                                                     int rows, int cols, int fr, int fc, int ch)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)batch * ch) return;
+    const int c = (int)(t % ch);
+    const int n = (int)(t / ch);
+    const float *ip = in + (long)n * rows * cols * ch + c;
+    float acc = 0.f;
+    for (int y = 0; y < fr; y++)
+        for (int x = 0; x < fc; x++) acc += ip[((long)y * cols + x) * ch];
+    out[t] = acc / (float)(fr * fc);
+}
+
+// softmax + argmax: one 256-lane workgroup per image; wave shuffles then a 4-entry LDS combine.
+__global__ __launch_bounds__(256) void softmax_f32(float *__restrict__ probs, int *__restrict__ argmax,
+                                                   const float *__restrict__ logits, int classes)
+{
+    __shared__ float s_val[4];
+    __shared__ int s_idx[4];
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *l = logits + (long)n * classes;
+    float mx = -INFINITY;
+    int am = 0x7fffffff;
+    for (int k = tid; k < classes; k += 256) {
+        float v = l[k];
+        if (v > mx) { mx = v; am = k; }
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        float ov = __shfl_xor(mx, d, 64);
+        int oi = __shfl_xor(am, d, 64);
+        if (ov > mx || (ov == mx && oi < am)) { mx = ov; am = oi; }
+    }
+    if (lane == 0) { s_val[wave] = mx; s_idx[wave] = am; }
+    __syncthreads();
+    mx = s_val[0]; am = s_idx[0];
+    for (int w = 1; w < 4; w++)
+        if (s_val[w] > mx || (s_val[w] == mx && s_idx[w] < am)) { mx = s_val[w]; am = s_idx[w]; }
+    __syncthreads();
+    float sum = 0.f;
+    for (int k = tid; k < classes; k += 256) sum += expf(l[k] - mx);
+    for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
+    if (lane == 0) s_val[wave] = sum;
+    __syncthreads();
+    sum = s_val[0] + s_val[1] + s_val[2] + s_val[3];
+    if (probs)
+        for (int k = tid; k < classes; k += 256) probs[(long)n * classes + k] = expf(l[k] - mx) / sum;
+    if (argmax && tid == 0) argmax[n] = am;
+}
+
+__global__ __launch_bounds__(256) void normalize_u8_f32(float *__restrict__ out, const uint8_t *__restrict__ in,
+                                                        size_t count, float scale, float bias)
+{
+    const size_t t = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (t + 3 < count) {
+        const uchar4 v = *reinterpret_cast<const uchar4 *>(in + t);
+        *reinterpret_cast<f4 *>(out + t) =
+            f4{ fmaf((float)v.x, scale, bias), fmaf((float)v.y, scale, bias), fmaf((float)v.z, scale, bias),
+                fmaf((float)v.w, scale, bias) };
+    } else {
+        for (size_t i = t; i < count; i++) out[i] = fmaf((float)in[i], scale, bias);
+    }
+}
+
+}   // namespace
+
+int mbn_launch_f32_conv(const mbn_call &c, float *out, const float *in, const float *filt, int rows, int cols, int fs,
+                        int stride, int op_size)
+{
+    ConvArgs a;
+    a.out = out; a.in = in; a.filt = filt; a.scale = c.scale; a.shift = c.shift;
+    a.batch = c.batch; a.rows = rows; a.cols = cols; a.cin = c.cin; a.fs = fs; a.stride = stride;
+    a.orow = (rows + stride - 1) / stride; a.ocol = (cols + stride - 1) / stride; a.cout = op_size;
+    a.pad_top = c.pad_top >= 0 ? c.pad_top : mbn_same_pad(rows, a.orow, fs, stride);
+    a.pad_left = c.pad_left >= 0 ? c.pad_left : mbn_same_pad(cols, a.ocol, fs, stride);
+    a.act = c.act;
+    const size_t wbytes = (size_t)fs * fs * c.cin * op_size * sizeof(float);
+    const bool fast = (op_size % 4) == 0 && wbytes <= 64 * 1024 && ((uintptr_t)out % 16) == 0 &&
+                      ((uintptr_t)filt % 16) == 0 && (!c.scale || ((uintptr_t)c.scale % 16) == 0) &&
+                      (!c.shift || ((uintptr_t)c.shift % 16) == 0);
+    if (fast) {
+        a.total = (long)c.batch * a.orow * a.ocol * (op_size / 4);
+        hipLaunchKernelGGL(conv_f32_nhwc, dim3((unsigned)((a.total + 255) / 256)), dim3(256), wbytes, c.stream, a);
+    } else {
+        a.total = 0;
+        long total = (long)c.batch * a.orow * a.ocol * op_size;
+        hipLaunchKernelGGL(conv_generic_f32_nhwc, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c.stream, a);
+    }
+    return MBN_OK;
+}
+
+int mbn_launch_f32_pool(const mbn_call &c, float *out, const float *in, int rows, int cols, int fs, int channels)
+{
+    const int fr = fs < rows ? fs : rows, fc = fs < cols ? fs : cols;
+    const long total = (long)c.batch * channels;
+    hipLaunchKernelGGL(pool_f32_nhwc, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c.stream, out, in, c.batch,
+                       rows, cols, fr, fc, channels);
+    return MBN_OK;
+}
+
+int mbn_launch_f32_softmax(mbn_context *, hipStream_t s, float *probs, int32_t *argmax, const float *logits, int batch,
+                           int classes)
+{
+    hipLaunchKernelGGL(softmax_f32, dim3(batch), dim3(256), 0, s, probs, argmax, logits, classes);
+    return MBN_OK;
+}
+
+int mbn_launch_normalize(mbn_context *, hipStream_t s, float *out, const uint8_t *in, size_t count, float scale,
+                         float bias)
+{
+    const size_t lanes = (count + 3) / 4;
+    const bool aligned = ((uintptr_t)in % 4) == 0 && ((uintptr_t)out % 16) == 0;
+    if (!aligned) return MBN_EINVAL;
+    hipLaunchKernelGGL(normalize_u8_f32, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, s, out, in, count, scale,
+                       bias);
+    return MBN_OK;
+}

@@ -1,0 +1,82 @@
+// mbn_internal.h — shared between the C-ABI translation unit and the gfx950 kernel files.
+// Not part of the public boundary (that is include/mbn.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+#include <unordered_map>
+
+#include "mbn.h"
+
+struct mbn_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool profiling = false;
+    bool ev_valid = false;
+    uint32_t literal_quirks = MBN_QUIRKS_KERNEL_CL;
+    char last_error[256] = {0};
+    char name[128] = {0};
+    int num_cus = 256;
+    std::mutex mu;
+    std::unordered_map<void *, size_t> allocs;   // buffers handed out by mbn_alloc
+};
+
+static inline int mbn_record_hip_error(mbn_context *ctx, hipError_t e, const char *what)
+{
+    if (ctx) snprintf(ctx->last_error, sizeof(ctx->last_error), "%s: %s", what, hipGetErrorString(e));
+    return MBN_EDEVICE;
+}
+
+#define MBN_HIP_TRY(ctx, expr)                                                    \
+    do {                                                                          \
+        hipError_t _e = (expr);                                                   \
+        if (_e != hipSuccess) return mbn_record_hip_error((ctx), _e, #expr);      \
+    } while (0)
+
+// Resolved per-call view of (positional args + ext) handed to the kernel launchers.
+struct mbn_call {
+    mbn_context *ctx;
+    hipStream_t stream;
+    int batch;
+    int act;
+    int pad_top, pad_left;
+    int in_rows, in_cols;
+    int cin;
+    int g0, g1;
+    uint32_t quirks;
+    const float *scale, *shift;
+};
+
+// ---- launchers implemented in the kernel files; each returns MBN_* and launches on c.stream ----
+// LITERAL (uint8 planar NCHW / int32) — mbn_literal.hip
+int mbn_launch_lit_convolute(const mbn_call &c, uint8_t *out, const uint8_t *r, const uint8_t *g, const uint8_t *b,
+                             const int32_t *filt, int rows, int cols, int fs, int stride, int op_size);
+int mbn_launch_lit_depthwise(const mbn_call &c, uint8_t *out, const uint8_t *in, const int32_t *filt, int rows,
+                             int cols, int fs, int stride, int op_size);
+int mbn_launch_lit_pointwise(const mbn_call &c, uint8_t *out, const uint8_t *in, const int32_t *filt, int rows,
+                             int cols, int cin, int op_size);
+int mbn_launch_lit_pool(const mbn_call &c, uint8_t *out, const uint8_t *in, int rows, int cols, int fs, int op_size);
+
+// F32 NHWC — mbn_f32_dw.hip / mbn_f32_pw.hip / mbn_f32_misc.hip
+int mbn_launch_f32_conv(const mbn_call &c, float *out, const float *in, const float *filt, int rows, int cols, int fs,
+                        int stride, int op_size);
+int mbn_launch_f32_depthwise(const mbn_call &c, float *out, const float *in, const float *filt, int rows, int cols,
+                             int fs, int stride, int channels);
+int mbn_launch_f32_pointwise(const mbn_call &c, float *out, const float *in, const float *filt, long m, int cin,
+                             int op_size);
+int mbn_launch_f32_pool(const mbn_call &c, float *out, const float *in, int rows, int cols, int fs, int channels);
+int mbn_launch_f32_softmax(mbn_context *ctx, hipStream_t s, float *probs, int32_t *argmax, const float *logits,
+                           int batch, int classes);
+int mbn_launch_normalize(mbn_context *ctx, hipStream_t s, float *out, const uint8_t *in, size_t count, float scale,
+                         float bias);
+
+static inline int mbn_same_pad(int in, int out, int k, int stride)
+{
+    int total = (out - 1) * stride + k - in;
+    if (total < 0) total = 0;
+    return total / 2;
+}

@@ -1,0 +1,200 @@
+/*
+ * mbn_net.c — the C host that sequences MobileNet-V1 through the C-ABI (include/mbn.h).
+ *
+ * Counterpart of the reference's main(): MobileNet.c:240-2763 is 29 hand-unrolled blocks, each doing
+ * clCreateKernel -> readSquezeNetKernel -> clCreateBuffer x3 -> blocking H2D x2 -> clSetKernelArg ->
+ * clEnqueueNDRangeKernel -> clFinish -> blocking D2H (template at MobileNet.c:322-403). Here the same
+ * layer order is a loop over the plan; weights are uploaded once, activations ping-pong between two buffers
+ * that stay in HBM, every call is asynchronous on the context's stream, and nothing crosses PCIe between layers.
+ *
+ * Plain C: this file uses nothing but the functions declared in mbn.h.
+ */
+#include <stdlib.h>
+#include <string.h>
+
+#include "mbn.h"
+
+struct mbn_net {
+    mbn_context *ctx;
+    mbn_plan plan;
+    int max_batch;
+    void *dev_blob;
+    int own_blob;
+    void *act[2];
+    int keep;
+    void *keep_buf[MBN_MAX_LAYERS];
+    void *last_out[MBN_MAX_LAYERS];
+};
+
+static const float *blob_at(const mbn_net *net, int64_t off)
+{
+    return off < 0 ? NULL : (const float *)net->dev_blob + off;
+}
+
+static int net_alloc_common(mbn_context *ctx, const mbn_plan *plan, int max_batch, mbn_net **out)
+{
+    if (!ctx || !plan || !out || max_batch <= 0 || plan->n_layers <= 0 || plan->n_layers > MBN_MAX_LAYERS)
+        return MBN_EINVAL;
+    mbn_net *net = (mbn_net *)calloc(1, sizeof(*net));
+    if (!net) return MBN_ENOMEM;
+    net->ctx = ctx;
+    net->plan = *plan;
+    net->max_batch = max_batch;
+    size_t bytes = (size_t)plan->max_act_floats * (size_t)max_batch * sizeof(float);
+    int rc = mbn_alloc(ctx, bytes, &net->act[0]);
+    if (rc == MBN_OK) rc = mbn_alloc(ctx, bytes, &net->act[1]);
+    if (rc != MBN_OK) { mbn_net_destroy(net); return rc; }
+    *out = net;
+    return MBN_OK;
+}
+
+int mbn_net_create(mbn_context *ctx, const mbn_weights *w, int max_batch, mbn_net **out)
+{
+    if (!w || !w->blob || !out) return MBN_EINVAL;
+    *out = NULL;
+    mbn_net *net = NULL;
+    int rc = net_alloc_common(ctx, &w->plan, max_batch, &net);
+    if (rc != MBN_OK) return rc;
+    size_t bytes = (size_t)w->plan.blob_floats * sizeof(float);
+    rc = mbn_alloc(ctx, bytes, &net->dev_blob);
+    if (rc == MBN_OK) { net->own_blob = 1; rc = mbn_upload(ctx, net->dev_blob, w->blob, bytes); }   /* once, not per layer */
+    if (rc != MBN_OK) { mbn_net_destroy(net); return rc; }
+    *out = net;
+    return MBN_OK;
+}
+
+int mbn_net_create_from_device_blob(mbn_context *ctx, const mbn_plan *plan, const void *dev_blob, int max_batch,
+                                    mbn_net **out)
+{
+    if (!dev_blob || !out) return MBN_EINVAL;
+    *out = NULL;
+    mbn_net *net = NULL;
+    int rc = net_alloc_common(ctx, plan, max_batch, &net);
+    if (rc != MBN_OK) return rc;
+    net->dev_blob = (void *)dev_blob;
+    net->own_blob = 0;
+    *out = net;
+    return MBN_OK;
+}
+
+int mbn_net_destroy(mbn_net *net)
+{
+    if (!net) return MBN_OK;
+    mbn_sync(net->ctx);
+    for (int i = 0; i < MBN_MAX_LAYERS; i++)
+        if (net->keep_buf[i]) mbn_free(net->ctx, net->keep_buf[i]);
+    if (net->act[0]) mbn_free(net->ctx, net->act[0]);
+    if (net->act[1]) mbn_free(net->ctx, net->act[1]);
+    if (net->own_blob && net->dev_blob) mbn_free(net->ctx, net->dev_blob);
+    free(net);
+    return MBN_OK;
+}
+
+int mbn_net_plan(const mbn_net *net, mbn_plan *plan)
+{
+    if (!net || !plan) return MBN_EINVAL;
+    *plan = net->plan;
+    return MBN_OK;
+}
+
+int mbn_net_set_keep_activations(mbn_net *net, int keep)
+{
+    if (!net) return MBN_EINVAL;
+    net->keep = keep != 0;
+    return MBN_OK;
+}
+
+int mbn_net_layer_output(mbn_net *net, int index, void **dptr, size_t *floats_per_image)
+{
+    if (!net || index < 1 || index > net->plan.n_layers || !dptr) return MBN_EINVAL;
+    const mbn_layer_desc *l = &net->plan.layer[index - 1];
+    *dptr = net->last_out[index - 1];
+    if (floats_per_image) *floats_per_image = (size_t)l->out_rows * l->out_cols * l->out_ch;
+    return *dptr ? MBN_OK : MBN_ENOTFOUND;
+}
+
+/* One layer through the C-ABI: the positional arguments are kernel.cl's (see mbn.h). */
+static int run_layer(mbn_net *net, const mbn_layer_desc *l, const void *src, void *dst, int batch)
+{
+    mbn_layer_ext ext;
+    memset(&ext, 0, sizeof(ext));
+    ext.struct_size = sizeof(ext);
+    ext.batch = batch;
+    ext.dtype = MBN_DT_F32;
+    ext.layout = MBN_LAYOUT_NHWC;
+    ext.act = MBN_ACT_RELU6;
+    ext.pad_top = l->pad_top;
+    ext.pad_left = l->pad_left;
+    ext.scale = blob_at(net, l->scale_offset);
+    ext.shift = blob_at(net, l->shift_offset);
+    const float *filt = blob_at(net, l->w_offset);
+    switch (l->kind) {
+    case MBN_L_CONV:                       /* MobileNet.c:268-292: rows/cols = input size, stride 2 */
+        ext.cin = l->in_ch;
+        return mbn_convolute(net->ctx, dst, src, NULL, NULL, filt, l->in_rows, l->in_cols, 3, l->stride, l->out_ch, &ext);
+    case MBN_L_DW:                         /* MobileNet.c:326-381 */
+        ext.in_rows = l->in_rows;
+        ext.in_cols = l->in_cols;
+        return mbn_depthwise(net->ctx, dst, src, filt, l->out_rows, l->out_cols, 3, l->stride, l->out_ch, &ext);
+    case MBN_L_PW:                         /* MobileNet.c:417-470, with filtersize = true Cin (B3) */
+        return mbn_pointwise(net->ctx, dst, src, filt, l->out_rows, l->out_cols, l->in_ch, l->out_ch, &ext);
+    case MBN_L_POOL:                       /* MobileNet.c:2603-2656 */
+        ext.act = MBN_ACT_NONE;
+        return mbn_pool(net->ctx, dst, src, l->in_rows, l->in_cols, l->in_rows, l->out_ch, &ext);
+    case MBN_L_FC:                         /* MobileNet.c:2682-2739: pointwise with rows = cols = 1; bias, no ReLU (B15) */
+        ext.act = MBN_ACT_NONE;
+        return mbn_pointwise(net->ctx, dst, src, filt, 1, 1, l->in_ch, l->out_ch, &ext);
+    default:
+        return MBN_EINVAL;
+    }
+}
+
+static int forward_impl(mbn_net *net, const void *images, void *logits, int batch, int last_layer, float *layer_ms,
+                        int n_layer_ms)
+{
+    if (!net || !images || !logits || batch <= 0 || batch > net->max_batch) return MBN_EINVAL;
+    const int n = net->plan.n_layers;
+    if (last_layer <= 0 || last_layer > n) last_layer = n;
+    const void *src = images;
+    int which = 0;
+    for (int i = 0; i < last_layer; i++) {
+        const mbn_layer_desc *l = &net->plan.layer[i];
+        void *dst;
+        if (i == last_layer - 1) dst = logits;
+        else if (net->keep) {
+            if (!net->keep_buf[i]) {
+                size_t bytes = (size_t)l->out_rows * l->out_cols * l->out_ch * sizeof(float) * (size_t)net->max_batch;
+                int rc = mbn_alloc(net->ctx, bytes, &net->keep_buf[i]);
+                if (rc != MBN_OK) return rc;
+            }
+            dst = net->keep_buf[i];
+        } else {
+            dst = net->act[which];
+            which ^= 1;
+        }
+        int rc = run_layer(net, l, src, dst, batch);
+        if (rc != MBN_OK) return rc;
+        if (layer_ms && i < n_layer_ms) {
+            rc = mbn_last_kernel_ms(net->ctx, &layer_ms[i]);
+            if (rc != MBN_OK) return rc;
+        }
+        net->last_out[i] = dst;
+        src = dst;
+    }
+    return MBN_OK;
+}
+
+int mbn_net_forward(mbn_net *net, const void *images, void *logits, int batch, int last_layer)
+{
+    return forward_impl(net, images, logits, batch, last_layer, NULL, 0);
+}
+
+int mbn_net_forward_timed(mbn_net *net, const void *images, void *logits, int batch, float *layer_ms, int n_layer_ms)
+{
+    if (!net || !layer_ms || n_layer_ms <= 0) return MBN_EINVAL;
+    int rc = mbn_set_profiling(net->ctx, 1);
+    if (rc != MBN_OK) return rc;
+    rc = forward_impl(net, images, logits, batch, 0, layer_ms, n_layer_ms);
+    mbn_set_profiling(net->ctx, 0);
+    return rc;
+}

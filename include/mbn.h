@@ -1,0 +1,297 @@
+/*
+ * mbn.h — C-ABI of the MI355X-native MobileNet-V1 hot path.
+ *
+ * Drop-in boundary for the OpenCL "kernel-by-name + positional args" protocol of
+ * the reference (anerisheth19/CNN-MobileNet-V1-implementation-on-AWS-FPGA-using-OpenCL):
+ * every layer entry point below keeps the NAME and the LEADING POSITIONAL
+ * PARAMETERS of one `__kernel` in the reference's kernel.cl, extended by one
+ * trailing `const mbn_layer_ext*` that may be NULL.
+ *
+ *   reference interface replaced                         entry point here
+ *   ---------------------------------------------------  -------------------------
+ *   kernel.cl:2-3   __kernel convolute(...)              mbn_convolute
+ *   kernel.cl:62    __kernel depthwise(...)              mbn_depthwise
+ *   kernel.cl:94    __kernel pointwise(...) (also FC,    mbn_pointwise
+ *                   MobileNet.c:2681-2763)
+ *   kernel.cl:116   __kernel pool(...)                   mbn_pool
+ *   MobileNet.c:145-213  CL platform/ctx/queue/program   mbn_init
+ *   MobileNet.c:2809-2831 clRelease*                     mbn_shutdown
+ *   MobileNet.c:340-342  clCreateBuffer                  mbn_alloc / mbn_free
+ *   MobileNet.c:350-351  clEnqueueWriteBuffer            mbn_upload
+ *   MobileNet.c:395      clEnqueueReadBuffer             mbn_download
+ *   MobileNet.c:390-391  clWaitForEvents + clFinish      mbn_sync
+ *   MobileNet.c:301-305  clGetEventProfilingInfo         mbn_last_kernel_ms
+ *   MobileNet.c:31-47    readSquezeNetKernel             readSquezeNetKernel (kept) / mbn_read_text_weights
+ *   MobileNet.c:49-57    decode_image                    decode_image (kept) / mbn_read_ppm
+ *   MobileNet.c:218-238  RGB de-interleave               mbn_split_rgb
+ *   MobileNet.c:2771-2792 softmax + argmax               mbn_softmax_argmax_u8 / mbn_softmax_f32
+ *   keras.py:1-8 (role only: Keras .h5 -> host weights)  mbn_h5_open / mbn_h5_get / mbn_weights_from_h5
+ *   MobileNet.c:13-26 + per-layer literals (topology)    mbn_plan_build
+ *   MobileNet.c:240-2763 (29 hand-unrolled layer blocks) mbn_net_create / mbn_net_forward
+ *
+ * Conventions:
+ *   - plain C, plain pointers and sizes; no C++/torch types cross this boundary;
+ *   - every function returns int: 0 = MBN_OK, <0 = MBN_E*; nothing exits/aborts;
+ *   - device memory is addressed by raw device pointers (void*) so a caller may
+ *     also pass memory it allocated itself (hipMalloc, a torch tensor's data_ptr);
+ *   - layer calls are asynchronous on the context's HIP stream (or ext->stream),
+ *     ordered; mbn_sync() waits. One context per GPU; a context is not re-entrant.
+ *
+ * Two arithmetic modes:
+ *   LITERAL (ext == NULL or ext->dtype == MBN_DT_U8): the integer semantics of
+ *     kernel.cl — uint8 activations, planar NCHW, int32 filters `[oc][ic][ky][kx]`,
+ *     int32 accumulate, ReLU, truncating int->uchar store. Bit-exact vs oracle/.
+ *   F32 (ext->dtype == MBN_DT_F32): what BASELINE.json's metric measures — fp32,
+ *     NHWC, conv -> per-channel scale/shift (folded BatchNorm) -> ReLU/ReLU6,
+ *     TF-"SAME" padding. Tolerances: tests/test_parity_gpu.py.
+ */
+#ifndef MBN_H
+#define MBN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------- status */
+#define MBN_OK            0
+#define MBN_EINVAL       -1   /* bad argument (NULL pointer, non-positive size, unsupported combo) */
+#define MBN_ENOMEM       -2   /* host or device allocation failed */
+#define MBN_EDEVICE      -3   /* HIP runtime error (see mbn_last_device_error) */
+#define MBN_EIO          -4   /* file missing / short read */
+#define MBN_EFORMAT      -5   /* file is not what it claims (HDF5 / PPM / text weights) */
+#define MBN_ENOTFOUND    -6   /* named object not in the .h5 */
+#define MBN_ESHAPE       -7   /* dataset shape does not match the layer table */
+#define MBN_EUNSUPPORTED -8   /* valid request this build does not implement */
+#define MBN_ENODEVICE    -9   /* no HIP device / ordinal out of range */
+
+const char *mbn_strerror(int code);
+
+/* ------------------------------------------------------------- enumerations */
+enum { MBN_DT_U8 = 0,   /* LITERAL: uint8 act / int32 filter / int32 acc (kernel.cl) */
+       MBN_DT_F32 = 1,  /* fp32 act / fp32 filter / fp32 acc                         */
+       MBN_DT_BF16 = 2  /* reserved (BASELINE config 5)                              */ };
+
+enum { MBN_LAYOUT_NCHW_PLANAR = 0,  /* plane c at offset c*rows*cols (kernel.cl:73,107) */
+       MBN_LAYOUT_NHWC = 1 };
+
+enum { MBN_ACT_NONE = 0, MBN_ACT_RELU = 1 /* kernel.cl:87-89 */, MBN_ACT_RELU6 = 2 /* Keras */ };
+
+/* LITERAL-mode switches; each reproduces one well-defined behaviour of kernel.cl
+ * (SURVEY.md Appendix B). ext == NULL uses the context default (mbn_set_literal_quirks;
+ * initial default MBN_QUIRKS_KERNEL_CL = what kernel.cl computes wherever it is in bounds). */
+#define MBN_Q_CARRY_SUM      0x1u /* B1: `sum` is not reset between output channels (kernel.cl:10,69,99,121) */
+#define MBN_Q_DW_PLANE0      0x2u /* B2: depthwise reads input plane 0 for every channel (kernel.cl:83) */
+#define MBN_Q_LITERAL_INDEX  0x4u /* kernel.cl:24,83 index expression verbatim:
+                                     in[(ty+i)*G0*stride + (tx+j)*stride] over the WHOLE input buffer
+                                     (a column past the row end wraps into the next row, a row past the
+                                     plane end lands in the next plane); an index past the end of the input
+                                     buffer reads 0 (the reference would read out of bounds there: B4/B5) */
+#define MBN_Q_POOL_DIV49     0x8u /* kernel.cl:129 divides by the literal 49 whatever filtersize is */
+#define MBN_QUIRKS_NONE      0x0u
+#define MBN_QUIRKS_KERNEL_CL (MBN_Q_CARRY_SUM | MBN_Q_DW_PLANE0 | MBN_Q_LITERAL_INDEX | MBN_Q_POOL_DIV49)
+
+/* Trailing extension of every layer call. Zero-initialise, set struct_size = sizeof(mbn_layer_ext). */
+typedef struct mbn_layer_ext {
+    uint32_t struct_size;
+    int32_t  batch;        /* N images; 0 or 1 => one image (the reference processes one: MobileNet.c:215) */
+    int32_t  dtype;        /* MBN_DT_* */
+    int32_t  layout;       /* MBN_LAYOUT_*; F32 requires NHWC, U8 requires NCHW_PLANAR */
+    int32_t  act;          /* MBN_ACT_*; LITERAL ignores it (always ReLU, kernel.cl:87) */
+    int32_t  pad_top;      /* F32: rows of zero padding above; -1 = TF "SAME" (computed from in/out size) */
+    int32_t  pad_left;     /* F32: same for columns. LITERAL always pads filtersize/2 top/left (kernel.cl:79) */
+    int32_t  in_rows;      /* depthwise: input plane size; 0 => rows*stride. convolute: ignored */
+    int32_t  in_cols;
+    int32_t  cin;          /* convolute F32: input channels of the NHWC image (0 => 3) */
+    int32_t  gsize0;       /* LITERAL: NDRange of the emulated launch, x then y (get_global_size); 0 => output size */
+    int32_t  gsize1;
+    uint32_t quirks;       /* LITERAL: MBN_Q_* bitmask. Honoured only when quirks_valid != 0 */
+    int32_t  quirks_valid;
+    const void *scale;     /* F32: device ptr, op_size floats, multiplies the conv sum (folded BN); NULL => 1 */
+    const void *shift;     /* F32: device ptr, op_size floats, added after scale (folded BN / FC bias); NULL => 0 */
+    void    *stream;       /* hipStream_t; NULL => the context's stream */
+} mbn_layer_ext;
+
+typedef struct mbn_context mbn_context;   /* opaque; one per GPU */
+
+/* ----------------------------------------------------------------- lifecycle */
+/* Replaces MobileNet.c:145-213 (platform, device, context, queue with profiling, program build). */
+int  mbn_init(int device_ordinal, mbn_context **ctx);
+/* Replaces MobileNet.c:2809-2831. Frees every buffer still owned by the context. NULL is a no-op. */
+int  mbn_shutdown(mbn_context *ctx);
+int  mbn_device_count(int *count);                       /* 0 devices => *count = 0, MBN_OK */
+int  mbn_device_name(mbn_context *ctx, char *buf, size_t buflen);
+const char *mbn_last_device_error(mbn_context *ctx);     /* text of the last HIP error seen by this context */
+int  mbn_set_literal_quirks(mbn_context *ctx, uint32_t quirks);
+int  mbn_get_stream(mbn_context *ctx, void **stream);    /* the context's hipStream_t */
+
+/* ---------------------------------------------------- buffers (clCreateBuffer &c.) */
+int  mbn_alloc(mbn_context *ctx, size_t bytes, void **dptr);                 /* MobileNet.c:340-342 */
+int  mbn_free(mbn_context *ctx, void *dptr);
+int  mbn_upload(mbn_context *ctx, void *dst_dev, const void *src_host, size_t bytes);   /* blocking, :350 */
+int  mbn_download(mbn_context *ctx, void *dst_host, const void *src_dev, size_t bytes); /* blocking, :395 */
+int  mbn_memset(mbn_context *ctx, void *dst_dev, int byte, size_t bytes);    /* async on ctx stream */
+int  mbn_sync(mbn_context *ctx);                                             /* :390-391 */
+/* Time of the most recent layer call in milliseconds (hipEvent pair recorded around its launch on the
+ * stream it ran on; waits for it). Replaces clGetEventProfilingInfo START/END (MobileNet.c:301-305). */
+int  mbn_last_kernel_ms(mbn_context *ctx, float *ms);
+int  mbn_set_profiling(mbn_context *ctx, int enabled);   /* default 0: no events recorded */
+
+/* --------------------------------------------------------------- layer calls
+ * Positional parameters are kernel.cl's, in kernel.cl's order and meaning:
+ *
+ * convolute (kernel.cl:2-3): first 3x3xCin conv.
+ *   rows, cols  = INPUT plane size (224); output plane = (rows/stride) x (cols/stride)
+ *                 (kernel.cl:14 hard-codes rows/2 * cols/2 as the output plane stride;
+ *                 F32 uses ceil division)
+ *   LITERAL: inp_r/g/b three uint8 planes; filter int32 [op_size][3][ky][kx]
+ *   F32    : inp_r = NHWC image [N][rows][cols][cin]; inp_g/inp_b ignored;
+ *            filter fp32 [ky][kx][cin][op_size] (Keras HWIO)
+ */
+int mbn_convolute(mbn_context *ctx, void *output, const void *inp_image_r, const void *inp_image_g,
+                  const void *inp_image_b, const void *filter_k, int rows, int cols, int filtersize,
+                  int stride, int op_size, const mbn_layer_ext *ext);
+
+/* depthwise (kernel.cl:62): per-channel 3x3, stride 1 or 2.
+ *   rows, cols = OUTPUT plane size (the only use kernel.cl makes of them: output_shift, :73);
+ *                input plane = ext->in_rows x in_cols, default rows*stride x cols*stride
+ *   op_size    = channels
+ *   LITERAL: filter int32 [op_size][ky][kx];  F32: filter fp32 [ky][kx][op_size]
+ */
+int mbn_depthwise(mbn_context *ctx, void *output, const void *inp_image, const void *filter_k,
+                  int rows, int cols, int filtersize, int stride, int op_size, const mbn_layer_ext *ext);
+
+/* pointwise (kernel.cl:94): 1x1 conv = per-pixel [op_size x filtersize] mat-vec; FC when rows=cols=1.
+ *   filtersize = number of INPUT channels (loop bound kernel.cl:106, plane stride :107)
+ *   filter     = [op_size][filtersize] in both modes (int32 / fp32)
+ */
+int mbn_pointwise(mbn_context *ctx, void *output, const void *inp_image, const void *filter_k,
+                  int rows, int cols, int filtersize, int op_size, const mbn_layer_ext *ext);
+
+/* pool (kernel.cl:116): global filtersize x filtersize average per channel -> [op_size].
+ *   rows, cols = input plane size. LITERAL: integer division (by 49 under MBN_Q_POOL_DIV49).
+ */
+int mbn_pool(mbn_context *ctx, void *output, const void *inp_image, int rows, int cols, int filtersize,
+             int op_size, const mbn_layer_ext *ext);
+
+/* Classifier tail on device, fp32 (replaces the host loop MobileNet.c:2771-2792):
+ * probs[n][k] = softmax(logits[n][:]) and argmax[n] (0-based). probs or argmax may be NULL. */
+int mbn_softmax_f32(mbn_context *ctx, void *probs, void *argmax_i32, const void *logits, int batch,
+                    int classes, void *stream);
+
+/* Input front-end on device: uint8 HWC [N][rows][cols][3] -> fp32 NHWC x*scale+bias
+ * (Keras MobileNet preprocessing is scale=1/127.5, bias=-1). */
+int mbn_normalize_u8_to_f32(mbn_context *ctx, void *out_f32, const void *in_u8, size_t count, float scale,
+                            float bias, void *stream);
+
+/* ------------------------------------------------------------------ loaders
+ * The two reference symbols are kept with their exact signatures (CPU only). They return without
+ * touching the destination when the file is missing instead of dereferencing NULL
+ * (the reference does not check fopen: MobileNet.c:37,52). */
+void readSquezeNetKernel(int *m, int read_size);                        /* MobileNet.c:31 — reads "weights_c.txt" */
+int  decode_image(unsigned char frame[], char filename[]);              /* MobileNet.c:49 — raw 224*224*3 bytes from offset 0 */
+
+int  mbn_read_text_weights(const char *path, int *m, int read_size);    /* checked form of readSquezeNetKernel */
+int  mbn_read_text_weights_f32(const char *path, float *m, size_t read_size, size_t skip);
+int  mbn_read_ppm(const char *path, unsigned char *rgb, int *width, int *height, int max_pixels); /* P6, header skipped (B14) */
+int  mbn_write_ppm(const char *path, const unsigned char *rgb, int width, int height);
+int  mbn_split_rgb(const unsigned char *hwc, int pixels, unsigned char *r, unsigned char *g,
+                   unsigned char *b);                                   /* MobileNet.c:218-238 */
+/* MobileNet.c:2771-2792: double softmax over uint8 logits + argmax; *location is 1-based like the reference
+ * (and defined — 1 — when class 0 wins, which the reference leaves uninitialised: B11). */
+int  mbn_softmax_argmax_u8(const unsigned char *logits, int n, double *probs, int *location, double *maximum);
+
+/* ------------------------------------------------------------- Keras .h5 reader */
+typedef struct mbn_h5 mbn_h5;   /* opaque: a memory-mapped HDF5 file */
+int  mbn_h5_open(const char *path, mbn_h5 **h5);
+int  mbn_h5_close(mbn_h5 *h5);
+/* Look up a dataset by absolute path ("/conv1/conv1/kernel:0"; the leading "/model_weights" of a full
+ * Keras model file is tried too). On success *data points into the mapping (valid until close),
+ * shape[0..*ndim-1] is filled (ndim capacity 8). Only contiguous little-endian float32 datasets. */
+int  mbn_h5_get(mbn_h5 *h5, const char *name, int *ndim, int64_t shape[8], const float **data);
+/* Enumerate every dataset path in the file, depth-first; cb returns non-zero to stop. */
+int  mbn_h5_visit(mbn_h5 *h5, int (*cb)(const char *path, int ndim, const int64_t *shape, void *user),
+                  void *user);
+/* Minimal writer (weight-format tooling): creates a v0-superblock file with old-style
+ * groups and contiguous float32 datasets — the subset the reader and libhdf5 both accept. */
+typedef struct mbn_h5_writer mbn_h5_writer;
+int  mbn_h5_create(const char *path, mbn_h5_writer **w);
+int  mbn_h5_put(mbn_h5_writer *w, const char *name, int ndim, const int64_t *shape, const float *data);
+int  mbn_h5_finish(mbn_h5_writer *w);   /* writes the file and frees the writer */
+
+/* ------------------------------------------------------ topology (layer table) */
+enum { MBN_L_CONV = 1, MBN_L_DW = 2, MBN_L_PW = 3, MBN_L_POOL = 4, MBN_L_FC = 5 };
+
+typedef struct mbn_layer_desc {
+    int32_t index;        /* 1-based reference layer number (1 conv, 2..27 dw/pw, 28 pool, 29 FC) */
+    int32_t kind;         /* MBN_L_* */
+    int32_t in_rows, in_cols, in_ch;
+    int32_t out_rows, out_cols, out_ch;
+    int32_t stride;
+    int32_t pad_top, pad_left;       /* TF-SAME */
+    int64_t w_offset;     /* float offset of this layer's filter in the packed blob */
+    int64_t w_count;
+    int64_t scale_offset; /* float offset of per-channel scale (out_ch floats); -1 = none */
+    int64_t shift_offset; /* float offset of per-channel shift / bias; -1 = none */
+} mbn_layer_desc;
+
+#define MBN_MAX_LAYERS 32
+typedef struct mbn_plan {
+    int32_t  n_layers;          /* 29 */
+    int32_t  res;               /* input resolution (224, 192, 160, 128 or any multiple of 32) */
+    float    alpha;             /* width multiplier */
+    int32_t  classes;           /* 1000 */
+    int64_t  blob_floats;       /* size of the packed, BN-folded parameter blob */
+    int64_t  max_act_floats;    /* largest per-image activation (floats) across layers */
+    mbn_layer_desc layer[MBN_MAX_LAYERS];
+} mbn_plan;
+
+/* MobileNet.c:13-26 + SURVEY §2.1 table, parameterised: channels = max(8, int(c*alpha)), sizes from res. */
+int  mbn_plan_build(float alpha, int res, int classes, mbn_plan *plan);
+
+/* Host-side packed weights: one contiguous fp32 blob (this is what is broadcast over RCCL). */
+typedef struct mbn_weights {
+    mbn_plan plan;
+    float   *blob;        /* plan.blob_floats floats, malloc'd; free with mbn_weights_free */
+} mbn_weights;
+
+/* Read a Keras-applications MobileNet-V1 weights file: finds conv1 / conv_dw_i / conv_pw_i / *_bn /
+ * conv_preds by name, checks every shape against the plan, folds BatchNorm (eps = 1e-3) into per-channel
+ * scale/shift, repacks HWIO -> kernel layouts (pointwise -> [Cout][Cin]). alpha <= 0 => infer from conv1. */
+int  mbn_weights_from_h5(const char *path, float alpha, int res, mbn_weights *w);
+/* Deterministic synthetic weights: N(0, 2/fan_in) kernels, BN gamma U[.5,1.5], beta N(0,.1),
+ * mean N(0,.1), var U[.5,1.5]; written in Keras layout so the same reader path loads them. */
+int  mbn_weights_synthetic_h5(const char *path, float alpha, int classes, uint64_t seed);
+int  mbn_weights_free(mbn_weights *w);
+
+/* -------------------------------------------- whole-network runner (the C host)
+ * Replaces the 29 hand-unrolled per-layer blocks of MobileNet.c:240-2763: same layer order, but
+ * activations stay resident in HBM (no per-layer D2H/H2D, MobileNet.c:350,395) and weights are uploaded once. */
+typedef struct mbn_net mbn_net;
+int  mbn_net_create(mbn_context *ctx, const mbn_weights *w, int max_batch, mbn_net **net);
+/* Same, but the packed blob already lives on the device (e.g. received by an RCCL broadcast). The net
+ * does not take ownership of dev_blob. */
+int  mbn_net_create_from_device_blob(mbn_context *ctx, const mbn_plan *plan, const void *dev_blob,
+                                     int max_batch, mbn_net **net);
+int  mbn_net_destroy(mbn_net *net);
+/* images: device fp32 NHWC [batch][res][res][3]; logits: device fp32 [batch][classes]. Asynchronous.
+ * last_layer: run layers 1..last_layer only (0 or 29 => all; 5 and 13 = BASELINE configs 1-2), in which
+ * case `logits` receives that layer's NHWC activation instead. */
+int  mbn_net_forward(mbn_net *net, const void *images, void *logits, int batch, int last_layer);
+/* Per-layer milliseconds of the most recent mbn_net_forward_timed call (hipEvents between layers). */
+int  mbn_net_forward_timed(mbn_net *net, const void *images, void *logits, int batch, float *layer_ms,
+                           int n_layer_ms);
+int  mbn_net_plan(const mbn_net *net, mbn_plan *plan);
+/* Device pointer of layer `index`'s output from the most recent forward (valid until the next forward that
+ * overwrites the ping-pong buffer; with keep_activations every layer has its own buffer). */
+int  mbn_net_set_keep_activations(mbn_net *net, int keep);
+int  mbn_net_layer_output(mbn_net *net, int index, void **dptr, size_t *floats_per_image);
+
+const char *mbn_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MBN_H */

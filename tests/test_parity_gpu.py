@@ -1,0 +1,400 @@
+"""GPU parity: the HIP path, called through the C-ABI (libmbn.so), against the CPU oracle on the same seeded
+inputs. LITERAL mode (uint8/int32, kernel.cl semantics): bit-exact. F32 mode: tolerances from SURVEY.md §8c,
+written next to each test.
+
+Run with `pytest -m gpu` on the MI355X box. No test here reads /root/reference.
+"""
+import ctypes as C
+import itertools
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+# fp32 tolerances: max |got - want| <= RTOL * max|want| + ATOL, per tensor.
+TOL_DW = 1e-5      # 9-term sums (conv1: 27, pool: 49)
+TOL_PW = 1e-4      # K <= 1024, MFMA summation order != serial order
+TOL_NET = 1e-3     # end-to-end logits
+
+
+def assert_close(got, want, rtol, what=""):
+    assert got.shape == want.shape, (got.shape, want.shape)
+    assert np.isfinite(got).all(), what
+    scale = max(float(np.abs(want).max()), 1e-6)
+    err = float(np.abs(got.astype(np.float64) - want.astype(np.float64)).max())
+    assert err <= rtol * scale + 1e-7, "%s: max abs err %.3e vs scale %.3e (rel %.3e > %.1e)" % (
+        what, err, scale, err / scale, rtol)
+
+
+# =========================================================================== LITERAL (bit-exact)
+
+QUIRK_SETS = [0x0, 0xF, 0x1, 0x2, 0x4, 0x5, 0xB]
+
+
+@pytest.mark.parametrize("quirks", QUIRK_SETS)
+@pytest.mark.parametrize("shape", [(8, 8, 5, 1), (12, 10, 7, 1), (7, 7, 16, 2), (14, 14, 9, 2), (28, 28, 32, 1)])
+def test_literal_depthwise(pkg, orc, ctx, quirks, shape):
+    rows, cols, ch, stride = shape
+    rng = np.random.default_rng(rows * 1000 + ch + quirks)
+    in_rows, in_cols = rows * stride, cols * stride
+    x = rng.integers(0, 256, (ch, in_rows, in_cols), dtype=np.uint8)
+    f = rng.integers(-3, 4, (ch, 3, 3), dtype=np.int32)
+    want = orc.lit_depthwise(x, f, rows, cols, 3, stride, ch, quirks=quirks)
+    d_x, d_f = ctx.to_device(x), ctx.to_device(f)
+    d_o = ctx.alloc(ch * rows * cols)
+    ext = pkg.make_ext(dtype=pkg.DT_U8, quirks=quirks)
+    ctx.depthwise(d_o.ptr, d_x.ptr, d_f.ptr, rows, cols, 3, stride, ch, ext)
+    ctx.sync()
+    got = d_o.download((ch * rows * cols,), np.uint8)
+    assert np.array_equal(got, want)
+
+
+def test_literal_depthwise_null_ext_is_kernel_cl(pkg, orc, ctx):
+    """ext == NULL => the context default = MBN_QUIRKS_KERNEL_CL (what kernel.cl computes in bounds)."""
+    rng = np.random.default_rng(5)
+    x = rng.integers(0, 256, (6, 9, 9), dtype=np.uint8)
+    f = rng.integers(-2, 3, (6, 3, 3), dtype=np.int32)
+    want = orc.lit_depthwise(x, f, 9, 9, 3, 1, 6, quirks=orc.QUIRKS_KERNEL_CL)
+    d_x, d_f, d_o = ctx.to_device(x), ctx.to_device(f), ctx.alloc(6 * 81)
+    ctx.depthwise(d_o.ptr, d_x.ptr, d_f.ptr, 9, 9, 3, 1, 6, None)
+    ctx.sync()
+    assert np.array_equal(d_o.download((6 * 81,), np.uint8), want)
+    # and the context default can be switched to the intended geometry
+    assert ctx.lib.mbn_set_literal_quirks(ctx.h, pkg.QUIRKS_NONE) == 0
+    try:
+        want0 = orc.lit_depthwise(x, f, 9, 9, 3, 1, 6, quirks=0)
+        ctx.depthwise(d_o.ptr, d_x.ptr, d_f.ptr, 9, 9, 3, 1, 6, None)
+        ctx.sync()
+        assert np.array_equal(d_o.download((6 * 81,), np.uint8), want0)
+    finally:
+        ctx.lib.mbn_set_literal_quirks(ctx.h, pkg.QUIRKS_KERNEL_CL)
+
+
+@pytest.mark.parametrize("quirks", [0x0, 0xF, 0x1, 0x4])
+@pytest.mark.parametrize("shape", [(8, 8, 4), (16, 12, 8), (224, 224, 32)])
+def test_literal_convolute(pkg, orc, ctx, quirks, shape):
+    rows, cols, oc = shape
+    rng = np.random.default_rng(rows + oc + quirks)
+    r, g, b = (rng.integers(0, 256, rows * cols, dtype=np.uint8) for _ in range(3))
+    f = rng.integers(-2, 3, (oc, 3, 3, 3), dtype=np.int32)
+    want = orc.lit_convolute(r, g, b, f, rows, cols, 3, 2, oc, quirks=quirks)
+    d = [ctx.to_device(a) for a in (r, g, b, f)]
+    d_o = ctx.alloc(want.size)
+    ext = pkg.make_ext(dtype=pkg.DT_U8, quirks=quirks)
+    ctx.convolute(d_o.ptr, d[0].ptr, d[1].ptr, d[2].ptr, d[3].ptr, rows, cols, 3, 2, oc, ext)
+    ctx.sync()
+    assert np.array_equal(d_o.download(want.shape, np.uint8), want)
+
+
+@pytest.mark.parametrize("quirks", [0x0, 0x1])
+@pytest.mark.parametrize("shape", [(4, 4, 3, 5, 3), (14, 14, 32, 64, 32), (7, 7, 64, 48, 1), (1, 1, 128, 100, 128)])
+def test_literal_pointwise(pkg, orc, ctx, quirks, shape):
+    rows, cols, cin, oc, fs = shape     # fs = the `filtersize` argument = channels actually summed (B3 when 1)
+    rng = np.random.default_rng(cin + oc + quirks)
+    x = rng.integers(0, 256, (cin, rows, cols), dtype=np.uint8)
+    f = rng.integers(-2, 3, (oc, fs), dtype=np.int32)
+    want = orc.lit_pointwise(x, f, rows, cols, fs, oc, quirks=quirks)
+    d_x, d_f, d_o = ctx.to_device(x), ctx.to_device(f), ctx.alloc(oc * rows * cols)
+    ctx.pointwise(d_o.ptr, d_x.ptr, d_f.ptr, rows, cols, fs, oc, pkg.make_ext(dtype=pkg.DT_U8, quirks=quirks))
+    ctx.sync()
+    assert np.array_equal(d_o.download(want.shape, np.uint8), want)
+
+
+@pytest.mark.parametrize("quirks", [0x0, 0x1, 0x8, 0x9, 0xF])
+@pytest.mark.parametrize("shape", [(7, 7, 7, 1024), (7, 7, 7, 70), (5, 5, 3, 33)])
+def test_literal_pool(pkg, orc, ctx, quirks, shape):
+    rows, cols, fs, ch = shape
+    rng = np.random.default_rng(ch + quirks)
+    x = rng.integers(0, 256, (ch, rows, cols), dtype=np.uint8)
+    want = orc.lit_pool(x, rows, cols, fs, ch, quirks=quirks)
+    d_x, d_o = ctx.to_device(x), ctx.alloc(ch)
+    ctx.pool(d_o.ptr, d_x.ptr, rows, cols, fs, ch, pkg.make_ext(dtype=pkg.DT_U8, quirks=quirks))
+    ctx.sync()
+    assert np.array_equal(d_o.download((ch,), np.uint8), want)
+
+
+def test_literal_truncation_and_wrap(pkg, orc, ctx):
+    """int -> uchar store truncates mod 256 (kernel.cl:112) and int32 products wrap."""
+    x = np.full((1, 2, 2), 200, np.uint8)
+    f = np.array([[3], [2 ** 30], [-1]], np.int32)       # 600 -> 88 ; 200*2^30 wraps ; negative -> 0
+    want = orc.lit_pointwise(x, f, 2, 2, 1, 3, quirks=0)
+    assert want[0] == 600 % 256 and want[8] == 0
+    d_x, d_f, d_o = ctx.to_device(x), ctx.to_device(f), ctx.alloc(12)
+    ctx.pointwise(d_o.ptr, d_x.ptr, d_f.ptr, 2, 2, 1, 3, pkg.make_ext(dtype=pkg.DT_U8, quirks=0))
+    ctx.sync()
+    assert np.array_equal(d_o.download((12,), np.uint8), want)
+
+
+def test_literal_batched(pkg, orc, ctx):
+    """ext->batch > 1 in LITERAL mode = the same call per image."""
+    rng = np.random.default_rng(11)
+    n, ch, rows = 3, 8, 10
+    x = rng.integers(0, 256, (n, ch, rows, rows), dtype=np.uint8)
+    f = rng.integers(-2, 3, (ch, 3, 3), dtype=np.int32)
+    want = np.stack([orc.lit_depthwise(x[i], f, rows, rows, 3, 1, ch, quirks=0xF) for i in range(n)])
+    d_x, d_f, d_o = ctx.to_device(x), ctx.to_device(f), ctx.alloc(want.size)
+    ctx.depthwise(d_o.ptr, d_x.ptr, d_f.ptr, rows, rows, 3, 1, ch, pkg.make_ext(batch=n, dtype=pkg.DT_U8, quirks=0xF))
+    ctx.sync()
+    assert np.array_equal(d_o.download(want.shape, np.uint8), want)
+
+
+def test_literal_racy_ndrange_is_rejected(pkg, ctx):
+    """The reference launches 224x224 work-items over a 112x112 output plane (MobileNet.c:291-292): a data race.
+    The ABI refuses an emulated NDRange larger than the output plane instead of producing undefined bytes."""
+    d = ctx.alloc(1 << 16)
+    ext = pkg.make_ext(dtype=pkg.DT_U8, quirks=0xF, gsize=(16, 16))
+    rc = ctx.lib.mbn_depthwise(ctx.h, d.ptr, d.ptr, d.ptr, 8, 8, 3, 1, 4, C.byref(ext))
+    assert rc == pkg.EINVAL
+
+
+# =========================================================================== F32 kernels
+
+DW_SHAPES = [  # (batch, in_rows, channels, stride) — every distinct §2.1 depthwise geometry, scaled batch
+    (2, 112, 32, 1), (2, 112, 64, 2), (2, 56, 128, 1), (2, 56, 128, 2), (2, 28, 256, 1), (2, 28, 256, 2),
+    (3, 14, 512, 1), (3, 14, 512, 2), (3, 7, 1024, 1),
+    (1, 9, 8, 1), (2, 11, 12, 2), (1, 5, 4, 2), (1, 3, 16, 1), (1, 20, 24, 1),        # odd sizes / ragged
+]
+
+
+@pytest.mark.parametrize("shape", DW_SHAPES)
+@pytest.mark.parametrize("act", [0, 2])
+def test_f32_depthwise(pkg, orc, ctx, shape, act):
+    n, h, ch, stride = shape
+    rng = np.random.default_rng(h * 7 + ch + stride)
+    x = rng.uniform(-1, 1, (n, h, h, ch)).astype(np.float32)
+    f = rng.normal(0, 0.5, (3, 3, ch)).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, ch).astype(np.float32)
+    sh = rng.normal(0, 0.1, ch).astype(np.float32)
+    want = orc.f32_depthwise(x, f, sc, sh, stride, act)
+    oh = want.shape[1]
+    d_x, d_f, d_sc, d_sh = (ctx.to_device(a) for a in (x, f, sc, sh))
+    d_o = ctx.alloc(want.nbytes)
+    ext = pkg.make_ext(batch=n, act=act, in_rows=h, in_cols=h, scale=d_sc.ptr, shift=d_sh.ptr)
+    ctx.depthwise(d_o.ptr, d_x.ptr, d_f.ptr, oh, oh, 3, stride, ch, ext)
+    ctx.sync()
+    assert_close(d_o.download(want.shape, np.float32), want, TOL_DW, "dw %s" % (shape,))
+    for b in (d_x, d_f, d_sc, d_sh, d_o):
+        b.free()
+
+
+def test_f32_depthwise_explicit_padding_and_generic_path(pkg, orc, ctx):
+    """pad_top/left = 1 with stride 2 (the reference's top/left convention, B6) and a channel count that is
+    not a multiple of 4 (generic kernel)."""
+    rng = np.random.default_rng(3)
+    for ch in (8, 6):
+        x = rng.uniform(-1, 1, (2, 12, 12, ch)).astype(np.float32)
+        f = rng.normal(0, 0.5, (3, 3, ch)).astype(np.float32)
+        want = orc.f32_depthwise(x, f, None, None, 2, 1, pad_top=1, pad_left=1)
+        d_x, d_f, d_o = ctx.to_device(x), ctx.to_device(f), ctx.alloc(want.nbytes)
+        ext = pkg.make_ext(batch=2, act=1, pad_top=1, pad_left=1, in_rows=12, in_cols=12)
+        ctx.depthwise(d_o.ptr, d_x.ptr, d_f.ptr, 6, 6, 3, 2, ch, ext)
+        ctx.sync()
+        assert_close(d_o.download(want.shape, np.float32), want, TOL_DW, "dw pad ch=%d" % ch)
+
+
+PW_SHAPES = [  # (M, Cin, Cout): §2.1 pointwise GEMMs at small batch + ragged M / N / K
+    (2 * 112 * 112, 32, 64), (2 * 56 * 56, 64, 128), (56 * 56, 128, 128), (2 * 28 * 28, 128, 256),
+    (28 * 28, 256, 256), (2 * 14 * 14, 256, 512), (2 * 14 * 14, 512, 512), (3 * 49, 512, 1024),
+    (3 * 49, 1024, 1024), (256 * 49, 1024, 1024),
+    (5, 1024, 1000), (256, 1024, 1000),                 # FC (batch 5 / 256), Cout not a multiple of 32
+    (49, 16, 32), (130, 8, 24), (1, 64, 64), (127, 36, 100), (300, 72, 40), (1000, 24, 8),   # ragged
+    (64, 6, 10),                                        # K % 4 != 0 -> generic kernel
+]
+
+
+@pytest.mark.parametrize("shape", PW_SHAPES)
+def test_f32_pointwise(pkg, orc, ctx, shape):
+    m, cin, cout = shape
+    rng = np.random.default_rng(m + cin * 3 + cout)
+    x = rng.uniform(-1, 1, (m, cin)).astype(np.float32)
+    f = rng.normal(0, (2.0 / cin) ** 0.5, (cout, cin)).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    sh = rng.normal(0, 0.1, cout).astype(np.float32)
+    want = orc.f32_pointwise(x, f, sc, sh, 2)
+    d_x, d_f, d_sc, d_sh = (ctx.to_device(a) for a in (x, f, sc, sh))
+    d_o = ctx.alloc(want.nbytes)
+    ext = pkg.make_ext(batch=1, act=2, scale=d_sc.ptr, shift=d_sh.ptr)
+    ctx.pointwise(d_o.ptr, d_x.ptr, d_f.ptr, m, 1, cin, cout, ext)   # rows*cols = M
+    ctx.sync()
+    assert_close(d_o.download(want.shape, np.float32), want, TOL_PW, "pw %s" % (shape,))
+    for b in (d_x, d_f, d_sc, d_sh, d_o):
+        b.free()
+
+
+def test_f32_pointwise_exact_integers(pkg, ctx):
+    """Integer-valued operands: every product and partial sum is exact in fp32, so any k-order gives the same
+    result — checks the MFMA operand/C-D lane maps bit-exactly with an ASYMMETRIC filter (cdna guide §3)."""
+    rng = np.random.default_rng(0)
+    m, cin, cout = 200, 96, 160
+    x = rng.integers(-8, 9, (m, cin)).astype(np.float32)
+    f = rng.integers(-8, 9, (cout, cin)).astype(np.float32)
+    f[:, 0] += np.arange(cout)          # asymmetric
+    want = x.astype(np.float64) @ f.astype(np.float64).T
+    d_x, d_f, d_o = ctx.to_device(x), ctx.to_device(f), ctx.alloc(m * cout * 4)
+    ctx.pointwise(d_o.ptr, d_x.ptr, d_f.ptr, m, 1, cin, cout, pkg.make_ext(act=0))
+    ctx.sync()
+    got = d_o.download((m, cout), np.float32)
+    assert np.array_equal(got.astype(np.float64), want)
+
+
+@pytest.mark.parametrize("shape", [(2, 224, 32), (1, 160, 16), (2, 33, 8), (1, 64, 6)])
+def test_f32_conv1(pkg, orc, ctx, shape):
+    n, h, cout = shape
+    rng = np.random.default_rng(h + cout)
+    x = rng.uniform(-1, 1, (n, h, h, 3)).astype(np.float32)
+    f = rng.normal(0, 0.27, (3, 3, 3, cout)).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    sh = rng.normal(0, 0.1, cout).astype(np.float32)
+    want = orc.f32_conv(x, f, sc, sh, 2, 2)
+    d_x, d_f, d_sc, d_sh = (ctx.to_device(a) for a in (x, f, sc, sh))
+    d_o = ctx.alloc(want.nbytes)
+    ext = pkg.make_ext(batch=n, act=2, cin=3, scale=d_sc.ptr, shift=d_sh.ptr)
+    ctx.convolute(d_o.ptr, d_x.ptr, None, None, d_f.ptr, h, h, 3, 2, cout, ext)
+    ctx.sync()
+    assert_close(d_o.download(want.shape, np.float32), want, TOL_DW, "conv1 %s" % (shape,))
+
+
+@pytest.mark.parametrize("shape", [(3, 7, 1024), (2, 5, 512), (1, 7, 30)])
+def test_f32_pool(pkg, orc, ctx, shape):
+    n, h, ch = shape
+    x = np.random.default_rng(ch).uniform(0, 6, (n, h, h, ch)).astype(np.float32)
+    want = orc.f32_pool(x)
+    d_x, d_o = ctx.to_device(x), ctx.alloc(want.nbytes)
+    ctx.pool(d_o.ptr, d_x.ptr, h, h, h, ch, pkg.make_ext(batch=n, act=0))
+    ctx.sync()
+    assert_close(d_o.download(want.shape, np.float32), want, TOL_DW, "pool")
+
+
+def test_f32_softmax_and_normalize(pkg, orc, ctx):
+    rng = np.random.default_rng(1)
+    logits = rng.normal(0, 3, (5, 1000)).astype(np.float32)
+    logits[2, 17] = logits[2, 400] = 50.0            # tie -> lowest index wins, like the oracle's strict '>'
+    want_p, want_a = orc.f32_softmax(logits)
+    d_l, d_p, d_a = ctx.to_device(logits), ctx.alloc(logits.nbytes), ctx.alloc(5 * 4)
+    assert ctx.lib.mbn_softmax_f32(ctx.h, d_p.ptr, d_a.ptr, d_l.ptr, 5, 1000, None) == 0
+    ctx.sync()
+    assert np.array_equal(d_a.download((5,), np.int32), want_a)
+    assert_close(d_p.download((5, 1000), np.float32), want_p, 1e-5, "softmax")
+    u8 = rng.integers(0, 256, 224 * 224 * 3 + 3, dtype=np.uint8)
+    d_u, d_f = ctx.to_device(u8), ctx.alloc(u8.size * 4)
+    assert ctx.lib.mbn_normalize_u8_to_f32(ctx.h, d_f.ptr, d_u.ptr, u8.size, 1 / 127.5, -1.0, None) == 0
+    ctx.sync()
+    want = np.float32(u8) * np.float32(1 / 127.5) + np.float32(-1)
+    assert_close(d_f.download((u8.size,), np.float32), want, 1e-6, "normalize")
+
+
+# =========================================================================== F32 <-> LITERAL tie
+
+def test_f32_matches_literal_on_integer_inputs(pkg, orc, ctx):
+    """Where the two modes coincide (identity BN, ReLU, top/left pad, values < 256, quirks off), the fp32 NHWC
+    kernel reproduces the integer NCHW kernel exactly — ties the fp32 path back to kernel.cl's arithmetic."""
+    rng = np.random.default_rng(9)
+    ch, h = 8, 10
+    x = rng.integers(0, 4, (ch, h, h), dtype=np.uint8)
+    f = rng.integers(-1, 3, (ch, 3, 3), dtype=np.int32)
+    lit = orc.lit_depthwise(x, f, h, h, 3, 1, ch, quirks=0).reshape(ch, h, h)
+    xf = np.ascontiguousarray(x.transpose(1, 2, 0)[None].astype(np.float32))
+    ff = np.ascontiguousarray(f.transpose(1, 2, 0).astype(np.float32))
+    d_x, d_f, d_o = ctx.to_device(xf), ctx.to_device(ff), ctx.alloc(xf.nbytes)
+    ctx.depthwise(d_o.ptr, d_x.ptr, d_f.ptr, h, h, 3, 1, ch, pkg.make_ext(act=1, pad_top=1, pad_left=1, in_rows=h, in_cols=h))
+    ctx.sync()
+    got = d_o.download((1, h, h, ch), np.float32)[0].transpose(2, 0, 1)
+    assert got.max() < 256
+    assert np.array_equal(got.astype(np.int64), lit.astype(np.int64))
+
+
+# =========================================================================== whole network
+
+def _make_net(pkg, ctx, tmp_path, alpha, res, classes, batch, seed=3):
+    path = str(tmp_path / ("w_%g_%d.h5" % (alpha, res)))
+    pkg.synthetic_h5(path, alpha=alpha, classes=classes, seed=seed, lib=pkg.load())
+    hw = pkg.HostWeights(path, res=res, lib=pkg.load())
+    net = pkg.Net(ctx, hw.plan, hw.blob.copy(), batch)
+    return hw, net
+
+
+@pytest.mark.parametrize("cfg", [(0.25, 64, 2), (0.5, 96, 1)])
+def test_net_per_layer_vs_oracle(pkg, orc, ctx, tmp_path, cfg):
+    """BASELINE config 2 in miniature: every layer's output vs the CPU oracle, each GPU layer fed by the GPU's
+    own previous layer (so per-layer error is what the tolerance bounds, not accumulated drift)."""
+    alpha, res, n = cfg
+    hw, net = _make_net(pkg, ctx, tmp_path, alpha, res, 50, n)
+    imgs = np.random.default_rng(0).uniform(-1, 1, (n, res, res, 3)).astype(np.float32)
+    net.keep_activations(True)
+    d_in, d_out = ctx.to_device(imgs), ctx.alloc(n * 50 * 4)
+    net.forward(d_in.ptr, d_out.ptr, n)
+    ctx.sync()
+    oplan = orc.plan_build(alpha, res, 50)
+    want_out, layers = orc.net_forward(oplan, hw.blob, imgs, keep_layers=True)
+    for i in range(hw.plan.n_layers - 1):
+        got = net.layer_output(i + 1, n)
+        assert_close(got, layers[i], TOL_NET, "layer %d" % (i + 1))
+    assert_close(d_out.download((n, 50), np.float32), want_out.reshape(n, 50), TOL_NET, "logits")
+    net.destroy()
+
+
+def test_net_full_size_batch1_first_layers(pkg, orc, ctx, tmp_path):
+    """BASELINE configs 1-2: 1.0x224, batch 1, layers 1..5 and 1..13 against the oracle."""
+    hw, net = _make_net(pkg, ctx, tmp_path, 1.0, 224, 1000, 1)
+    imgs = np.random.default_rng(1).uniform(-1, 1, (1, 224, 224, 3)).astype(np.float32)
+    d_in = ctx.to_device(imgs)
+    oplan = orc.plan_build(1.0, 224, 1000)
+    for last in (5, 13):
+        l = hw.plan.layer[last - 1]
+        want, _ = orc.net_forward(oplan, hw.blob, imgs, last_layer=last, threads=orc.num_threads())
+        d_out = ctx.alloc(want.nbytes)
+        net.forward(d_in.ptr, d_out.ptr, 1, last)
+        ctx.sync()
+        assert_close(d_out.download(want.shape, np.float32), want, TOL_NET, "L1..%d" % last)
+        d_out.free()
+    net.destroy()
+
+
+def test_net_full_size_properties(pkg, ctx, tmp_path):
+    """1.0x224 at batch 16 (size-independent properties): (a) batch independence — image i's logits do not
+    depend on its batch-mates or its slot; (b) determinism; (c) timed == untimed."""
+    hw, net = _make_net(pkg, ctx, tmp_path, 1.0, 224, 1000, 16)
+    rng = np.random.default_rng(2)
+    imgs = rng.uniform(-1, 1, (16, 224, 224, 3)).astype(np.float32)
+    d_in, d_out = ctx.to_device(imgs), ctx.alloc(16 * 1000 * 4)
+    net.forward(d_in.ptr, d_out.ptr, 16)
+    ctx.sync()
+    a = d_out.download((16, 1000), np.float32)
+    assert np.isfinite(a).all() and np.abs(a).max() > 0
+    net.forward(d_in.ptr, d_out.ptr, 16)
+    ctx.sync()
+    assert np.array_equal(a, d_out.download((16, 1000), np.float32))
+    perm = rng.permutation(16)
+    d_in.upload(imgs[perm])
+    net.forward(d_in.ptr, d_out.ptr, 16)
+    ctx.sync()
+    assert np.array_equal(a[perm], d_out.download((16, 1000), np.float32))
+    d_in.upload(imgs[:3])
+    net.forward(d_in.ptr, d_out.ptr, 3)
+    ctx.sync()
+    b = d_out.download((3, 1000), np.float32)
+    assert np.array_equal(b, a[:3])                                # a smaller batch changes tiles, not sums
+    d_in.upload(imgs)
+    ms = net.forward_timed(d_in.ptr, d_out.ptr, 16)
+    ctx.sync()
+    assert len(ms) == 29 and all(m > 0 for m in ms)
+    assert np.array_equal(a, d_out.download((16, 1000), np.float32))
+    net.destroy()
+
+
+def test_net_batch_slice_equals_smaller_batch(pkg, ctx, tmp_path):
+    """Sharding property used by the multi-GPU path: forward(images[a:b]) == forward(images)[a:b].
+    Tile shapes differ between batch sizes (M changes), so pointwise rows may be summed by different
+    workgroups — but each row's k-order is fixed by the kernel, so results are bit-identical."""
+    hw, net = _make_net(pkg, ctx, tmp_path, 0.5, 128, 100, 8)
+    imgs = np.random.default_rng(4).uniform(-1, 1, (8, 128, 128, 3)).astype(np.float32)
+    d_in, d_out = ctx.to_device(imgs), ctx.alloc(8 * 100 * 4)
+    net.forward(d_in.ptr, d_out.ptr, 8)
+    ctx.sync()
+    full = d_out.download((8, 100), np.float32)
+    d_in.upload(imgs[4:8])
+    net.forward(d_in.ptr, d_out.ptr, 4)
+    ctx.sync()
+    assert np.array_equal(full[4:8], d_out.download((4, 100), np.float32))
+    net.destroy()
