@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""bench.py — images/sec of the MobileNet-V1 hot path on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus 1 --steps K --warmup W            one GPU
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W            one rank per GPU (RCCL)
+
+A "step" = one forward of all 29 layers (MobileNet.c:240-2763 order) over one batch of synthetic 224x224x3 fp32
+images that is already resident in HBM. Workload at N=1 = BASELINE.json configs[2]: MobileNet-V1 1.0x224, fp32,
+batch 256. With N ranks every rank runs the same per-GPU batch on its own images (weak scaling, independent images:
+no data-path collective); the packed parameter blob is broadcast once from rank 0 over RCCL before timing.
+
+Prints ONE JSON line on rank 0. Extra objects:
+  roofline      the dominant kernel (pw_gemm_f32: the 13 pointwise GEMMs): algorithmic FLOPs per launch / average
+                launch duration measured with HIP events on the kernel's stream over the timed region, vs the fp32
+                MFMA peak 157.3 TFLOP/s (MI355X_MICROARCH.md). `stages` carries the same for every stage group,
+                depthwise against the 8 TB/s HBM peak.
+  cpu_baseline  the oracle's C restatement (kind "port": the reference has no CPU path and cannot be built here)
+                timed on this box's host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix peak
+
+
+def layer_work(l, batch, pkg):
+    """Algorithmic FLOPs and HBM bytes of one layer launch (input read once, output
+    written once, fp32; weights counted once per launch)."""
+    in_b = 4.0 * l.in_rows * l.in_cols * l.in_ch * batch
+    out_b = 4.0 * l.out_rows * l.out_cols * l.out_ch * batch
+    px = float(l.out_rows * l.out_cols * batch)
+    if l.kind == pkg.L_CONV:
+        flops, w = 2.0 * 27 * l.out_ch * px, 4.0 * 27 * l.out_ch
+    elif l.kind == pkg.L_DW:
+        flops, w = 2.0 * 9 * l.out_ch * px, 4.0 * 9 * l.out_ch
+    elif l.kind in (pkg.L_PW, pkg.L_FC):
+        flops, w = 2.0 * l.in_ch * l.out_ch * px, 4.0 * l.in_ch * l.out_ch
+    else:
+        flops, w = float(l.in_rows * l.in_cols * l.in_ch * batch), 0.0
+    return flops, in_b + out_b + w
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
+    ap.add_argument("--alpha", type=float, default=1.0)
+    ap.add_argument("--res", type=int, default=224)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-images", type=int, default=0, help="images in the CPU baseline sample (0 = auto)")
+    ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        args.gpus = world
+
+    import numpy as np
+    import torch   # device plumbing only: RCCL broadcast, barrier, device-wide synchronize
+    import torch.distributed as dist
+
+    from mbn_amd import import_package
+    pkg = import_package()
+    lib = pkg.load()          # raises if the HIP extension is missing: no fallback
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm
+
+    # ---- parameters: rank 0 writes a synthetic Keras-layout .h5 and reads it back through the real loader
+    plan = pkg.plan_build(args.alpha, args.res, 1000, lib=lib)
+    blob_t = torch.empty(plan.blob_floats, dtype=torch.float32, device=dev)
+    if rank == 0:
+        path = "/tmp/mbn_bench_%d.h5" % os.getpid()
+        pkg.synthetic_h5(path, alpha=args.alpha, classes=1000, seed=0xC0FFEE, lib=lib)
+        hw = pkg.HostWeights(path, alpha=args.alpha, res=args.res, lib=lib)
+        os.remove(path)
+        assert hw.plan.blob_floats == plan.blob_floats
+        blob_t.copy_(torch.from_numpy(hw.blob))
+        hw.free()
+    if world > 1:
+        dist.broadcast(blob_t, src=0)      # the one collective of the path: ~17 MB over xGMI, off the timed path
+    torch.cuda.synchronize()
+
+    ctx = pkg.Context(local_rank)
+    net = pkg.Net(ctx, plan, blob_t.data_ptr(), args.batch)
+
+    # ---- synthetic input, U[-1,1) (Keras x/127.5-1 range), generated on the host then uploaded once
+    rng = np.random.default_rng(0xC0FFEE + rank)
+    imgs = rng.random((args.batch, args.res, args.res, 3), dtype=np.float32) * 2.0 - 1.0
+    d_in = ctx.to_device(imgs)
+    del imgs
+    d_out = ctx.alloc(args.batch * 1000 * 4)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        net.forward(d_in.ptr, d_out.ptr, args.batch)
+    ctx.sync()
+
+    n_layers = plan.n_layers
+    profile = not args.no_profile
+    if profile:
+        ctx.profile_begin(n_layers * args.steps)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        net.forward(d_in.ptr, d_out.ptr, args.batch)
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    layer_ms = None
+    if profile:
+        ms = ctx.profile_end(n_layers * args.steps)
+        arr = np.asarray(ms, dtype=np.float64).reshape(args.steps, n_layers)
+        layer_ms = arr.mean(axis=0)
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    logits = d_out.download((args.batch, 1000), np.float32)
+    if not np.isfinite(logits).all():
+        sys.exit("non-finite logits")
+
+    if rank == 0:
+        total_images = args.batch * world * args.steps
+        out = {
+            "metric": "images/sec MobileNet-V1 1.0x224 fp32, batch 256; per-stage HBM GB/s vs roofline",
+            "value": total_images / elapsed,
+            "unit": "images/sec",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1000.0 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "MobileNet-V1 %.2gx%d fp32, batch %d per GPU, 29 layers, 1000 classes "
+                                   "(BASELINE.json configs[2])" % (args.alpha, args.res, args.batch),
+                       "global_batch": args.batch * world, "per_gpu_batch": args.batch,
+                       "parallelism": "batch-sharded x%d, weights broadcast once over RCCL" % world,
+                       "device": ctx.name()},
+        }
+        if layer_ms is not None:
+            groups = {"conv1": [pkg.L_CONV], "depthwise": [pkg.L_DW], "pointwise": [pkg.L_PW], "pool": [pkg.L_POOL],
+                      "fc": [pkg.L_FC]}
+            stages, per_layer = {}, []
+            for i in range(n_layers):
+                l = plan.layer[i]
+                f, b = layer_work(l, args.batch, pkg)
+                per_layer.append({"layer": i + 1, "kind": int(l.kind), "ms": round(float(layer_ms[i]), 5),
+                                  "GBps": round(b / layer_ms[i] / 1e6, 1), "TFLOPs": round(f / layer_ms[i] / 1e9, 2)})
+            for name, kinds in groups.items():
+                idx = [i for i in range(n_layers) if plan.layer[i].kind in kinds]
+                fl = sum(layer_work(plan.layer[i], args.batch, pkg)[0] for i in idx)
+                by = sum(layer_work(plan.layer[i], args.batch, pkg)[1] for i in idx)
+                ms_sum = float(sum(layer_ms[i] for i in idx))
+                st = {"launches": len(idx), "ms": round(ms_sum, 4), "GBps": round(by / ms_sum / 1e6, 1),
+                      "TFLOPs": round(fl / ms_sum / 1e9, 2)}
+                st["frac_hbm"] = round(st["GBps"] / HBM_PEAK_GBS, 4)
+                st["frac_mfma"] = round(st["TFLOPs"] / MFMA_F32_PEAK_TFLOPS, 4)
+                stages[name] = st
+            pw = stages["pointwise"]
+            pw_idx = [i for i in range(n_layers) if plan.layer[i].kind == pkg.L_PW]
+            flops_per_launch = sum(layer_work(plan.layer[i], args.batch, pkg)[0] for i in pw_idx) / len(pw_idx)
+            avg_ms = pw["ms"] / len(pw_idx)
+            out["roofline"] = {
+                "kernel": "pw_gemm_f32 (13 pointwise 1x1 conv launches per step)",
+                "bound": "mfma", "achieved": round(flops_per_launch / avg_ms / 1e9, 2), "peak": MFMA_F32_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(flops_per_launch / avg_ms / 1e9 / MFMA_F32_PEAK_TFLOPS, 4),
+                "traffic": None, "avg_launch_ms": round(avg_ms, 5),
+                "algorithmic_flops_per_launch": flops_per_launch,
+            }
+            out["stages"] = stages
+            out["layers"] = per_layer
+            out["sum_kernel_ms"] = round(float(layer_ms.sum()), 4)
+        if world == 1 and not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import oracle as orc   # cpu_baseline leg: the oracle is the thing timed here, never the product path
+            oplan = orc.plan_build(args.alpha, args.res, 1000)
+            cores = orc.num_threads()
+            n_img = args.cpu_images or max(2, cores)
+            blob = blob_t.cpu().numpy()
+            sample = np.random.default_rng(1).random((n_img, args.res, args.res, 3), dtype=np.float32) * 2 - 1
+            c0 = time.perf_counter()
+            ref, _ = orc.net_forward(oplan, blob, sample, threads=cores)
+            c1 = time.perf_counter()
+            out["cpu_baseline"] = {"value": n_img / (c1 - c0), "unit": "images/sec", "cores": cores, "kind": "port",
+                                   "sample": "%d images, same network/weights, C restatement of kernel.cl semantics "
+                                             "in fp32 NHWC (oracle/mbn_oracle.c), OpenMP over output pixels, %.1f s"
+                                             % (n_img, c1 - c0)}
+        print(json.dumps(out))
+        sys.stdout.flush()
+
+    net.destroy()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -134,6 +134,8 @@ def load():
         lib.mbn_sync.argtypes = [vp]
         lib.mbn_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
         lib.mbn_set_profiling.argtypes = [vp, ci]
+        lib.mbn_profile_begin.argtypes = [vp, ci]
+        lib.mbn_profile_end.argtypes = [vp, C.POINTER(C.c_float), ci, C.POINTER(ci)]
         ext = C.POINTER(LayerExt)
         lib.mbn_convolute.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ext]
         lib.mbn_depthwise.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, ext]
@@ -254,6 +256,15 @@ class Context:
         s = C.c_void_p()
         _chk(self.lib.mbn_get_stream(self.h, C.byref(s)))
         return s.value or 0
+
+    def profile_begin(self, capacity: int):
+        _chk(self.lib.mbn_profile_begin(self.h, capacity))
+
+    def profile_end(self, capacity: int):
+        ms = (C.c_float * capacity)()
+        n = C.c_int()
+        _chk(self.lib.mbn_profile_end(self.h, ms, capacity, C.byref(n)), self.last_error())
+        return [ms[i] for i in range(n.value)]
 
     def close(self):
         if self.h:

@@ -74,6 +74,7 @@ int mbn_shutdown(mbn_context *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     for (auto &kv : ctx->allocs) (void)hipFree(kv.first);
     ctx->allocs.clear();
+    for (hipEvent_t e : ctx->pool) (void)hipEventDestroy(e);
     (void)hipEventDestroy(ctx->ev_start);
     (void)hipEventDestroy(ctx->ev_stop);
     (void)hipStreamDestroy(ctx->stream);
@@ -189,6 +190,33 @@ int mbn_last_kernel_ms(mbn_context *ctx, float *ms)
     return MBN_OK;
 }
 
+int mbn_profile_begin(mbn_context *ctx, int capacity)
+{
+    if (!ctx || capacity <= 0 || capacity > (1 << 20)) return MBN_EINVAL;
+    (void)hipSetDevice(ctx->device);
+    while ((int)ctx->pool.size() < 2 * capacity) {
+        hipEvent_t e;
+        MBN_HIP_TRY(ctx, hipEventCreate(&e));
+        ctx->pool.push_back(e);
+    }
+    ctx->pool_cap = capacity;
+    ctx->pool_used = 0;
+    ctx->pool_on = true;
+    return MBN_OK;
+}
+
+int mbn_profile_end(mbn_context *ctx, float *ms, int ms_capacity, int *count)
+{
+    if (!ctx || !ms || !count || ms_capacity < 0) return MBN_EINVAL;
+    ctx->pool_on = false;
+    (void)hipSetDevice(ctx->device);
+    MBN_HIP_TRY(ctx, hipDeviceSynchronize());
+    int n = ctx->pool_used < ms_capacity ? ctx->pool_used : ms_capacity;
+    for (int i = 0; i < n; i++) MBN_HIP_TRY(ctx, hipEventElapsedTime(&ms[i], ctx->pool[2 * i], ctx->pool[2 * i + 1]));
+    *count = n;
+    return MBN_OK;
+}
+
 }   // extern "C"
 
 // --------------------------------------------------------------------------- call resolution
@@ -198,13 +226,19 @@ namespace {
 struct Scope {   // hipEvent pair around one layer call when profiling is on (MobileNet.c:301-305 analogue)
     mbn_context *ctx;
     hipStream_t s;
+    int slot = -1;
     Scope(mbn_context *c, hipStream_t st) : ctx(c), s(st)
     {
         (void)hipSetDevice(ctx->device);
         if (ctx->profiling) (void)hipEventRecord(ctx->ev_start, s);
+        if (ctx->pool_on && ctx->pool_used < ctx->pool_cap) {
+            slot = ctx->pool_used++;
+            (void)hipEventRecord(ctx->pool[2 * slot], s);
+        }
     }
     int finish(int rc)
     {
+        if (slot >= 0) (void)hipEventRecord(ctx->pool[2 * slot + 1], s);
         if (ctx->profiling) {
             (void)hipEventRecord(ctx->ev_stop, s);
             ctx->ev_valid = true;

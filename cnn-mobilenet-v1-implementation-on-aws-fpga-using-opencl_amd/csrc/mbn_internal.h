@@ -8,6 +8,7 @@
 
 #include <mutex>
 #include <unordered_map>
+#include <vector>
 
 #include "mbn.h"
 
@@ -21,6 +22,9 @@ struct mbn_context {
     char last_error[256] = {0};
     char name[128] = {0};
     int num_cus = 256;
+    std::vector<hipEvent_t> pool;                // mbn_profile_begin/end: 2 events per recorded call
+    int pool_cap = 0, pool_used = 0;
+    bool pool_on = false;
     std::mutex mu;
     std::unordered_map<void *, size_t> allocs;   // buffers handed out by mbn_alloc
 };

@@ -138,6 +138,12 @@ int  mbn_sync(mbn_context *ctx);                                             /* 
  * stream it ran on; waits for it). Replaces clGetEventProfilingInfo START/END (MobileNet.c:301-305). */
 int  mbn_last_kernel_ms(mbn_context *ctx, float *ms);
 int  mbn_set_profiling(mbn_context *ctx, int enabled);   /* default 0: no events recorded */
+/* Event pool for measuring every layer call of a timed region without synchronising inside it:
+ * after mbn_profile_begin each layer call records a hipEvent pair on the stream it is launched on into the
+ * next free slot (calls beyond `capacity` are not recorded); mbn_profile_end waits for the stream and returns
+ * the per-call milliseconds in call order. */
+int  mbn_profile_begin(mbn_context *ctx, int capacity);
+int  mbn_profile_end(mbn_context *ctx, float *ms, int ms_capacity, int *count);
 
 /* --------------------------------------------------------------- layer calls
  * Positional parameters are kernel.cl's, in kernel.cl's order and meaning:
