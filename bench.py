@@ -58,12 +58,14 @@ def main():
     ap.add_argument("--res", type=int, default=224)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=0, help="images in the CPU baseline sample (0 = auto)")
+    ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the CPU baseline (cap; box share is 16)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from mbn_amd import import_package
+    pkg = import_package()
+    from mbn_amd_pkg import dist as mdist      # the protocol rehearsed on gloo in tests/test_dist_cpu.py
+    rank, local_rank, world = mdist.env_rank_world()
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
@@ -71,19 +73,14 @@ def main():
 
     import numpy as np
     import torch   # device plumbing only: RCCL broadcast, barrier, device-wide synchronize
-    import torch.distributed as dist
 
-    from mbn_amd import import_package
-    pkg = import_package()
     lib = pkg.load()          # raises if the HIP extension is missing: no fallback
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm
+    mdist.init("nccl", dev)                    # nccl == RCCL on ROCm; no-op for one process
 
     # ---- parameters: rank 0 writes a synthetic Keras-layout .h5 and reads it back through the real loader
     plan = pkg.plan_build(args.alpha, args.res, 1000, lib=lib)
@@ -96,8 +93,7 @@ def main():
         assert hw.plan.blob_floats == plan.blob_floats
         blob_t.copy_(torch.from_numpy(hw.blob))
         hw.free()
-    if world > 1:
-        dist.broadcast(blob_t, src=0)      # the one collective of the path: ~17 MB over xGMI, off the timed path
+    mdist.broadcast_blob(blob_t, 0)            # the one collective of the path: ~17 MB over xGMI, off the timed path
     torch.cuda.synchronize()
 
     ctx = pkg.Context(local_rank)
@@ -110,9 +106,7 @@ def main():
     del imgs
     d_out = ctx.alloc(args.batch * 1000 * 4)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
+    barrier = mdist.barrier
 
     for _ in range(args.warmup):
         net.forward(d_in.ptr, d_out.ptr, args.batch)
@@ -137,10 +131,7 @@ def main():
         arr = np.asarray(ms, dtype=np.float64).reshape(args.steps, n_layers)
         layer_ms = arr.mean(axis=0)
 
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = mdist.max_over_ranks(elapsed, dev)
 
     logits = d_out.download((args.batch, 1000), np.float32)
     if not np.isfinite(logits).all():
@@ -204,7 +195,7 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import oracle as orc   # cpu_baseline leg: the oracle is the thing timed here, never the product path
             oplan = orc.plan_build(args.alpha, args.res, 1000)
-            cores = orc.num_threads()
+            cores = min(orc.num_threads(), args.cpu_threads)      # the one-GPU box's CPU share is 16 cores
             n_img = args.cpu_images or max(2, cores)
             blob = blob_t.cpu().numpy()
             sample = np.random.default_rng(1).random((n_img, args.res, args.res, 3), dtype=np.float32) * 2 - 1
@@ -220,8 +211,7 @@ def main():
 
     net.destroy()
     ctx.close()
-    if world > 1:
-        dist.destroy_process_group()
+    mdist.shutdown()
 
 
 if __name__ == "__main__":

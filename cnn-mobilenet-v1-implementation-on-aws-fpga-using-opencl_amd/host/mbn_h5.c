@@ -40,6 +40,8 @@ struct mbn_h5 {
     uint64_t base;          /* superblock base address */
     int so, sl;             /* size of offsets / lengths */
     uint64_t root_ohdr;     /* root group object header */
+    void **copies;          /* aligned copies of datasets whose bytes sit unaligned in the file (compact layout) */
+    int ncopies;
 };
 
 /* ------------------------------------------------------------------ byte helpers */
@@ -402,6 +404,8 @@ int mbn_h5_close(mbn_h5 *h)
     if (!h) return MBN_OK;
     if (h->map) munmap((void *)h->map, h->size);
     if (h->fd >= 0) close(h->fd);
+    for (int i = 0; i < h->ncopies; i++) free(h->copies[i]);
+    free(h->copies);
     free(h);
     return MBN_OK;
 }
@@ -466,7 +470,17 @@ static int dataset_view(const mbn_h5 *h, uint64_t ohdr, int *ndim, int64_t shape
         if (o.data_size < count * 4) return MBN_EFORMAT;
         p = o.compact;
     } else return MBN_EUNSUPPORTED;                                      /* chunked */
-    if (((uintptr_t)p & 3) != 0) return MBN_EUNSUPPORTED;               /* cannot hand out an unaligned float* */
+    if (((uintptr_t)p & 3) != 0) {                                      /* cannot hand out an unaligned float*: copy */
+        mbn_h5 *hm = (mbn_h5 *)h;
+        void **nc = (void **)realloc(hm->copies, sizeof(void *) * (size_t)(hm->ncopies + 1));
+        if (!nc) return MBN_ENOMEM;
+        hm->copies = nc;
+        void *cp = malloc(count ? count * 4 : 4);
+        if (!cp) return MBN_ENOMEM;
+        memcpy(cp, p, count * 4);
+        hm->copies[hm->ncopies++] = cp;
+        p = (const uint8_t *)cp;
+    }
     if (ndim) *ndim = o.ndim;
     if (shape) for (int i = 0; i < o.ndim; i++) shape[i] = o.shape[i];
     if (data) *data = (const float *)p;

@@ -1,0 +1,431 @@
+"""CPU tests of the C host (no GPU needed): the C-ABI library loads and exports every symbol include/mbn.h declares,
+the topology table, the loaders kept from the reference, and the from-scratch Keras .h5 reader/writer — validated
+against files written by the real libhdf5 (tests/golden/*.h5, generator: tests/golden/make_h5_fixtures.py)."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+LIBHDF5 = "/opt/conda/lib/libhdf5.so"
+
+
+# ----------------------------------------------------------------------------- ABI surface
+
+def test_abi_library_loads_and_exports_every_declared_symbol(pkg):
+    lib = pkg.load()                       # libmbn.so: HIP kernels + C-ABI + C host; loading needs no GPU
+    names = pkg.declared_symbols()
+    assert len(names) >= 45
+    for must in ("mbn_convolute", "mbn_depthwise", "mbn_pointwise", "mbn_pool", "mbn_init", "mbn_shutdown",
+                 "readSquezeNetKernel", "decode_image", "mbn_h5_open", "mbn_h5_get", "mbn_weights_from_h5",
+                 "mbn_net_forward", "mbn_profile_begin"):
+        assert must in names
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    host = pkg.host_lib()                  # the C host alone must not depend on HIP
+    assert hasattr(host, "mbn_plan_build") and not hasattr(host, "mbn_depthwise")
+
+
+def test_layer_ext_struct_matches_header(pkg):
+    """ctypes mirror == C struct: compile a 3-line C program against include/mbn.h and compare sizeof/offsetof."""
+    import subprocess
+    import tempfile
+    src = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "mbn.h"
+int main(void){printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(mbn_layer_ext), offsetof(mbn_layer_ext, quirks),
+ offsetof(mbn_layer_ext, scale), offsetof(mbn_layer_ext, stream), sizeof(mbn_layer_desc), sizeof(mbn_plan),
+ offsetof(mbn_plan, layer));return 0;}'''
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(pkg.REPO_ROOT, "include"), "-o", os.path.join(d, "t"),
+                               os.path.join(d, "t.c")])
+        vals = [int(x) for x in subprocess.check_output([os.path.join(d, "t")]).split()]
+    E, D, P = pkg.LayerExt, pkg.LayerDesc, pkg.Plan
+    assert vals == [C.sizeof(E), E.quirks.offset, E.scale.offset, E.stream.offset, C.sizeof(D), C.sizeof(P),
+                    P.layer.offset]
+
+
+def test_no_device_is_an_error_code_not_a_crash(pkg):
+    lib = pkg.load()
+    n = C.c_int(-1)
+    assert lib.mbn_device_count(C.byref(n)) == 0
+    if n.value > 0:
+        pytest.skip("a GPU is visible here")
+    h = C.c_void_p()
+    assert lib.mbn_init(0, C.byref(h)) == pkg.ENODEVICE      # no fallback path: nothing computes without a GPU
+    assert not h.value
+    with pytest.raises(pkg.MbnError):
+        pkg.Context(0)
+    assert lib.mbn_shutdown(None) == 0
+    assert lib.mbn_sync(None) == pkg.EINVAL
+    assert lib.mbn_depthwise(None, None, None, None, 1, 1, 3, 1, 1, None) == pkg.EINVAL
+    assert lib.mbn_strerror(pkg.ENODEVICE).decode() == "no HIP device"
+
+
+# ----------------------------------------------------------------------------- topology
+
+def test_plan_matches_survey_table(pkg):
+    p = pkg.plan_build(1.0, 224, 1000)
+    assert p.n_layers == 29
+    L = [p.layer[i] for i in range(29)]
+    assert [l.kind for l in L] == [1] + [2, 3] * 13 + [4, 5]
+    assert [l.index for l in L] == list(range(1, 30))
+    # (in_rows, in_ch, out_rows, out_ch, stride)
+    table = {1: (224, 3, 112, 32, 2), 2: (112, 32, 112, 32, 1), 3: (112, 32, 112, 64, 1), 4: (112, 64, 56, 64, 2),
+             5: (56, 64, 56, 128, 1), 8: (56, 128, 28, 128, 2), 9: (28, 128, 28, 256, 1), 12: (28, 256, 14, 256, 2),
+             13: (14, 256, 14, 512, 1), 24: (14, 512, 7, 512, 2), 25: (7, 512, 7, 1024, 1), 26: (7, 1024, 7, 1024, 1),
+             27: (7, 1024, 7, 1024, 1), 28: (7, 1024, 1, 1024, 1), 29: (1, 1024, 1, 1000, 1)}
+    for idx, want in table.items():
+        l = L[idx - 1]
+        assert (l.in_rows, l.in_ch, l.out_rows, l.out_ch, l.stride) == want, idx
+    # TF-SAME: stride-1 depthwise pads 1, stride-2 on even sizes pads 0 (i.e. bottom/right only)
+    assert (L[1].pad_top, L[3].pad_top, L[0].pad_top) == (1, 0, 0)
+    # parameter counts: conv/FC 4 210 088 weights + 2 x 10 944 folded BN + 1000 bias
+    assert sum(l.w_count for l in L) == 864 + 44640 + 3139584 + 1024000
+    assert sum(l.out_ch for l in L if l.scale_offset >= 0) == 10944   # 27 BN layers: 10 944 scales (+ as many shifts)
+    assert p.max_act_floats == 112 * 112 * 64
+    offs = [l.w_offset for l in L if l.w_count] + [l.scale_offset for l in L if l.scale_offset >= 0]
+    assert all(o % 64 == 0 for o in offs)      # 256-byte aligned segments
+
+
+@pytest.mark.parametrize("alpha,res", [(0.5, 160), (0.25, 128), (0.75, 192), (1.0, 96)])
+def test_plan_width_and_resolution(pkg, orc, alpha, res):
+    p = pkg.plan_build(alpha, res, 1000)
+    o = orc.plan_build(alpha, res, 1000)        # independent restatement of the same table
+    assert (p.n_layers, p.blob_floats, p.max_act_floats) == (o.n_layers, o.blob_floats, o.max_act_floats)
+    for i in range(p.n_layers):
+        a, b = p.layer[i], o.layer[i]
+        for f in ("index", "kind", "in_rows", "in_cols", "in_ch", "out_rows", "out_cols", "out_ch", "stride", "pad_top",
+                  "pad_left", "w_offset", "w_count", "scale_offset", "shift_offset"):
+            assert getattr(a, f) == getattr(b, f), (i, f)
+    assert p.layer[0].out_ch == int(32 * alpha) and p.layer[26].out_ch == int(1024 * alpha)
+    assert p.layer[27].in_rows == res // 32
+
+
+def test_plan_rejects_bad_arguments(pkg):
+    lib = pkg.host_lib()
+    p = pkg.Plan()
+    for a, r, c in ((0.0, 224, 1000), (-1.0, 224, 1000), (1.0, 8, 1000), (1.0, 224, 0), (0.01, 224, 10)):
+        assert lib.mbn_plan_build(a, r, c, C.byref(p)) == pkg.EINVAL
+    assert lib.mbn_plan_build(1.0, 224, 1000, None) == pkg.EINVAL
+
+
+# ----------------------------------------------------------------------------- loaders kept from the reference
+
+def test_text_weight_loader(pkg, tmp_path):
+    lib = pkg.host_lib()
+    f = tmp_path / "weights_c.txt"
+    f.write_text("1.9 -2.7e0 3 0.999 -0.5\n  1e2\t7.0e-1 300")
+    m = np.full(10, -99, np.int32)
+    assert lib.mbn_read_text_weights(str(f).encode(), m.ctypes.data, 8) == 0
+    assert list(m[:8]) == [1, -2, 3, 0, 0, 100, 0, 300] and m[8] == -99      # double -> int truncates toward zero (B8)
+    assert lib.mbn_read_text_weights(str(f).encode(), m.ctypes.data, 9) == pkg.EFORMAT   # fewer tokens than asked
+    assert lib.mbn_read_text_weights(b"/nonexistent/w.txt", m.ctypes.data, 1) == pkg.EIO
+    x = np.zeros(3, np.float32)
+    assert lib.mbn_read_text_weights_f32(str(f).encode(), x.ctypes.data, 3, 1) == 0
+    assert np.allclose(x, [-2.7, 3, 0.999])
+    # the reference symbol itself: same name/signature, reads ./weights_c.txt, every call from the start of the file
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        a, b = np.zeros(3, np.int32), np.zeros(5, np.int32)
+        lib.readSquezeNetKernel(a.ctypes.data, 3)
+        lib.readSquezeNetKernel(b.ctypes.data, 5)
+        assert list(a) == [1, -2, 3] and list(b) == [1, -2, 3, 0, 0]       # same prefix for every "layer"
+        os.remove("weights_c.txt")
+        lib.readSquezeNetKernel(a.ctypes.data, 3)                          # missing file: no crash, buffer untouched
+        assert list(a) == [1, -2, 3]
+    finally:
+        os.chdir(cwd)
+
+
+def test_image_loaders(pkg, tmp_path):
+    lib = pkg.host_lib()
+    rng = np.random.default_rng(0)
+    rgb = rng.integers(0, 256, (224, 224, 3), dtype=np.uint8)
+    ppm = str(tmp_path / "Cat_Image0.ppm").encode()
+    assert lib.mbn_write_ppm(ppm, rgb.ctypes.data, 224, 224) == 0
+    out = np.zeros_like(rgb)
+    w, h = C.c_int(), C.c_int()
+    assert lib.mbn_read_ppm(ppm, out.ctypes.data, C.byref(w), C.byref(h), 224 * 224) == 0
+    assert (w.value, h.value) == (224, 224) and np.array_equal(out, rgb)
+    assert lib.mbn_read_ppm(ppm, out.ctypes.data, C.byref(w), C.byref(h), 100) == pkg.EINVAL   # too small a buffer
+    # comments + odd whitespace in the header
+    p2 = tmp_path / "c.ppm"
+    p2.write_bytes(b"P6 # made by hand\n2\t1\n# another\n255\n" + bytes([1, 2, 3, 4, 5, 6]))
+    small = np.zeros(6, np.uint8)
+    assert lib.mbn_read_ppm(str(p2).encode(), small.ctypes.data, C.byref(w), C.byref(h), 4) == 0
+    assert list(small) == [1, 2, 3, 4, 5, 6] and (w.value, h.value) == (2, 1)
+    (tmp_path / "bad.ppm").write_bytes(b"P5\n2 2\n255\n....")
+    assert lib.mbn_read_ppm(str(tmp_path / "bad.ppm").encode(), small.ctypes.data, C.byref(w), C.byref(h), 4) == pkg.EFORMAT
+    # decode_image keeps the reference's behaviour: raw bytes from offset 0, header included (B14)
+    frame = np.zeros(224 * 224 * 3, np.uint8)
+    assert lib.decode_image(frame.ctypes.data, ppm) == 0
+    header = b"P6\n224 224\n255\n"
+    assert bytes(frame[:len(header)]) == header
+    assert np.array_equal(frame[len(header):], rgb.ravel()[:frame.size - len(header)])
+    assert lib.decode_image(frame.ctypes.data, b"/nonexistent.ppm") == pkg.EIO
+    # RGB de-interleave (MobileNet.c:218-238)
+    r, g, b = (np.zeros(224 * 224, np.uint8) for _ in range(3))
+    assert lib.mbn_split_rgb(rgb.ctypes.data, 224 * 224, r.ctypes.data, g.ctypes.data, b.ctypes.data) == 0
+    assert np.array_equal(r, rgb[..., 0].ravel()) and np.array_equal(b, rgb[..., 2].ravel())
+
+
+def test_host_softmax_argmax_u8(pkg, orc):
+    lib = pkg.host_lib()
+    logits = np.random.default_rng(3).integers(0, 40, 1000, dtype=np.uint8)
+    logits[417] = 60
+    probs = np.zeros(1000)
+    loc, mx = C.c_int(), C.c_double()
+    assert lib.mbn_softmax_argmax_u8(logits.ctypes.data, 1000, probs.ctypes.data, C.byref(loc), C.byref(mx)) == 0
+    op, oloc, omx = orc.softmax_argmax_u8(logits)
+    assert loc.value == oloc == 418 and mx.value == omx and np.array_equal(probs, op)   # 1-based like MobileNet.c:2788
+    assert abs(probs.sum() - 1) < 1e-12
+    logits[:] = 0
+    logits[0] = 9
+    lib.mbn_softmax_argmax_u8(logits.ctypes.data, 1000, probs.ctypes.data, C.byref(loc), C.byref(mx))
+    assert loc.value == 1       # defined when class 0 wins (the reference leaves `location` uninitialised, B11)
+
+
+# ----------------------------------------------------------------------------- .h5 reader / writer
+
+def h5_get(lib, path, name):
+    h = C.c_void_p()
+    rc = lib.mbn_h5_open(path.encode(), C.byref(h))
+    if rc:
+        return rc, None
+    nd, shp, p = C.c_int(), (C.c_int64 * 8)(), C.POINTER(C.c_float)()
+    rc = lib.mbn_h5_get(h, name.encode(), C.byref(nd), shp, C.byref(p))
+    a = None
+    if rc == 0:
+        shape = tuple(shp[i] for i in range(nd.value))
+        n = int(np.prod(shape)) if shape else 1
+        a = np.ctypeslib.as_array(p, shape=(n,)).reshape(shape).copy()
+    lib.mbn_h5_close(h)
+    return rc, a
+
+
+def h5_list(lib, path):
+    h = C.c_void_p()
+    assert lib.mbn_h5_open(path.encode(), C.byref(h)) == 0
+    seen = {}
+    CB = C.CFUNCTYPE(C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int64), C.c_void_p)
+
+    def cb(p, nd, shp, _):
+        seen[p.decode()] = tuple(shp[i] for i in range(nd))
+        return 0
+    fn = CB(cb)
+    assert lib.mbn_h5_visit(h, C.cast(fn, C.c_void_p), None) == 0
+    lib.mbn_h5_close(h)
+    return seen
+
+
+@pytest.mark.parametrize("stem", ["keras_like_earliest", "latest_format"])
+def test_h5_reader_on_libhdf5_written_files(pkg, stem):
+    lib = pkg.host_lib()
+    exp = json.load(open(os.path.join(GOLD, stem + ".json")))
+    for name, v in exp.items():
+        rc, a = h5_get(lib, os.path.join(GOLD, stem + ".h5"), name)
+        assert rc == 0, (name, rc)
+        assert list(a.shape) == v["shape"]
+        assert np.array_equal(a.ravel(), np.float32(v["data"])), name
+
+
+def test_h5_reader_visits_every_keras_dataset(pkg):
+    lib = pkg.host_lib()
+    sums = json.load(open(os.path.join(GOLD, "keras_like_earliest_sums.json")))
+    seen = h5_list(lib, os.path.join(GOLD, "keras_like_earliest.h5"))
+    assert set(seen) == set(sums) and len(seen) == 1 + 4 + 13 * 10 + 2
+    for name, (shape, total) in sums.items():
+        rc, a = h5_get(lib, os.path.join(GOLD, "keras_like_earliest.h5"), name)
+        assert rc == 0 and list(a.shape) == shape
+        assert abs(float(np.float64(a).sum()) - total) <= 1e-9 * max(1.0, abs(total)), name
+
+
+def test_h5_reader_errors(pkg, tmp_path):
+    lib = pkg.host_lib()
+    p = os.path.join(GOLD, "unsupported.h5")
+    assert h5_get(lib, p, "/chunked")[0] == pkg.EUNSUPPORTED
+    assert h5_get(lib, p, "/f64")[0] == pkg.EUNSUPPORTED
+    rc, ok = h5_get(lib, p, "/ok")
+    assert rc == 0 and np.array_equal(ok, np.arange(6, dtype=np.float32).reshape(2, 3))
+    assert h5_get(lib, p, "/missing")[0] == pkg.ENOTFOUND
+    assert h5_get(lib, p, "/ok/deeper")[0] in (pkg.ENOTFOUND, pkg.EFORMAT)
+    assert h5_get(lib, os.path.join(GOLD, "keras_like_earliest.h5"), "/conv1")[0] == pkg.ENOTFOUND   # a group
+    assert h5_get(lib, "/nonexistent.h5", "/x")[0] == pkg.EIO
+    junk = tmp_path / "junk.h5"
+    junk.write_bytes(os.urandom(4096))
+    assert h5_get(lib, str(junk), "/x")[0] == pkg.EFORMAT
+    tiny = tmp_path / "tiny.h5"
+    tiny.write_bytes(b"\x89HDF\r\n\x1a\n")
+    assert h5_get(lib, str(tiny), "/x")[0] == pkg.EFORMAT
+    # truncated real file: must fail cleanly, never read past the mapping
+    data = open(os.path.join(GOLD, "keras_like_earliest.h5"), "rb").read()
+    for cut in (100, 700, 5000, len(data) // 2):
+        t = tmp_path / ("cut%d.h5" % cut)
+        t.write_bytes(data[:cut])
+        assert h5_get(lib, str(t), "/conv_preds/conv_preds/bias:0")[0] != 0 or cut > 5000
+
+
+def test_h5_fuzz_never_crashes(pkg, tmp_path):
+    """Bit-flip fuzz of a real file: any return code is fine, a crash is not."""
+    lib = pkg.host_lib()
+    data = bytearray(open(os.path.join(GOLD, "latest_format.h5"), "rb").read())
+    rng = np.random.default_rng(5)
+    t = tmp_path / "fuzz.h5"
+    for _ in range(300):
+        d = bytearray(data)
+        for _ in range(int(rng.integers(1, 6))):
+            d[int(rng.integers(0, len(d)))] = int(rng.integers(0, 256))
+        t.write_bytes(bytes(d))
+        for name in ("/top", "/grp/inner/vec:0", "/grp/compact"):
+            h5_get(lib, str(t), name)
+        h = C.c_void_p()
+        if lib.mbn_h5_open(str(t).encode(), C.byref(h)) == 0:
+            CB = C.CFUNCTYPE(C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int64), C.c_void_p)
+            fn = CB(lambda *a: 0)
+            lib.mbn_h5_visit(h, C.cast(fn, C.c_void_p), None)
+            lib.mbn_h5_close(h)
+
+
+def _write(lib, path, items):
+    w = C.c_void_p()
+    assert lib.mbn_h5_create(path.encode(), C.byref(w)) == 0
+    for name, arr in items:
+        a = np.ascontiguousarray(arr, np.float32)
+        shp = (C.c_int64 * max(a.ndim, 1))(*a.shape)
+        assert lib.mbn_h5_put(w, name.encode(), a.ndim, shp, a.ctypes.data) == 0, name
+    assert lib.mbn_h5_finish(w) == 0
+
+
+def test_h5_writer_roundtrip_and_libhdf5_reads_it(pkg, tmp_path):
+    lib = pkg.host_lib()
+    rng = np.random.default_rng(8)
+    items = [("/a/a/kernel:0", rng.normal(size=(3, 3, 3, 8))), ("/a/a/bias:0", rng.normal(size=(8,))),
+             ("/b/deep/er/x", rng.normal(size=(5, 7))), ("/top", rng.normal(size=(2,)))]
+    items += [("/many/d%03d" % i, rng.normal(size=(i % 5 + 1,))) for i in range(70)]     # > default SNOD capacity
+    path = str(tmp_path / "w.h5")
+    _write(lib, path, items)
+    seen = h5_list(lib, path)
+    assert set(seen) == {n for n, _ in items}
+    for name, arr in items:
+        rc, a = h5_get(lib, path, name)
+        assert rc == 0 and np.array_equal(a, np.float32(arr)), name
+    # duplicate / malformed names are refused
+    w = C.c_void_p()
+    assert lib.mbn_h5_create(str(tmp_path / "dup.h5").encode(), C.byref(w)) == 0
+    one = np.ones(1, np.float32)
+    shp = (C.c_int64 * 1)(1)
+    assert lib.mbn_h5_put(w, b"/x", 1, shp, one.ctypes.data) == 0
+    assert lib.mbn_h5_put(w, b"/x", 1, shp, one.ctypes.data) == pkg.EINVAL
+    assert lib.mbn_h5_put(w, b"/x/y", 1, shp, one.ctypes.data) == pkg.EINVAL
+    assert lib.mbn_h5_put(w, b"/", 1, shp, one.ctypes.data) == pkg.EINVAL
+    assert lib.mbn_h5_finish(w) == 0
+    if not os.path.exists(LIBHDF5):
+        pytest.skip("libhdf5 not present: cross-read by the real library skipped")
+    h5 = C.CDLL(LIBHDF5)
+    hid = C.c_int64
+    h5.H5Fopen.restype = h5.H5Dopen2.restype = h5.H5Dget_space.restype = hid
+    h5.H5Fopen.argtypes = [C.c_char_p, C.c_uint, hid]
+    h5.H5Dopen2.argtypes = [hid, C.c_char_p, hid]
+    h5.H5Dget_space.argtypes = [hid]
+    h5.H5Sget_simple_extent_npoints.argtypes = [hid]
+    h5.H5Sget_simple_extent_npoints.restype = C.c_int64
+    h5.H5Dread.argtypes = [hid, hid, hid, hid, hid, C.c_void_p]
+    h5.H5Dclose.argtypes = h5.H5Fclose.argtypes = h5.H5Sclose.argtypes = [hid]
+    h5.H5open()
+    nf32 = hid.in_dll(h5, "H5T_NATIVE_FLOAT_g").value
+    f = h5.H5Fopen(path.encode(), 0, 0)
+    assert f >= 0, "libhdf5 refuses the file written by mbn_h5_create"
+    for name, arr in items:
+        d = h5.H5Dopen2(f, name.encode(), 0)
+        assert d >= 0, name
+        sp = h5.H5Dget_space(d)
+        n = h5.H5Sget_simple_extent_npoints(sp)
+        assert n == np.asarray(arr).size
+        out = np.zeros(n, np.float32)
+        assert h5.H5Dread(d, nf32, 0, 0, 0, out.ctypes.data) >= 0
+        assert np.array_equal(out, np.float32(arr).ravel()), name
+        h5.H5Sclose(sp)
+        h5.H5Dclose(d)
+    h5.H5Fclose(f)
+
+
+# ----------------------------------------------------------------------------- weights: .h5 -> folded, packed blob
+
+def _expected_blob(lib, path, plan):
+    """BN folding + repacking restated in numpy from the datasets of the file."""
+    blob = np.zeros(plan.blob_floats, np.float32)
+
+    def get(name):
+        rc, a = h5_get(lib, path, name)
+        assert rc == 0, name
+        return a
+
+    def fold(g, l):
+        ga, be, mu, va = (get("/%s/%s/%s:0" % (g, g, k)).astype(np.float64)
+                          for k in ("gamma", "beta", "moving_mean", "moving_variance"))
+        s = ga / np.sqrt(va + 1e-3)
+        blob[l.scale_offset:l.scale_offset + l.out_ch] = s
+        blob[l.shift_offset:l.shift_offset + l.out_ch] = be - mu * s
+
+    dw = pw = 0
+    for i in range(plan.n_layers):
+        l = plan.layer[i]
+        if l.kind == 1:
+            blob[l.w_offset:l.w_offset + l.w_count] = get("/conv1/conv1/kernel:0").ravel()
+            fold("conv1_bn", l)
+        elif l.kind == 2:
+            dw += 1
+            blob[l.w_offset:l.w_offset + l.w_count] = get("/conv_dw_%d/conv_dw_%d/depthwise_kernel:0" % (dw, dw)).ravel()
+            fold("conv_dw_%d_bn" % dw, l)
+        elif l.kind == 3:
+            pw += 1
+            k = get("/conv_pw_%d/conv_pw_%d/kernel:0" % (pw, pw))[0, 0]
+            blob[l.w_offset:l.w_offset + l.w_count] = k.T.ravel()          # [Cin][Cout] -> [Cout][Cin]
+            fold("conv_pw_%d_bn" % pw, l)
+        elif l.kind == 5:
+            k = get("/conv_preds/conv_preds/kernel:0")[0, 0]
+            blob[l.w_offset:l.w_offset + l.w_count] = k.T.ravel()
+            blob[l.shift_offset:l.shift_offset + l.out_ch] = get("/conv_preds/conv_preds/bias:0")
+    return blob
+
+
+def test_weights_from_keras_like_h5(pkg):
+    lib = pkg.host_lib()
+    path = os.path.join(GOLD, "keras_like_earliest.h5")
+    hw = pkg.HostWeights(path, alpha=0.0, res=64)           # alpha inferred from conv1's kernel shape
+    assert abs(hw.plan.alpha - 0.125) < 1e-6 and hw.plan.classes == 10 and hw.plan.res == 64
+    want = _expected_blob(lib, path, hw.plan)
+    assert np.allclose(hw.blob, want, rtol=1e-6, atol=1e-7)
+    assert np.array_equal(hw.blob[hw.plan.layer[0].w_offset:][:27 * 4], want[hw.plan.layer[0].w_offset:][:27 * 4])
+    hw.free()
+    w = pkg.Weights()
+    assert lib.mbn_weights_from_h5(path.encode(), 1.0, 224, C.byref(w)) == pkg.ESHAPE     # wrong alpha for this file
+    assert lib.mbn_weights_from_h5(b"/nonexistent.h5", 1.0, 224, C.byref(w)) == pkg.EIO
+    assert lib.mbn_weights_from_h5(os.path.join(GOLD, "latest_format.h5").encode(), 1.0, 224, C.byref(w)) == pkg.ENOTFOUND
+
+
+def test_synthetic_weights_go_through_the_real_loader(pkg, tmp_path):
+    lib = pkg.host_lib()
+    path = str(tmp_path / "syn.h5")
+    pkg.synthetic_h5(path, alpha=0.25, classes=20, seed=42)
+    hw = pkg.HostWeights(path, res=96)
+    assert (hw.plan.classes, hw.plan.layer[0].out_ch) == (20, 8)
+    want = _expected_blob(lib, path, hw.plan)
+    assert np.allclose(hw.blob, want, rtol=1e-6, atol=1e-7)
+    # deterministic in the seed, different across seeds, sane statistics (He-normal kernels, gamma in [.5,1.5])
+    p2 = str(tmp_path / "syn2.h5")
+    pkg.synthetic_h5(p2, alpha=0.25, classes=20, seed=42)
+    assert open(path, "rb").read() == open(p2, "rb").read()
+    pkg.synthetic_h5(p2, alpha=0.25, classes=20, seed=43)
+    assert open(path, "rb").read() != open(p2, "rb").read()
+    _, k = h5_get(lib, path, "/conv_pw_13/conv_pw_13/kernel:0")
+    assert abs(k.std() - (2.0 / 256) ** 0.5) < 0.01 and abs(k.mean()) < 0.01
+    _, g = h5_get(lib, path, "/conv_pw_13_bn/conv_pw_13_bn/gamma:0")
+    assert 0.5 <= g.min() and g.max() <= 1.5
+    hw.free()
