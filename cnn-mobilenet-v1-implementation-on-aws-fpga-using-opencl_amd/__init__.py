@@ -136,6 +136,7 @@ def load():
         lib.mbn_set_profiling.argtypes = [vp, ci]
         lib.mbn_profile_begin.argtypes = [vp, ci]
         lib.mbn_profile_end.argtypes = [vp, C.POINTER(C.c_float), ci, C.POINTER(ci)]
+        lib.mbn_profile_pause.argtypes = [vp, ci]
         ext = C.POINTER(LayerExt)
         lib.mbn_convolute.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ext]
         lib.mbn_depthwise.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, ext]
@@ -259,6 +260,9 @@ class Context:
 
     def profile_begin(self, capacity: int):
         _chk(self.lib.mbn_profile_begin(self.h, capacity))
+
+    def profile_pause(self, paused: bool):
+        _chk(self.lib.mbn_profile_pause(self.h, int(paused)))
 
     def profile_end(self, capacity: int):
         ms = (C.c_float * capacity)()

@@ -7,7 +7,36 @@
 
 #include <new>
 
+mbn_tunables g_mbn_tune;
+
 extern "C" {
+
+static int *tune_slot(const char *key)
+{
+    if (!key) return nullptr;
+    if (!strcmp(key, "dw_variant")) return &g_mbn_tune.dw_variant;
+    if (!strcmp(key, "dw_nseg")) return &g_mbn_tune.dw_nseg;
+    if (!strcmp(key, "pw_tile")) return &g_mbn_tune.pw_tile;
+    if (!strcmp(key, "conv_variant")) return &g_mbn_tune.conv_variant;
+    if (!strcmp(key, "misc")) return &g_mbn_tune.misc;
+    return nullptr;
+}
+
+int mbn_tune_set(const char *key, int value)
+{
+    int *p = tune_slot(key);
+    if (!p) return MBN_ENOTFOUND;
+    *p = value;
+    return MBN_OK;
+}
+
+int mbn_tune_get(const char *key, int *value)
+{
+    int *p = tune_slot(key);
+    if (!p || !value) return p ? MBN_EINVAL : MBN_ENOTFOUND;
+    *value = *p;
+    return MBN_OK;
+}
 
 int mbn_device_count(int *count)
 {
@@ -183,6 +212,13 @@ int mbn_profile_begin(mbn_context *ctx, int capacity)
     ctx->pool_cap = capacity;
     ctx->pool_used = 0;
     ctx->pool_on = true;
+    return MBN_OK;
+}
+
+int mbn_profile_pause(mbn_context *ctx, int paused)
+{
+    if (!ctx) return MBN_EINVAL;
+    ctx->pool_on = !paused && ctx->pool_cap > 0;
     return MBN_OK;
 }
 

@@ -1,16 +1,17 @@
 // mbn_f32_dw.hip — fp32 NHWC 3x3 depthwise conv + folded-BN scale/shift + ReLU/ReLU6 for gfx950.
 // Replaces the arithmetic of the reference's `depthwise` kernel (kernel.cl:62-92) in the fp32 mode the metric
 // measures. HBM-bound (0.9-2.2 flop/B): the design goal is to read every input byte once and write every
-// output byte once with 16-B-per-lane, fully coalesced accesses, and to keep enough loads in flight.
+// output byte once with 16-B-per-lane, coalesced accesses, and to keep enough loads in flight.
 //
-// Decomposition ("column march"): a lane owns 4 consecutive channels (one float4) of one output column `ox`
-// and walks DOWN the image rows of one segment, keeping the 3x3 input window of float4s in registers. Each
-// new output row needs only STRIDE new input rows (3 float4 loads each), so an input element is requested
-// 3x (stride 1) / 1.5x (stride 2) in total; the two neighbour-column requests hit the L1/TA path of the same
-// workgroup (the lanes owning ox-1 / ox+1 fetch the same lines), so HBM sees each line once.
-// Lanes are laid out channel-fastest then column, so a wave's load of one input row is one contiguous
-// 1-KiB span of the NHWC row (C floats per pixel x consecutive pixels) — the coalescing NHWC was chosen for.
-// The 9 filter taps and the scale/shift of the lane's 4 channels live in registers for the whole march.
+// Decomposition ("column march"): a lane owns 4 consecutive channels (one float4) of TW adjacent output columns
+// and walks DOWN the output rows of one segment, keeping the 3 x (TW*S+2) input window of float4s in registers.
+// Each new output row needs only STRIDE new input rows, so an input element is requested (TW*S+2)/(TW*S) times
+// per row instead of 9/S^2 times; the left/right halo requests are served by the L1 of the same workgroup because
+// the lanes that own the neighbouring columns sit in the same wave or the next one.
+// Lane layout inside a wave: CW lanes along channels (CW*16 contiguous bytes of one pixel), then columns. For wide
+// layers (C >= 64) CW is capped at 16 so that a 256-lane workgroup covers >= 16*TW columns of one 64-channel slab:
+// with CW = C/4 a workgroup of a 512-channel layer would hold 2 pixels and every halo request would miss the L1.
+// The 9 filter taps and scale/shift of the lane's 4 channels stay in registers for the whole march.
 #include "mbn_internal.h"
 
 namespace {
@@ -38,33 +39,42 @@ struct DwArgs {
     const float *in, *filt, *scale, *shift;
     int batch, in_rows, in_cols, rows, cols, ch, pad_top, pad_left, act;
     int seg_rows, nseg;     // output rows per segment / segments per image
-    long total;             // lanes with work: batch * nseg * cols * (ch/4)
+    int cw;                 // lanes along channels inside a slab (channels per slab = 4*cw)
+    int nslab;              // ch / (4*cw)
+    int lcols;              // lane-columns per row = ceil(cols / TW)
+    long total;             // lanes with work
 };
 
-// Load the 3 float4 of input row `iy` around this lane's columns (ix0, ix0+1, ix0+2); zero outside the image.
-__device__ __forceinline__ void load_row(const DwArgs &a, const float *img, int iy, int ix0, int c, f4 &l, f4 &m, f4 &r)
+// One input row for a lane: NC = TW*STRIDE+2 float4 at columns ix0 .. ix0+NC-1; zero outside the image.
+template <int NC>
+__device__ __forceinline__ void load_row(const DwArgs &a, const float *img, int iy, int ix0, int c, f4 (&r)[NC])
 {
-    const f4 z = f4{ 0.f, 0.f, 0.f, 0.f };
-    l = m = r = z;
-    if (iy < 0 || iy >= a.in_rows) return;
+    const bool rowok = iy >= 0 && iy < a.in_rows;
     const float *row = img + ((long)iy * a.in_cols) * a.ch + c;
-    if (ix0 >= 0 && ix0 < a.in_cols) l = ld4(row + (long)ix0 * a.ch);
-    if (ix0 + 1 >= 0 && ix0 + 1 < a.in_cols) m = ld4(row + (long)(ix0 + 1) * a.ch);
-    if (ix0 + 2 >= 0 && ix0 + 2 < a.in_cols) r = ld4(row + (long)(ix0 + 2) * a.ch);
+#pragma unroll
+    for (int j = 0; j < NC; j++) {
+        const int ix = ix0 + j;
+        r[j] = (rowok && ix >= 0 && ix < a.in_cols) ? ld4(row + (long)ix * a.ch) : f4{ 0.f, 0.f, 0.f, 0.f };
+    }
 }
 
-template <int STRIDE>
+template <int STRIDE, int TW>
 __global__ __launch_bounds__(256) void dw3x3_f32_nhwc(DwArgs a)
 {
+    constexpr int NC = TW * STRIDE + 2;
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= a.total) return;
-    const int c4n = a.ch >> 2;
-    const int c = (int)(t % c4n) << 2;
-    long q = t / c4n;
-    const int ox = (int)(q % a.cols);
-    q /= a.cols;
+    // lane -> (channel-in-slab fastest, lane-column, slab, segment, image)
+    const int cl = (int)(t % a.cw);
+    long q = t / a.cw;
+    const int lc = (int)(q % a.lcols);
+    q /= a.lcols;
+    const int slab = (int)(q % a.nslab);
+    q /= a.nslab;
     const int seg = (int)(q % a.nseg);
     const int n = (int)(q / a.nseg);
+    const int c = (slab * a.cw + cl) << 2;
+    const int ox0 = lc * TW;
 
     f4 w[9];
 #pragma unroll
@@ -73,36 +83,34 @@ __global__ __launch_bounds__(256) void dw3x3_f32_nhwc(DwArgs a)
     const f4 sh = a.shift ? ld4(a.shift + c) : f4{ 0.f, 0.f, 0.f, 0.f };
 
     const float *img = a.in + (long)n * a.in_rows * a.in_cols * a.ch;
-    float *op = a.out + (((long)n * a.rows) * a.cols + ox) * a.ch + c;
+    float *op = a.out + (((long)n * a.rows) * a.cols + ox0) * a.ch + c;
     const int oy0 = seg * a.seg_rows;
     const int oy1 = min(oy0 + a.seg_rows, a.rows);
-    const int ix0 = ox * STRIDE - a.pad_left;
+    const int ix0 = ox0 * STRIDE - a.pad_left;
 
-    // window rows: r0 = input row oy*S - pad, r1 = +1, r2 = +2
-    f4 r0l, r0m, r0r, r1l, r1m, r1r, r2l, r2m, r2r;
+    f4 r0[NC], r1[NC], r2[NC];
     int iy = oy0 * STRIDE - a.pad_top;
-    load_row(a, img, iy, ix0, c, r0l, r0m, r0r);
-    if (STRIDE == 1) load_row(a, img, iy + 1, ix0, c, r1l, r1m, r1r);
+    load_row<NC>(a, img, iy, ix0, c, r0);
+    if (STRIDE == 1) load_row<NC>(a, img, iy + 1, ix0, c, r1);
 
     for (int oy = oy0; oy < oy1; oy++) {
         iy = oy * STRIDE - a.pad_top;
-        if (STRIDE == 1) {
-            load_row(a, img, iy + 2, ix0, c, r2l, r2m, r2r);
-        } else {
-            load_row(a, img, iy + 1, ix0, c, r1l, r1m, r1r);
-            load_row(a, img, iy + 2, ix0, c, r2l, r2m, r2r);
+        if (STRIDE == 2) load_row<NC>(a, img, iy + 1, ix0, c, r1);
+        load_row<NC>(a, img, iy + 2, ix0, c, r2);
+#pragma unroll
+        for (int p = 0; p < TW; p++) {
+            const int j = p * STRIDE;
+            f4 acc = f4{ 0.f, 0.f, 0.f, 0.f };
+            acc = fma4(r0[j], w[0], acc); acc = fma4(r0[j + 1], w[1], acc); acc = fma4(r0[j + 2], w[2], acc);
+            acc = fma4(r1[j], w[3], acc); acc = fma4(r1[j + 1], w[4], acc); acc = fma4(r1[j + 2], w[5], acc);
+            acc = fma4(r2[j], w[6], acc); acc = fma4(r2[j + 1], w[7], acc); acc = fma4(r2[j + 2], w[8], acc);
+            acc = act4(fma4(acc, sc, sh), a.act);
+            if (TW == 1 || ox0 + p < a.cols) *reinterpret_cast<f4 *>(op + ((long)oy * a.cols + p) * a.ch) = acc;
         }
-        f4 acc = f4{ 0.f, 0.f, 0.f, 0.f };
-        acc = fma4(r0l, w[0], acc); acc = fma4(r0m, w[1], acc); acc = fma4(r0r, w[2], acc);
-        acc = fma4(r1l, w[3], acc); acc = fma4(r1m, w[4], acc); acc = fma4(r1r, w[5], acc);
-        acc = fma4(r2l, w[6], acc); acc = fma4(r2m, w[7], acc); acc = fma4(r2r, w[8], acc);
-        acc = act4(fma4(acc, sc, sh), a.act);
-        *reinterpret_cast<f4 *>(op + (long)oy * a.cols * a.ch) = acc;
-        if (STRIDE == 1) {
-            r0l = r1l; r0m = r1m; r0r = r1r;
-            r1l = r2l; r1m = r2m; r1r = r2r;
-        } else {
-            r0l = r2l; r0m = r2m; r0r = r2r;
+#pragma unroll
+        for (int j = 0; j < NC; j++) {
+            if (STRIDE == 1) { r0[j] = r1[j]; r1[j] = r2[j]; }
+            else r0[j] = r2[j];
         }
     }
 }
@@ -151,27 +159,47 @@ int mbn_launch_f32_depthwise(const mbn_call &c, float *out, const float *in, con
                       ((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)filt % 16) == 0 &&
                       (!c.scale || ((uintptr_t)c.scale % 16) == 0) && (!c.shift || ((uintptr_t)c.shift % 16) == 0);
     if (!fast) {
-        a.seg_rows = rows; a.nseg = 1; a.total = 0;
+        a.seg_rows = rows; a.nseg = 1; a.total = 0; a.cw = a.nslab = a.lcols = 1;
         long total = (long)c.batch * rows * cols * channels;
         hipLaunchKernelGGL(dw_generic_f32_nhwc, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c.stream, a, fs,
                            stride);
         return MBN_OK;
     }
+    // variant: bit0..1 = TW-1 choice (0 default), bit 4 = legacy lane layout (cw = C/4)
+    const int var = g_mbn_tune.dw_variant;
+    int tw = (var & 3) ? (var & 3) : 2;              // default: 2 output columns per lane
+    if (tw > 2) tw = 2;
+    const int c4 = channels / 4;
+    int cw = c4;
+    if (!(var & 16)) {                               // slab of <= 16 lanes along channels (must divide C/4)
+        cw = c4 > 16 ? 16 : c4;
+        while (c4 % cw) cw--;
+    }
+    a.cw = cw;
+    a.nslab = c4 / cw;
+    a.lcols = (cols + tw - 1) / tw;
     // Segment the rows only when a full-height march would leave the chip under-filled: each extra segment
     // re-reads 2 halo rows (stride 1). Target >= ~2 resident rounds of 256 CUs x 2048 lanes.
-    const long cols_lanes = (long)c.batch * cols * (channels / 4);
+    const long row_lanes = (long)c.batch * a.lcols * c4;
     const long target = (long)c.ctx->num_cus * 2048 * 2;
     int nseg = 1;
-    if (cols_lanes < target) {
-        nseg = (int)((target + cols_lanes - 1) / cols_lanes);
+    if (g_mbn_tune.dw_nseg > 0) nseg = g_mbn_tune.dw_nseg;
+    else if (row_lanes < target) {
+        nseg = (int)((target + row_lanes - 1) / row_lanes);
         int max_seg = rows / 4 > 0 ? rows / 4 : 1;     // keep >= 4 output rows per segment
         if (nseg > max_seg) nseg = max_seg;
     }
+    if (nseg > rows) nseg = rows;
     a.seg_rows = (rows + nseg - 1) / nseg;
     a.nseg = (rows + a.seg_rows - 1) / a.seg_rows;
-    a.total = cols_lanes * a.nseg;
+    a.total = row_lanes * a.nseg;
     dim3 grid((unsigned)((a.total + 255) / 256));
-    if (stride == 1) hipLaunchKernelGGL(dw3x3_f32_nhwc<1>, grid, dim3(256), 0, c.stream, a);
-    else hipLaunchKernelGGL(dw3x3_f32_nhwc<2>, grid, dim3(256), 0, c.stream, a);
+    if (stride == 1) {
+        if (tw == 1) hipLaunchKernelGGL((dw3x3_f32_nhwc<1, 1>), grid, dim3(256), 0, c.stream, a);
+        else hipLaunchKernelGGL((dw3x3_f32_nhwc<1, 2>), grid, dim3(256), 0, c.stream, a);
+    } else {
+        if (tw == 1) hipLaunchKernelGGL((dw3x3_f32_nhwc<2, 1>), grid, dim3(256), 0, c.stream, a);
+        else hipLaunchKernelGGL((dw3x3_f32_nhwc<2, 2>), grid, dim3(256), 0, c.stream, a);
+    }
     return MBN_OK;
 }

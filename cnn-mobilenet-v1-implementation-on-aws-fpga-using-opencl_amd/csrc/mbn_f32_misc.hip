@@ -66,6 +66,79 @@ __global__ __launch_bounds__(256) void conv_f32_nhwc(ConvArgs a)
     *reinterpret_cast<f4 *>(a.out + t * 4) = v;
 }
 
+// Specialisation for the network's first layer (3x3, Cin = 3, stride 2): one lane = 4 consecutive output channels of
+// PX = 4 consecutive output pixels of one row. Per filter row the lane reads the 9 input pixels x 3 channels it needs
+// as 6 aligned float4 + 3 floats (27 contiguous floats of the NHWC row; the cout/4 lanes of a pixel group read the same
+// addresses, one request), and each LDS weight float4 is reused for the 4 pixels: 432 FMAs per 21 global + 27 LDS
+// loads instead of 108 per 27 + 27. Stores stay whole 128-B lines per pixel.
+__global__ __launch_bounds__(256) void conv3x3s2c3_f32_nhwc(ConvArgs a)
+{
+    constexpr int PX = 4;
+    extern __shared__ __attribute__((aligned(16))) float wlds[];
+    const int wcount = 27 * a.cout;
+    for (int i = threadIdx.x * 4; i < wcount; i += blockDim.x * 4)
+        *reinterpret_cast<f4 *>(wlds + i) = *reinterpret_cast<const f4 *>(a.filt + i);
+    __syncthreads();
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.total) return;
+    const int c4n = a.cout >> 2;
+    const int oc = (int)(t % c4n) << 2;
+    long q = t / c4n;
+    const int gcols = a.ocol / PX;
+    const int ox0 = (int)(q % gcols) * PX;
+    q /= gcols;
+    const int oy = (int)(q % a.orow);
+    const int n = (int)(q / a.orow);
+    const float *img = a.in + (long)n * a.rows * a.cols * 3;
+    const int ix0 = ox0 * 2;                       // pad_left == 0 on this path
+    const bool last_ok = ix0 + 2 * PX < a.cols;    // the 9th pixel is the right zero-pad column for the last group
+    f4 acc[PX];
+#pragma unroll
+    for (int p = 0; p < PX; p++) acc[p] = f4{ 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+    for (int ky = 0; ky < 3; ky++) {
+        const int iy = oy * 2 + ky - a.pad_top;
+        if (iy < 0 || iy >= a.rows) continue;      // wave-uniform except across the oy boundary of a wave
+        const float *row = img + ((long)iy * a.cols + ix0) * 3;
+        float v[27];
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            const f4 x = *reinterpret_cast<const f4 *>(row + 4 * j);
+            v[4 * j] = x.x; v[4 * j + 1] = x.y; v[4 * j + 2] = x.z; v[4 * j + 3] = x.w;
+        }
+        v[24] = last_ok ? row[24] : 0.f;
+        v[25] = last_ok ? row[25] : 0.f;
+        v[26] = last_ok ? row[26] : 0.f;
+#pragma unroll
+        for (int kx = 0; kx < 3; kx++)
+#pragma unroll
+            for (int ci = 0; ci < 3; ci++) {
+                const f4 w = *reinterpret_cast<const f4 *>(wlds + ((ky * 3 + kx) * 3 + ci) * a.cout + oc);
+#pragma unroll
+                for (int p = 0; p < PX; p++) {
+                    const float x = v[(2 * p + kx) * 3 + ci];
+                    acc[p].x = fmaf(x, w.x, acc[p].x); acc[p].y = fmaf(x, w.y, acc[p].y);
+                    acc[p].z = fmaf(x, w.z, acc[p].z); acc[p].w = fmaf(x, w.w, acc[p].w);
+                }
+            }
+    }
+    const f4 sc = a.scale ? *reinterpret_cast<const f4 *>(a.scale + oc) : f4{ 1.f, 1.f, 1.f, 1.f };
+    const f4 sh = a.shift ? *reinterpret_cast<const f4 *>(a.shift + oc) : f4{ 0.f, 0.f, 0.f, 0.f };
+    float *op = a.out + ((((long)n * a.orow + oy) * a.ocol + ox0) * a.cout) + oc;
+#pragma unroll
+    for (int p = 0; p < PX; p++) {
+        f4 r = f4{ fmaf(acc[p].x, sc.x, sh.x), fmaf(acc[p].y, sc.y, sh.y), fmaf(acc[p].z, sc.z, sh.z),
+                   fmaf(acc[p].w, sc.w, sh.w) };
+        if (a.act == MBN_ACT_RELU6) {
+            r.x = fminf(fmaxf(r.x, 0.f), 6.f); r.y = fminf(fmaxf(r.y, 0.f), 6.f);
+            r.z = fminf(fmaxf(r.z, 0.f), 6.f); r.w = fminf(fmaxf(r.w, 0.f), 6.f);
+        } else if (a.act == MBN_ACT_RELU) {
+            r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f);
+        }
+        *reinterpret_cast<f4 *>(op + (long)p * a.cout) = r;
+    }
+}
+
 // any cout / unaligned: one lane per output element, filter from global memory
 __global__ __launch_bounds__(256) void conv_generic_f32_nhwc(ConvArgs a)
 {
@@ -178,7 +251,13 @@ int mbn_launch_f32_conv(const mbn_call &c, float *out, const float *in, const fl
     const bool fast = (op_size % 4) == 0 && wbytes <= 64 * 1024 && ((uintptr_t)out % 16) == 0 &&
                       ((uintptr_t)filt % 16) == 0 && (!c.scale || ((uintptr_t)c.scale % 16) == 0) &&
                       (!c.shift || ((uintptr_t)c.shift % 16) == 0);
-    if (fast) {
+    const bool first_layer = fast && fs == 3 && c.cin == 3 && stride == 2 && a.pad_left == 0 && (cols % 4) == 0 &&
+                             (a.ocol % 4) == 0 && 2 * a.ocol == cols && ((uintptr_t)in % 16) == 0 &&
+                             g_mbn_tune.conv_variant != 1;
+    if (first_layer) {
+        a.total = (long)c.batch * a.orow * (a.ocol / 4) * (op_size / 4);
+        hipLaunchKernelGGL(conv3x3s2c3_f32_nhwc, dim3((unsigned)((a.total + 255) / 256)), dim3(256), wbytes, c.stream, a);
+    } else if (fast) {
         a.total = (long)c.batch * a.orow * a.ocol * (op_size / 4);
         hipLaunchKernelGGL(conv_f32_nhwc, dim3((unsigned)((a.total + 255) / 256)), dim3(256), wbytes, c.stream, a);
     } else {

@@ -40,14 +40,14 @@ constexpr int BK = 32;
 
 __device__ __forceinline__ int swz(int row, int chunk) { return (row << 5) + (((chunk ^ (row >> 1)) & 7) << 2); }
 
-template <int BM, int BN, int WM, int WN, int NBUF>
-__global__ __launch_bounds__(256) void pw_gemm_f32(PwArgs a)
+template <int BM, int BN, int WM, int WN, int NBUF, bool KFULL>
+__global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void pw_gemm_f32(PwArgs a)
 {
     constexpr int WAVES_N = BN / WN;
+    constexpr int NT = 64 * (BM / WM) * WAVES_N;              // threads per workgroup
     constexpr int MI = WM / 32, NI = WN / 32;
-    constexpr int A_LD = BM * 8 / 256, B_LD = BN * 8 / 256;   // float4 loads per thread per k-tile
-    static_assert((BM / WM) * WAVES_N == 4, "4 waves per workgroup");
-    static_assert(A_LD >= 1 && B_LD >= 1, "tile too small for 256 threads");
+    constexpr int A_LD = BM * 8 / NT, B_LD = BN * 8 / NT;     // float4 loads per thread per k-tile
+    static_assert(A_LD >= 1 && B_LD >= 1 && A_LD * NT == BM * 8 && B_LD * NT == BN * 8, "tile/threads mismatch");
     __shared__ __attribute__((aligned(16))) float lds[NBUF * (BM + BN) * BK];
 
     // XCD-aware bijective remap (cdna guide T1): same-XCD blocks get consecutive logical ids.
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void pw_gemm_f32(PwArgs a)
     int a_dst[A_LD], b_dst[B_LD], a_kc[A_LD], b_kc[B_LD];
 #pragma unroll
     for (int p = 0; p < A_LD; p++) {
-        int idx = p * 256 + tid, row = idx >> 3, ch = idx & 7;
+        int idx = p * NT + tid, row = idx >> 3, ch = idx & 7;
         long gm = m0 + row;
         if (gm >= a.m) gm = a.m - 1;                 // clamp: rows past M are computed but never stored
         a_src[p] = a.in + gm * a.k + ch * 4;
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void pw_gemm_f32(PwArgs a)
     }
 #pragma unroll
     for (int p = 0; p < B_LD; p++) {
-        int idx = p * 256 + tid, row = idx >> 3, ch = idx & 7;
+        int idx = p * NT + tid, row = idx >> 3, ch = idx & 7;
         int gn = n0 + row;
         if (gn >= a.n) gn = a.n - 1;
         b_src[p] = a.filt + (long)gn * a.k + ch * 4;
@@ -99,10 +99,10 @@ __global__ __launch_bounds__(256) void pw_gemm_f32(PwArgs a)
     auto stage_load = [&](int k0) {
 #pragma unroll
         for (int p = 0; p < A_LD; p++)
-            a_reg[p] = (k0 + a_kc[p] < a.k) ? *reinterpret_cast<const f4 *>(a_src[p] + k0) : zero4;
+            a_reg[p] = (KFULL || k0 + a_kc[p] < a.k) ? *reinterpret_cast<const f4 *>(a_src[p] + k0) : zero4;
 #pragma unroll
         for (int p = 0; p < B_LD; p++)
-            b_reg[p] = (k0 + b_kc[p] < a.k) ? *reinterpret_cast<const f4 *>(b_src[p] + k0) : zero4;
+            b_reg[p] = (KFULL || k0 + b_kc[p] < a.k) ? *reinterpret_cast<const f4 *>(b_src[p] + k0) : zero4;
     };
     auto stage_store = [&](int buf) {
         float *base = lds + buf * (BM + BN) * BK;
@@ -195,12 +195,21 @@ __global__ __launch_bounds__(256) void pw_generic_f32(PwArgs a)
     a.out[t] = v;
 }
 
-template <int BM, int BN, int WM, int WN, int NBUF>
+template <int BM, int BN, int WM, int WN>
 void launch_cfg(PwArgs &a, hipStream_t s)
 {
+    constexpr int NT = 64 * (BM / WM) * (BN / WN);
     a.mt = (int)((a.m + BM - 1) / BM);
     a.nt = (a.n + BN - 1) / BN;
-    hipLaunchKernelGGL((pw_gemm_f32<BM, BN, WM, WN, NBUF>), dim3((unsigned)(a.mt * a.nt)), dim3(256), 0, s, a);
+    const dim3 grid((unsigned)(a.mt * a.nt)), block(NT);
+    const bool kfull = (a.k % BK) == 0;
+    if (a.k <= BK) {
+        if (kfull) hipLaunchKernelGGL((pw_gemm_f32<BM, BN, WM, WN, 1, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((pw_gemm_f32<BM, BN, WM, WN, 1, false>), grid, block, 0, s, a);
+    } else {
+        if (kfull) hipLaunchKernelGGL((pw_gemm_f32<BM, BN, WM, WN, 2, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((pw_gemm_f32<BM, BN, WM, WN, 2, false>), grid, block, 0, s, a);
+    }
 }
 
 }   // namespace
@@ -211,24 +220,35 @@ int mbn_launch_f32_pointwise(const mbn_call &c, float *out, const float *in, con
     PwArgs a;
     a.out = out; a.in = in; a.filt = filt; a.scale = c.scale; a.shift = c.shift;
     a.m = m; a.k = cin; a.n = op_size; a.act = c.act; a.mt = a.nt = 0;
-    if (m <= 0 || (long)((m + 63) / 64) * ((op_size + 63) / 64) > 0x7fffffffL) return MBN_EINVAL;
+    if (m <= 0 || (long)((m + 31) / 32) * ((op_size + 31) / 32) > 0x7fffffffL) return MBN_EINVAL;
     const bool fast = (cin % 4) == 0 && ((uintptr_t)in % 16) == 0 && ((uintptr_t)filt % 16) == 0;
     if (!fast) {
         long total = m * op_size;
         hipLaunchKernelGGL(pw_generic_f32, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c.stream, a);
         return MBN_OK;
     }
-    const long big_tiles = ((m + 127) / 128) * ((op_size + 127) / 128);
-    if (big_tiles < (long)c.ctx->num_cus) {
-        // too few 128x128 tiles to fill the chip (FC at batch<=256, batch-1 late layers): 64x64 tiles
-        if (cin <= BK) launch_cfg<64, 64, 32, 32, 1>(a, c.stream);
-        else launch_cfg<64, 64, 32, 32, 2>(a, c.stream);
-    } else if (op_size <= 64) {
-        if (cin <= BK) launch_cfg<128, 64, 64, 32, 1>(a, c.stream);
-        else launch_cfg<128, 64, 64, 32, 2>(a, c.stream);
-    } else {
-        if (cin <= BK) launch_cfg<128, 128, 64, 64, 1>(a, c.stream);
-        else launch_cfg<128, 128, 64, 64, 2>(a, c.stream);
+    // Tile choice measured per layer on MI355X (tools/layer_bench.py --tune pw_tile=1..10, profiles/r01): every
+    // shape lands within a few % of each other (the loop is matrix-pipe bound), <128,64> with 3 workgroups per CU is
+    // best or tied from K = 256 up, 8 waves of 32x64 win slightly for K <= 256, 64x64 for narrow outputs / small grids.
+    int tile = g_mbn_tune.pw_tile;
+    if (tile == 0) {
+        const long big_tiles = ((m + 127) / 128) * ((op_size + 63) / 64);
+        if (big_tiles < 2L * c.ctx->num_cus || op_size <= 64) tile = 3;
+        else if (cin <= 256 && op_size >= 128) tile = 5;
+        else tile = 2;
+    }
+    switch (tile) {
+    case 1: launch_cfg<128, 128, 64, 64>(a, c.stream); break;   // 4 waves, 64 KB LDS, 2 WG/CU
+    case 2: launch_cfg<128, 64, 64, 32>(a, c.stream); break;    // 4 waves
+    case 3: launch_cfg<64, 64, 32, 32>(a, c.stream); break;     // 4 waves, small problems
+    case 4: launch_cfg<256, 128, 64, 64>(a, c.stream); break;   // 8 waves, 96 KB LDS, 1 WG/CU
+    case 5: launch_cfg<128, 128, 32, 64>(a, c.stream); break;   // 8 waves of 32x64, 2 WG/CU
+    case 6: launch_cfg<128, 256, 64, 64>(a, c.stream); break;   // 8 waves, 96 KB LDS
+    case 7: launch_cfg<64, 128, 32, 64>(a, c.stream); break;    // 4 waves, 48 KB LDS, 3 WG/CU
+    case 8: launch_cfg<128, 64, 32, 64>(a, c.stream); break;    // 4 waves of 32x64
+    case 9: launch_cfg<256, 64, 64, 64>(a, c.stream); break;    // 4 waves of 64x64, tall
+    case 10: launch_cfg<64, 256, 64, 64>(a, c.stream); break;   // 4 waves, wide
+    default: return MBN_EINVAL;
     }
     return MBN_OK;
 }

@@ -41,6 +41,16 @@ static inline int mbn_record_hip_error(mbn_context *ctx, hipError_t e, const cha
         if (_e != hipSuccess) return mbn_record_hip_error((ctx), _e, #expr);      \
     } while (0)
 
+// Process-wide tuning knobs (mbn_tune_set). 0 = shipped default everywhere.
+struct mbn_tunables {
+    int dw_variant = 0;   // depthwise kernel variant
+    int dw_nseg = 0;      // force row segments per image (0 = heuristic)
+    int pw_tile = 0;      // pointwise tile config override
+    int conv_variant = 0; // conv1 kernel variant
+    int misc = 0;
+};
+extern mbn_tunables g_mbn_tune;
+
 // Resolved per-call view of (positional args + ext) handed to the kernel launchers.
 struct mbn_call {
     mbn_context *ctx;

@@ -144,6 +144,7 @@ int  mbn_set_profiling(mbn_context *ctx, int enabled);   /* default 0: no events
  * the per-call milliseconds in call order. */
 int  mbn_profile_begin(mbn_context *ctx, int capacity);
 int  mbn_profile_end(mbn_context *ctx, float *ms, int ms_capacity, int *count);
+int  mbn_profile_pause(mbn_context *ctx, int paused);   /* 1: stop recording (slots keep their order), 0: resume */
 
 /* --------------------------------------------------------------- layer calls
  * Positional parameters are kernel.cl's, in kernel.cl's order and meaning:
@@ -296,6 +297,11 @@ int  mbn_net_set_keep_activations(mbn_net *net, int keep);
 int  mbn_net_layer_output(mbn_net *net, int index, void **dptr, size_t *floats_per_image);
 
 const char *mbn_version(void);
+
+/* Tuning hooks, process-wide: select among built kernel variants / launch heuristics for A/B measurements
+ * (tools/layer_bench.py). 0 always means "the shipped default". Unknown key => MBN_ENOTFOUND. */
+int  mbn_tune_set(const char *key, int value);
+int  mbn_tune_get(const char *key, int *value);
 
 #ifdef __cplusplus
 }
