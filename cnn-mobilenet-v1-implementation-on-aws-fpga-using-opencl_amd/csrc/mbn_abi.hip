@@ -17,6 +17,7 @@ static int *tune_slot(const char *key)
     if (!strcmp(key, "dw_variant")) return &g_mbn_tune.dw_variant;
     if (!strcmp(key, "dw_nseg")) return &g_mbn_tune.dw_nseg;
     if (!strcmp(key, "pw_tile")) return &g_mbn_tune.pw_tile;
+    if (!strcmp(key, "pw_stage")) return &g_mbn_tune.pw_stage;
     if (!strcmp(key, "conv_variant")) return &g_mbn_tune.conv_variant;
     if (!strcmp(key, "misc")) return &g_mbn_tune.misc;
     return nullptr;

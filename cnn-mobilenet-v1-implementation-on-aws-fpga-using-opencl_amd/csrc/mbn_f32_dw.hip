@@ -12,6 +12,8 @@
 // layers (C >= 64) CW is capped at 16 so that a 256-lane workgroup covers >= 16*TW columns of one 64-channel slab:
 // with CW = C/4 a workgroup of a 512-channel layer would hold 2 pixels and every halo request would miss the L1.
 // The 9 filter taps and scale/shift of the lane's 4 channels stay in registers for the whole march.
+// Measured and rejected (profiles/r01): non-temporal output stores (-5..-22 %), one column per lane (TW=1, -10 %),
+// channel-fastest lanes across the full C (-15..-40 % on the 512/1024-channel layers).
 #include "mbn_internal.h"
 
 namespace {
@@ -178,10 +180,12 @@ int mbn_launch_f32_depthwise(const mbn_call &c, float *out, const float *in, con
     a.cw = cw;
     a.nslab = c4 / cw;
     a.lcols = (cols + tw - 1) / tw;
-    // Segment the rows only when a full-height march would leave the chip under-filled: each extra segment
-    // re-reads 2 halo rows (stride 1). Target >= ~2 resident rounds of 256 CUs x 2048 lanes.
+    // Row segments: every extra segment re-reads 2 (stride 1) or 1 (stride 2) halo rows from HBM — measured as
+    // 19-36 % over-fetch (FETCH_SIZE, profiles/r01) when segmenting for "two full rounds" of lanes — so segment
+    // only when a full-height march leaves the chip under-filled: ~12 waves/CU for stride 1, ~6 for stride 2
+    // (whose lanes keep 10 loads in flight per step). tools/layer_bench.py --tune dw_nseg=... is the sweep.
     const long row_lanes = (long)c.batch * a.lcols * c4;
-    const long target = (long)c.ctx->num_cus * 2048 * 2;
+    const long target = (long)c.ctx->num_cus * 64 * (stride == 1 ? 12 : 6);
     int nseg = 1;
     if (g_mbn_tune.dw_nseg > 0) nseg = g_mbn_tune.dw_nseg;
     else if (row_lanes < target) {

@@ -46,6 +46,7 @@ struct mbn_tunables {
     int dw_variant = 0;   // depthwise kernel variant
     int dw_nseg = 0;      // force row segments per image (0 = heuristic)
     int pw_tile = 0;      // pointwise tile config override
+    int pw_stage = 0;     // 1 = register staging instead of direct-to-LDS loads
     int conv_variant = 0; // conv1 kernel variant
     int misc = 0;
 };
