@@ -5,6 +5,7 @@ written next to each test.
 Run with `pytest -m gpu` on the MI355X box. No test here reads /root/reference.
 """
 import ctypes as C
+import os
 import itertools
 
 import numpy as np
@@ -398,3 +399,53 @@ def test_net_batch_slice_equals_smaller_batch(pkg, ctx, tmp_path):
     ctx.sync()
     assert np.array_equal(full[4:8], d_out.download((4, 100), np.float32))
     net.destroy()
+
+
+# =========================================================================== the C host binary (./mobilenet)
+
+def test_c_host_binary_literal_and_fp32(pkg, orc, tmp_path):
+    """`mobilenet` is the counterpart of the reference's ./out: plain C over the C-ABI. --literal runs the 29 integer
+    layers with the reference's loaders (weights_c.txt prefix re-read per layer, raw image bytes incl. PPM header) and
+    prints the reference's two kinds of line; check the printed argmax against the oracle run on the same inputs."""
+    import re
+    import subprocess
+    exe = os.path.join(pkg.PKG_DIR, "mobilenet")
+    assert os.path.exists(exe)
+    rng = np.random.default_rng(12)
+    wtxt = tmp_path / "weights_c.txt"
+    w = rng.integers(-1, 2, 1024 * 1024)
+    wtxt.write_text(" ".join("%d.0" % v for v in w))
+    img = rng.integers(0, 256, (224, 224, 3), dtype=np.uint8)
+    ppm = str(tmp_path / "Cat_Image0.ppm")
+    assert pkg.load().mbn_write_ppm(ppm.encode(), img.ctypes.data, 224, 224) == 0
+    r = subprocess.run([exe, "--literal", "--weights", str(wtxt), "--image", ppm], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert len(re.findall(r"Kernel Execution time for Layer \d+: ", r.stdout)) == 28
+    assert "Kernel Execution time for Fully Connected Layer" in r.stdout
+    m = re.search(r"present at location (\d+) and it's value is ([0-9.]+)", r.stdout)
+    assert m, r.stdout
+    # the same pipeline on the oracle: decode_image semantics = raw bytes from offset 0 (header included, B14)
+    raw = np.frombuffer(open(ppm, "rb").read()[:224 * 224 * 3], np.uint8).reshape(-1, 3)
+    planes = [np.ascontiguousarray(raw[:, k]) for k in range(3)]
+    plan = orc.plan_build(1.0, 224, 1000)
+    q = orc.QUIRKS_KERNEL_CL
+    x = None
+    for i in range(plan.n_layers):
+        l = plan.layer[i]
+        f = np.int32(w[:max(l.w_count, 1)])
+        if l.kind == orc.L_CONV:
+            x = orc.lit_convolute(*planes, f, 224, 224, 3, 2, l.out_ch, quirks=q)
+        elif l.kind == orc.L_DW:
+            x = orc.lit_depthwise(x, f, l.out_rows, l.out_cols, 3, l.stride, l.out_ch, quirks=q)
+        elif l.kind in (orc.L_PW, orc.L_FC):
+            x = orc.lit_pointwise(x, f, l.out_rows, l.out_cols, l.in_ch, l.out_ch, quirks=q)
+        else:
+            x = orc.lit_pool(x, l.in_rows, l.in_cols, 7, l.out_ch, quirks=q)
+    _, loc, mx = orc.softmax_argmax_u8(x)
+    assert int(m.group(1)) == loc and abs(float(m.group(2)) - mx) < 1e-5
+    # fp32 mode with synthetic weights: runs, prints 29 layer lines and a class in range
+    r = subprocess.run([exe, "--synthetic", "5", "--alpha", "0.25", "--res", "96", "--batch", "3"], capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    m = re.search(r"present at location (\d+) and it's value is ([0-9.]+)", r.stdout)
+    assert m and 1 <= int(m.group(1)) <= 1000 and 0 < float(m.group(2)) <= 1.0
