@@ -422,7 +422,7 @@ def test_c_host_binary_literal_and_fp32(pkg, orc, tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     assert len(re.findall(r"Kernel Execution time for Layer \d+: ", r.stdout)) == 28
     assert "Kernel Execution time for Fully Connected Layer" in r.stdout
-    m = re.search(r"present at location (\d+) and it's value is ([0-9.]+)", r.stdout)
+    m = re.search(r"present at location (\d+) and it's value is ([0-9]+\.[0-9]+)", r.stdout)
     assert m, r.stdout
     # the same pipeline on the oracle: decode_image semantics = raw bytes from offset 0 (header included, B14)
     raw = np.frombuffer(open(ppm, "rb").read()[:224 * 224 * 3], np.uint8).reshape(-1, 3)
@@ -447,5 +447,5 @@ def test_c_host_binary_literal_and_fp32(pkg, orc, tmp_path):
     r = subprocess.run([exe, "--synthetic", "5", "--alpha", "0.25", "--res", "96", "--batch", "3"], capture_output=True,
                        text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
-    m = re.search(r"present at location (\d+) and it's value is ([0-9.]+)", r.stdout)
+    m = re.search(r"present at location (\d+) and it's value is ([0-9]+\.[0-9]+)", r.stdout)
     assert m and 1 <= int(m.group(1)) <= 1000 and 0 < float(m.group(2)) <= 1.0
