@@ -31,21 +31,32 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix peak
 
 
-def layer_work(l, batch, pkg):
+def layer_work(l, batch, pkg, act_bytes=4.0):
     """Algorithmic FLOPs and HBM bytes of one layer launch (input read once, output
-    written once, fp32; weights counted once per launch)."""
-    in_b = 4.0 * l.in_rows * l.in_cols * l.in_ch * batch
-    out_b = 4.0 * l.out_rows * l.out_cols * l.out_ch * batch
+    written once; weights counted once per launch). act_bytes = 4 (fp32) or 2 (bf16 activations; conv1 still
+    reads the fp32 image, FC still writes fp32 logits)."""
+    in_b = (4.0 if l.kind == pkg.L_CONV else act_bytes) * l.in_rows * l.in_cols * l.in_ch * batch
+    out_b = (4.0 if l.kind == pkg.L_FC else act_bytes) * l.out_rows * l.out_cols * l.out_ch * batch
     px = float(l.out_rows * l.out_cols * batch)
     if l.kind == pkg.L_CONV:
         flops, w = 2.0 * 27 * l.out_ch * px, 4.0 * 27 * l.out_ch
     elif l.kind == pkg.L_DW:
         flops, w = 2.0 * 9 * l.out_ch * px, 4.0 * 9 * l.out_ch
     elif l.kind in (pkg.L_PW, pkg.L_FC):
-        flops, w = 2.0 * l.in_ch * l.out_ch * px, 4.0 * l.in_ch * l.out_ch
+        flops, w = 2.0 * l.in_ch * l.out_ch * px, act_bytes * l.in_ch * l.out_ch
     else:
         flops, w = float(l.in_rows * l.in_cols * l.in_ch * batch), 0.0
     return flops, in_b + out_b + w
+
+
+def load_traffic():
+    """HBM bytes per launch of the dominant kernel from the PMC counters (FETCH_SIZE x2 on gfx950 + WRITE_SIZE), measured
+    in separate rocprofv3 --pmc passes of this same workload (tools/pmc_pass.sh) and committed under profiles/.
+    bench.py cannot run the profiler on itself, so it reports the committed measurement, or null when there is none."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["pointwise_avg_bytes_per_launch"]
+    except Exception:
+        return None
 
 
 def main():
@@ -56,6 +67,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
     ap.add_argument("--alpha", type=float, default=1.0)
     ap.add_argument("--res", type=int, default=224)
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="storage type of activations and pointwise filters (arithmetic is fp32 either way)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=0, help="images in the CPU baseline sample (0 = auto)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the CPU baseline (cap; box share is 16)")
@@ -101,6 +114,11 @@ def main():
 
     ctx = pkg.Context(local_rank)
     net = pkg.Net(ctx, plan, blob_t.data_ptr(), args.batch)
+    bf16 = args.dtype == "bf16"
+    if bf16:
+        net.set_dtype(pkg.DT_BF16)
+    act_bytes = 2.0 if bf16 else 4.0
+    mfma_peak = 2500.0 if bf16 else MFMA_F32_PEAK_TFLOPS      # dense bf16 MFMA peak ~2.5 PFLOP/s (MI355X_MICROARCH.md)
 
     # ---- synthetic input, U[-1,1) (Keras x/127.5-1 range), generated on the host then uploaded once
     rng = np.random.default_rng(0xC0FFEE + rank)
@@ -164,10 +182,12 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": args.dtype,
             "data": "synthetic",
-            "config": {"workload": "MobileNet-V1 %.2gx%d fp32, batch %d per GPU, 29 layers, 1000 classes "
-                                   "(BASELINE.json configs[2])" % (args.alpha, args.res, args.batch),
+            "config": {"workload": "MobileNet-V1 %.2gx%d %s, batch %d per GPU, 29 layers, 1000 classes%s"
+                                   % (args.alpha, args.res, "bf16" if bf16 else "fp32", args.batch,
+                                      " (BASELINE.json configs[2])" if (not bf16 and args.alpha == 1.0 and args.res == 224
+                                                                         and args.batch == 256) else ""),
                        "global_batch": args.batch * world, "per_gpu_batch": args.batch,
                        "parallelism": "batch-sharded x%d, weights broadcast once over RCCL" % world,
                        "device": ctx.name()},
@@ -178,30 +198,41 @@ def main():
             stages, per_layer = {}, []
             for i in range(n_layers):
                 l = plan.layer[i]
-                f, b = layer_work(l, args.batch, pkg)
+                f, b = layer_work(l, args.batch, pkg, act_bytes)
                 per_layer.append({"layer": i + 1, "kind": int(l.kind), "ms": round(float(layer_ms[i]), 5),
                                   "GBps": round(b / layer_ms[i] / 1e6, 1), "TFLOPs": round(f / layer_ms[i] / 1e9, 2)})
             for name, kinds in groups.items():
                 idx = [i for i in range(n_layers) if plan.layer[i].kind in kinds]
-                fl = sum(layer_work(plan.layer[i], args.batch, pkg)[0] for i in idx)
-                by = sum(layer_work(plan.layer[i], args.batch, pkg)[1] for i in idx)
+                fl = sum(layer_work(plan.layer[i], args.batch, pkg, act_bytes)[0] for i in idx)
+                by = sum(layer_work(plan.layer[i], args.batch, pkg, act_bytes)[1] for i in idx)
                 ms_sum = float(sum(layer_ms[i] for i in idx))
                 st = {"launches": len(idx), "ms": round(ms_sum, 4), "GBps": round(by / ms_sum / 1e6, 1),
                       "TFLOPs": round(fl / ms_sum / 1e9, 2)}
                 st["frac_hbm"] = round(st["GBps"] / HBM_PEAK_GBS, 4)
-                st["frac_mfma"] = round(st["TFLOPs"] / MFMA_F32_PEAK_TFLOPS, 4)
+                st["frac_mfma"] = round(st["TFLOPs"] / mfma_peak, 4)
                 stages[name] = st
             pw = stages["pointwise"]
             pw_idx = [i for i in range(n_layers) if plan.layer[i].kind == pkg.L_PW]
-            flops_per_launch = sum(layer_work(plan.layer[i], args.batch, pkg)[0] for i in pw_idx) / len(pw_idx)
+            flops_per_launch = sum(layer_work(plan.layer[i], args.batch, pkg, act_bytes)[0] for i in pw_idx) / len(pw_idx)
+            bytes_per_launch = sum(layer_work(plan.layer[i], args.batch, pkg, act_bytes)[1] for i in pw_idx) / len(pw_idx)
             avg_ms = pw["ms"] / len(pw_idx)
-            out["roofline"] = {
-                "kernel": "pw_gemm_f32 (13 pointwise 1x1 conv launches per step)",
-                "bound": "mfma", "achieved": round(flops_per_launch / avg_ms / 1e9, 2), "peak": MFMA_F32_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(flops_per_launch / avg_ms / 1e9 / MFMA_F32_PEAK_TFLOPS, 4),
-                "traffic": None, "avg_launch_ms": round(avg_ms, 5),
-                "algorithmic_flops_per_launch": flops_per_launch,
-            }
+            if bf16:       # ridge ~312 flop/B: every pointwise layer is HBM-bound in bf16
+                out["roofline"] = {
+                    "kernel": "pw_gemm<bf16> (13 pointwise 1x1 conv launches per step)",
+                    "bound": "hbm", "achieved": round(bytes_per_launch / avg_ms / 1e6, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(bytes_per_launch / avg_ms / 1e6 / HBM_PEAK_GBS, 4),
+                    "traffic": None, "avg_launch_ms": round(avg_ms, 5),
+                    "algorithmic_bytes_per_launch": bytes_per_launch,
+                }
+            else:
+                out["roofline"] = {
+                    "kernel": "pw_gemm<float> (13 pointwise 1x1 conv launches per step)",
+                    "bound": "mfma", "achieved": round(flops_per_launch / avg_ms / 1e9, 2), "peak": MFMA_F32_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(flops_per_launch / avg_ms / 1e9 / MFMA_F32_PEAK_TFLOPS, 4),
+                    "traffic": load_traffic(), "avg_launch_ms": round(avg_ms, 5),
+                    "algorithmic_flops_per_launch": flops_per_launch,
+                    "algorithmic_bytes_per_launch": bytes_per_launch,
+                }
             out["stages"] = stages
             out["layers"] = per_layer
             out["sum_kernel_ms"] = round(float(layer_ms.sum()), 4)
@@ -216,7 +247,7 @@ def main():
             blob = blob_t.cpu().numpy()
             sample = np.random.default_rng(1).random((n_img, args.res, args.res, 3), dtype=np.float32) * 2 - 1
             c0 = time.perf_counter()
-            ref, _ = orc.net_forward(oplan, blob, sample, threads=cores)
+            ref, _ = orc.net_forward(oplan, blob, sample, threads=cores, bf16=bf16)
             c1 = time.perf_counter()
             out["cpu_baseline"] = {"value": n_img / (c1 - c0), "unit": "images/sec", "cores": cores, "kind": "port",
                                    "sample": "%d images, same network/weights, C restatement of kernel.cl semantics "

@@ -24,6 +24,7 @@ HEADER = os.path.join(REPO_ROOT, "include", "mbn.h")
 OK, EINVAL, ENOMEM, EDEVICE, EIO, EFORMAT, ENOTFOUND, ESHAPE, EUNSUPPORTED, ENODEVICE = 0, -1, -2, -3, -4, -5, -6, -7, -8, -9
 DT_U8, DT_F32, DT_BF16 = 0, 1, 2
 LAYOUT_NCHW_PLANAR, LAYOUT_NHWC = 0, 1
+IO_IN_F32, IO_OUT_F32 = 1, 2
 ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
 Q_CARRY_SUM, Q_DW_PLANE0, Q_LITERAL_INDEX, Q_POOL_DIV49 = 1, 2, 4, 8
 QUIRKS_NONE, QUIRKS_KERNEL_CL = 0, 0xF
@@ -42,7 +43,7 @@ class LayerExt(C.Structure):
                 ("act", C.c_int32), ("pad_top", C.c_int32), ("pad_left", C.c_int32), ("in_rows", C.c_int32),
                 ("in_cols", C.c_int32), ("cin", C.c_int32), ("gsize0", C.c_int32), ("gsize1", C.c_int32),
                 ("quirks", C.c_uint32), ("quirks_valid", C.c_int32), ("scale", C.c_void_p), ("shift", C.c_void_p),
-                ("stream", C.c_void_p)]
+                ("stream", C.c_void_p), ("io_flags", C.c_int32), ("reserved", C.c_int32)]
 
 
 class LayerDesc(C.Structure):
@@ -144,6 +145,9 @@ def load():
         lib.mbn_pool.argtypes = [vp, vp, vp, ci, ci, ci, ci, ext]
         lib.mbn_softmax_f32.argtypes = [vp, vp, vp, vp, ci, ci, vp]
         lib.mbn_normalize_u8_to_f32.argtypes = [vp, vp, vp, C.c_size_t, C.c_float, C.c_float, vp]
+        lib.mbn_convert_f32_to_bf16.argtypes = [vp, vp, vp, C.c_size_t, vp]
+        lib.mbn_convert_bf16_to_f32.argtypes = [vp, vp, vp, C.c_size_t, vp]
+        lib.mbn_net_set_dtype.argtypes = [vp, ci]
         lib.mbn_net_create.argtypes = [vp, C.POINTER(Weights), ci, C.POINTER(vp)]
         lib.mbn_net_create_from_device_blob.argtypes = [vp, C.POINTER(Plan), vp, ci, C.POINTER(vp)]
         lib.mbn_net_destroy.argtypes = [vp]
@@ -178,12 +182,13 @@ def declared_symbols():
 
 
 def make_ext(batch=1, dtype=DT_F32, act=ACT_RELU6, pad_top=-1, pad_left=-1, in_rows=0, in_cols=0, cin=0, scale=None,
-             shift=None, quirks=None, gsize=(0, 0), stream=None) -> LayerExt:
+             shift=None, quirks=None, gsize=(0, 0), stream=None, io_flags=0) -> LayerExt:
     e = LayerExt()
     e.struct_size = C.sizeof(LayerExt)
     e.batch = batch
     e.dtype = dtype
-    e.layout = LAYOUT_NHWC if dtype == DT_F32 else LAYOUT_NCHW_PLANAR
+    e.layout = LAYOUT_NCHW_PLANAR if dtype == DT_U8 else LAYOUT_NHWC
+    e.io_flags = io_flags
     e.act = act
     e.pad_top, e.pad_left = pad_top, pad_left
     e.in_rows, e.in_cols, e.cin = in_rows, in_cols, cin
@@ -194,6 +199,17 @@ def make_ext(batch=1, dtype=DT_F32, act=ACT_RELU6, pad_top=-1, pad_left=-1, in_r
     e.shift = shift
     e.stream = stream
     return e
+
+
+def bf16_bits_to_f32(raw: np.ndarray) -> np.ndarray:
+    """uint16 bf16 bit patterns -> float32 values."""
+    return (raw.astype(np.uint32) << 16).view(np.float32)
+
+
+def f32_to_bf16_bits(x: np.ndarray) -> np.ndarray:
+    """float32 -> bf16 bit patterns, round to nearest even (host-side helper for tests)."""
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
 
 
 class DeviceBuffer:
@@ -345,6 +361,10 @@ class Net:
         _chk(self.ctx.lib.mbn_net_forward_timed(self.h, images_ptr, out_ptr, batch, ms, MAX_LAYERS), self.ctx.last_error())
         return [ms[i] for i in range(self.plan.n_layers)]
 
+    def set_dtype(self, dtype):
+        self.dtype = dtype
+        _chk(self.ctx.lib.mbn_net_set_dtype(self.h, dtype), self.ctx.last_error())
+
     def keep_activations(self, keep=True):
         _chk(self.ctx.lib.mbn_net_set_keep_activations(self.h, int(keep)))
 
@@ -352,7 +372,12 @@ class Net:
         p, n = C.c_void_p(), C.c_size_t()
         _chk(self.ctx.lib.mbn_net_layer_output(self.h, index, C.byref(p), C.byref(n)))
         l = self.plan.layer[index - 1]
-        out = np.empty((batch, l.out_rows, l.out_cols, l.out_ch), np.float32)
+        shape = (batch, l.out_rows, l.out_cols, l.out_ch)
+        if getattr(self, "dtype", DT_F32) == DT_BF16 and l.kind != L_FC:
+            raw = np.empty(shape, np.uint16)
+            _chk(self.ctx.lib.mbn_download(self.ctx.h, raw.ctypes.data, p, raw.nbytes))
+            return bf16_bits_to_f32(raw)
+        out = np.empty(shape, np.float32)
         _chk(self.ctx.lib.mbn_download(self.ctx.h, out.ctypes.data, p, out.nbytes))
         return out
 

@@ -282,10 +282,12 @@ int resolve(mbn_context *ctx, const mbn_layer_ext *ext, mbn_call *c, int *dtype)
     if (!ext) return MBN_OK;
     if (ext->struct_size != sizeof(mbn_layer_ext)) return MBN_EINVAL;
     *dtype = ext->dtype;
-    if (ext->dtype == MBN_DT_BF16) return MBN_EUNSUPPORTED;
-    if (ext->dtype != MBN_DT_U8 && ext->dtype != MBN_DT_F32) return MBN_EINVAL;
+    if (ext->dtype != MBN_DT_U8 && ext->dtype != MBN_DT_F32 && ext->dtype != MBN_DT_BF16) return MBN_EINVAL;
     if (ext->dtype == MBN_DT_U8 && ext->layout != MBN_LAYOUT_NCHW_PLANAR) return MBN_EUNSUPPORTED;
-    if (ext->dtype == MBN_DT_F32 && ext->layout != MBN_LAYOUT_NHWC) return MBN_EUNSUPPORTED;
+    if (ext->dtype != MBN_DT_U8 && ext->layout != MBN_LAYOUT_NHWC) return MBN_EUNSUPPORTED;
+    if (ext->io_flags & ~(MBN_IO_IN_F32 | MBN_IO_OUT_F32)) return MBN_EINVAL;
+    c->dtype = ext->dtype;
+    c->io_flags = ext->dtype == MBN_DT_BF16 ? ext->io_flags : 0;
     if (ext->batch < 0) return MBN_EINVAL;
     c->batch = ext->batch > 0 ? ext->batch : 1;
     if (ext->act < MBN_ACT_NONE || ext->act > MBN_ACT_RELU6) return MBN_EINVAL;
@@ -331,8 +333,7 @@ int mbn_convolute(mbn_context *ctx, void *output, const void *inp_r, const void 
                                                   filtersize, stride, op_size));
     }
     if (c.cin <= 0) c.cin = 3;
-    return sc.finish(mbn_launch_f32_conv(c, (float *)output, (const float *)inp_r, (const float *)filter_k, rows, cols,
-                                         filtersize, stride, op_size));
+    return sc.finish(mbn_launch_f32_conv(c, output, inp_r, (const float *)filter_k, rows, cols, filtersize, stride, op_size));
 }
 
 int mbn_depthwise(mbn_context *ctx, void *output, const void *inp_image, const void *filter_k, int rows, int cols,
@@ -351,8 +352,8 @@ int mbn_depthwise(mbn_context *ctx, void *output, const void *inp_image, const v
     if (dtype == MBN_DT_U8)
         return sc.finish(mbn_launch_lit_depthwise(c, (uint8_t *)output, (const uint8_t *)inp_image,
                                                   (const int32_t *)filter_k, rows, cols, filtersize, stride, op_size));
-    return sc.finish(mbn_launch_f32_depthwise(c, (float *)output, (const float *)inp_image, (const float *)filter_k,
-                                              rows, cols, filtersize, stride, op_size));
+    return sc.finish(mbn_launch_f32_depthwise(c, output, inp_image, (const float *)filter_k, rows, cols, filtersize, stride,
+                                              op_size));
 }
 
 int mbn_pointwise(mbn_context *ctx, void *output, const void *inp_image, const void *filter_k, int rows, int cols,
@@ -369,8 +370,7 @@ int mbn_pointwise(mbn_context *ctx, void *output, const void *inp_image, const v
         return sc.finish(mbn_launch_lit_pointwise(c, (uint8_t *)output, (const uint8_t *)inp_image,
                                                   (const int32_t *)filter_k, rows, cols, filtersize, op_size));
     long m = (long)c.batch * rows * cols;
-    return sc.finish(mbn_launch_f32_pointwise(c, (float *)output, (const float *)inp_image, (const float *)filter_k, m,
-                                              filtersize, op_size));
+    return sc.finish(mbn_launch_f32_pointwise(c, output, inp_image, filter_k, m, filtersize, op_size));
 }
 
 int mbn_pool(mbn_context *ctx, void *output, const void *inp_image, int rows, int cols, int filtersize, int op_size,
@@ -388,7 +388,7 @@ int mbn_pool(mbn_context *ctx, void *output, const void *inp_image, int rows, in
         return sc.finish(mbn_launch_lit_pool(c, (uint8_t *)output, (const uint8_t *)inp_image, rows, cols, filtersize,
                                              op_size));
     }
-    return sc.finish(mbn_launch_f32_pool(c, (float *)output, (const float *)inp_image, rows, cols, filtersize, op_size));
+    return sc.finish(mbn_launch_f32_pool(c, output, inp_image, rows, cols, filtersize, op_size));
 }
 
 int mbn_softmax_f32(mbn_context *ctx, void *probs, void *argmax_i32, const void *logits, int batch, int classes,
@@ -399,6 +399,24 @@ int mbn_softmax_f32(mbn_context *ctx, void *probs, void *argmax_i32, const void 
     Scope sc(ctx, s);
     return sc.finish(mbn_launch_f32_softmax(ctx, s, (float *)probs, (int32_t *)argmax_i32, (const float *)logits, batch,
                                             classes));
+}
+
+int mbn_convert_f32_to_bf16(mbn_context *ctx, void *dst_bf16, const void *src_f32, size_t count, void *stream)
+{
+    if (!ctx || !dst_bf16 || !src_f32) return MBN_EINVAL;
+    if (count == 0) return MBN_OK;
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    Scope sc(ctx, s);
+    return sc.finish(mbn_launch_convert(ctx, s, dst_bf16, src_f32, count, 1));
+}
+
+int mbn_convert_bf16_to_f32(mbn_context *ctx, void *dst_f32, const void *src_bf16, size_t count, void *stream)
+{
+    if (!ctx || !dst_f32 || !src_bf16) return MBN_EINVAL;
+    if (count == 0) return MBN_OK;
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    Scope sc(ctx, s);
+    return sc.finish(mbn_launch_convert(ctx, s, dst_f32, src_bf16, count, 0));
 }
 
 int mbn_normalize_u8_to_f32(mbn_context *ctx, void *out_f32, const void *in_u8, size_t count, float scale, float bias,

@@ -1,10 +1,10 @@
-// mbn_f32_dw.hip — fp32 NHWC 3x3 depthwise conv + folded-BN scale/shift + ReLU/ReLU6 for gfx950.
-// Replaces the arithmetic of the reference's `depthwise` kernel (kernel.cl:62-92) in the fp32 mode the metric
-// measures. HBM-bound (0.9-2.2 flop/B): the design goal is to read every input byte once and write every
-// output byte once with 16-B-per-lane, coalesced accesses, and to keep enough loads in flight.
+// mbn_f32_dw.hip — NHWC 3x3 depthwise conv + folded-BN scale/shift + ReLU/ReLU6 for gfx950 (fp32 or bf16 storage,
+// fp32 arithmetic). Replaces the arithmetic of the reference's `depthwise` kernel (kernel.cl:62-92) in the mode the
+// metric measures. HBM-bound (0.9-2.2 flop/B): the design goal is to read every input byte once and write every
+// output byte once with wide, coalesced accesses, and to keep enough loads in flight.
 //
-// Decomposition ("column march"): a lane owns 4 consecutive channels (one float4) of TW adjacent output columns
-// and walks DOWN the output rows of one segment, keeping the 3 x (TW*S+2) input window of float4s in registers.
+// Decomposition ("column march"): a lane owns 4 consecutive channels (one float4 / four bf16) of TW adjacent output
+// columns and walks DOWN the output rows of one segment, keeping the 3 x (TW*S+2) input window in registers as fp32.
 // Each new output row needs only STRIDE new input rows, so an input element is requested (TW*S+2)/(TW*S) times
 // per row instead of 9/S^2 times; the left/right halo requests are served by the L1 of the same workgroup because
 // the lanes that own the neighbouring columns sit in the same wave or the next one.
@@ -19,8 +19,19 @@
 namespace {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ f4 ld4(const float *p) { return *reinterpret_cast<const f4 *>(p); }
+__device__ __forceinline__ f4 ld4(const __bf16 *p)
+{
+    const bf4 v = *reinterpret_cast<const bf4 *>(p);
+    return f4{ (float)v.x, (float)v.y, (float)v.z, (float)v.w };
+}
+__device__ __forceinline__ void st4(float *p, f4 v) { *reinterpret_cast<f4 *>(p) = v; }
+__device__ __forceinline__ void st4(__bf16 *p, f4 v)
+{
+    *reinterpret_cast<bf4 *>(p) = bf4{ (__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w };   // RNE
+}
 __device__ __forceinline__ f4 fma4(f4 a, f4 b, f4 c)
 {
     return f4{ fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w) };
@@ -37,8 +48,9 @@ __device__ __forceinline__ f4 act4(f4 v, int act)
 }
 
 struct DwArgs {
-    float *out;
-    const float *in, *filt, *scale, *shift;
+    void *out;
+    const void *in;
+    const float *filt, *scale, *shift;
     int batch, in_rows, in_cols, rows, cols, ch, pad_top, pad_left, act;
     int seg_rows, nseg;     // output rows per segment / segments per image
     int cw;                 // lanes along channels inside a slab (channels per slab = 4*cw)
@@ -47,12 +59,12 @@ struct DwArgs {
     long total;             // lanes with work
 };
 
-// One input row for a lane: NC = TW*STRIDE+2 float4 at columns ix0 .. ix0+NC-1; zero outside the image.
-template <int NC>
-__device__ __forceinline__ void load_row(const DwArgs &a, const float *img, int iy, int ix0, int c, f4 (&r)[NC])
+// One input row for a lane: NC = TW*STRIDE+2 channel-quads at columns ix0 .. ix0+NC-1; zero outside the image.
+template <int NC, typename T>
+__device__ __forceinline__ void load_row(const DwArgs &a, const T *img, int iy, int ix0, int c, f4 (&r)[NC])
 {
     const bool rowok = iy >= 0 && iy < a.in_rows;
-    const float *row = img + ((long)iy * a.in_cols) * a.ch + c;
+    const T *row = img + ((long)iy * a.in_cols) * a.ch + c;
 #pragma unroll
     for (int j = 0; j < NC; j++) {
         const int ix = ix0 + j;
@@ -60,8 +72,8 @@ __device__ __forceinline__ void load_row(const DwArgs &a, const float *img, int 
     }
 }
 
-template <int STRIDE, int TW>
-__global__ __launch_bounds__(256) void dw3x3_f32_nhwc(DwArgs a)
+template <int STRIDE, int TW, typename T>
+__global__ __launch_bounds__(256) void dw3x3_nhwc(DwArgs a)
 {
     constexpr int NC = TW * STRIDE + 2;
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -84,21 +96,21 @@ __global__ __launch_bounds__(256) void dw3x3_f32_nhwc(DwArgs a)
     const f4 sc = a.scale ? ld4(a.scale + c) : f4{ 1.f, 1.f, 1.f, 1.f };
     const f4 sh = a.shift ? ld4(a.shift + c) : f4{ 0.f, 0.f, 0.f, 0.f };
 
-    const float *img = a.in + (long)n * a.in_rows * a.in_cols * a.ch;
-    float *op = a.out + (((long)n * a.rows) * a.cols + ox0) * a.ch + c;
+    const T *img = reinterpret_cast<const T *>(a.in) + (long)n * a.in_rows * a.in_cols * a.ch;
+    T *op = reinterpret_cast<T *>(a.out) + (((long)n * a.rows) * a.cols + ox0) * a.ch + c;
     const int oy0 = seg * a.seg_rows;
     const int oy1 = min(oy0 + a.seg_rows, a.rows);
     const int ix0 = ox0 * STRIDE - a.pad_left;
 
     f4 r0[NC], r1[NC], r2[NC];
     int iy = oy0 * STRIDE - a.pad_top;
-    load_row<NC>(a, img, iy, ix0, c, r0);
-    if (STRIDE == 1) load_row<NC>(a, img, iy + 1, ix0, c, r1);
+    load_row<NC, T>(a, img, iy, ix0, c, r0);
+    if (STRIDE == 1) load_row<NC, T>(a, img, iy + 1, ix0, c, r1);
 
     for (int oy = oy0; oy < oy1; oy++) {
         iy = oy * STRIDE - a.pad_top;
-        if (STRIDE == 2) load_row<NC>(a, img, iy + 1, ix0, c, r1);
-        load_row<NC>(a, img, iy + 2, ix0, c, r2);
+        if (STRIDE == 2) load_row<NC, T>(a, img, iy + 1, ix0, c, r1);
+        load_row<NC, T>(a, img, iy + 2, ix0, c, r2);
 #pragma unroll
         for (int p = 0; p < TW; p++) {
             const int j = p * STRIDE;
@@ -107,7 +119,7 @@ __global__ __launch_bounds__(256) void dw3x3_f32_nhwc(DwArgs a)
             acc = fma4(r1[j], w[3], acc); acc = fma4(r1[j + 1], w[4], acc); acc = fma4(r1[j + 2], w[5], acc);
             acc = fma4(r2[j], w[6], acc); acc = fma4(r2[j + 1], w[7], acc); acc = fma4(r2[j + 2], w[8], acc);
             acc = act4(fma4(acc, sc, sh), a.act);
-            if (TW == 1 || ox0 + p < a.cols) *reinterpret_cast<f4 *>(op + ((long)oy * a.cols + p) * a.ch) = acc;
+            if (TW == 1 || ox0 + p < a.cols) st4(op + ((long)oy * a.cols + p) * a.ch, acc);
         }
 #pragma unroll
         for (int j = 0; j < NC; j++) {
@@ -118,7 +130,8 @@ __global__ __launch_bounds__(256) void dw3x3_f32_nhwc(DwArgs a)
 }
 
 // Generic fallback (any stride / filtersize / channel count): one lane per output element.
-__global__ __launch_bounds__(256) void dw_generic_f32_nhwc(DwArgs a, int fs, int stride)
+template <typename T>
+__global__ __launch_bounds__(256) void dw_generic_nhwc(DwArgs a, int fs, int stride)
 {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long total = (long)a.batch * a.rows * a.cols * a.ch;
@@ -129,7 +142,7 @@ __global__ __launch_bounds__(256) void dw_generic_f32_nhwc(DwArgs a, int fs, int
     q /= a.cols;
     const int oy = (int)(q % a.rows);
     const int n = (int)(q / a.rows);
-    const float *img = a.in + (long)n * a.in_rows * a.in_cols * a.ch;
+    const T *img = reinterpret_cast<const T *>(a.in) + (long)n * a.in_rows * a.in_cols * a.ch;
     float acc = 0.f;
     for (int ky = 0; ky < fs; ky++) {
         int iy = oy * stride + ky - a.pad_top;
@@ -137,39 +150,32 @@ __global__ __launch_bounds__(256) void dw_generic_f32_nhwc(DwArgs a, int fs, int
         for (int kx = 0; kx < fs; kx++) {
             int ix = ox * stride + kx - a.pad_left;
             if (ix < 0 || ix >= a.in_cols) continue;
-            acc = fmaf(img[((long)iy * a.in_cols + ix) * a.ch + c], a.filt[(long)(ky * fs + kx) * a.ch + c], acc);
+            acc = fmaf((float)img[((long)iy * a.in_cols + ix) * a.ch + c], a.filt[(long)(ky * fs + kx) * a.ch + c], acc);
         }
     }
     float v = fmaf(acc, a.scale ? a.scale[c] : 1.f, a.shift ? a.shift[c] : 0.f);
     if (a.act == MBN_ACT_RELU6) v = fminf(fmaxf(v, 0.f), 6.f);
     else if (a.act == MBN_ACT_RELU) v = fmaxf(v, 0.f);
-    a.out[t] = v;
+    reinterpret_cast<T *>(a.out)[t] = (T)v;
 }
 
-}   // namespace
-
-int mbn_launch_f32_depthwise(const mbn_call &c, float *out, const float *in, const float *filt, int rows, int cols,
-                             int fs, int stride, int channels)
+template <typename T>
+int launch_dw(const mbn_call &c, DwArgs &a, int rows, int cols, int fs, int stride, int channels)
 {
-    DwArgs a;
-    a.out = out; a.in = in; a.filt = filt; a.scale = c.scale; a.shift = c.shift;
-    a.batch = c.batch; a.in_rows = c.in_rows; a.in_cols = c.in_cols; a.rows = rows; a.cols = cols; a.ch = channels;
-    a.pad_top = c.pad_top >= 0 ? c.pad_top : mbn_same_pad(c.in_rows, rows, fs, stride);
-    a.pad_left = c.pad_left >= 0 ? c.pad_left : mbn_same_pad(c.in_cols, cols, fs, stride);
-    a.act = c.act;
+    const size_t io_align = sizeof(T) * 4;             // one channel-quad
     const bool fast = fs == 3 && (stride == 1 || stride == 2) && (channels % 4) == 0 &&
-                      ((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)filt % 16) == 0 &&
-                      (!c.scale || ((uintptr_t)c.scale % 16) == 0) && (!c.shift || ((uintptr_t)c.shift % 16) == 0);
+                      ((uintptr_t)a.in % io_align) == 0 && ((uintptr_t)a.out % io_align) == 0 &&
+                      ((uintptr_t)a.filt % 16) == 0 && (!c.scale || ((uintptr_t)c.scale % 16) == 0) &&
+                      (!c.shift || ((uintptr_t)c.shift % 16) == 0);
     if (!fast) {
         a.seg_rows = rows; a.nseg = 1; a.total = 0; a.cw = a.nslab = a.lcols = 1;
         long total = (long)c.batch * rows * cols * channels;
-        hipLaunchKernelGGL(dw_generic_f32_nhwc, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c.stream, a, fs,
-                           stride);
+        hipLaunchKernelGGL(dw_generic_nhwc<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c.stream, a, fs, stride);
         return MBN_OK;
     }
-    // variant: bit0..1 = TW-1 choice (0 default), bit 4 = legacy lane layout (cw = C/4)
+    // variant: bits 0..1 = TW (0 = default 2), bit 4 = lanes across the full C instead of 64-channel slabs
     const int var = g_mbn_tune.dw_variant;
-    int tw = (var & 3) ? (var & 3) : 2;              // default: 2 output columns per lane
+    int tw = (var & 3) ? (var & 3) : 2;
     if (tw > 2) tw = 2;
     const int c4 = channels / 4;
     int cw = c4;
@@ -199,11 +205,27 @@ int mbn_launch_f32_depthwise(const mbn_call &c, float *out, const float *in, con
     a.total = row_lanes * a.nseg;
     dim3 grid((unsigned)((a.total + 255) / 256));
     if (stride == 1) {
-        if (tw == 1) hipLaunchKernelGGL((dw3x3_f32_nhwc<1, 1>), grid, dim3(256), 0, c.stream, a);
-        else hipLaunchKernelGGL((dw3x3_f32_nhwc<1, 2>), grid, dim3(256), 0, c.stream, a);
+        if (tw == 1) hipLaunchKernelGGL((dw3x3_nhwc<1, 1, T>), grid, dim3(256), 0, c.stream, a);
+        else hipLaunchKernelGGL((dw3x3_nhwc<1, 2, T>), grid, dim3(256), 0, c.stream, a);
     } else {
-        if (tw == 1) hipLaunchKernelGGL((dw3x3_f32_nhwc<2, 1>), grid, dim3(256), 0, c.stream, a);
-        else hipLaunchKernelGGL((dw3x3_f32_nhwc<2, 2>), grid, dim3(256), 0, c.stream, a);
+        if (tw == 1) hipLaunchKernelGGL((dw3x3_nhwc<2, 1, T>), grid, dim3(256), 0, c.stream, a);
+        else hipLaunchKernelGGL((dw3x3_nhwc<2, 2, T>), grid, dim3(256), 0, c.stream, a);
     }
     return MBN_OK;
+}
+
+}   // namespace
+
+// `out`/`in` are fp32 or bf16 NHWC according to c.dtype; the filter and scale/shift are always fp32.
+int mbn_launch_f32_depthwise(const mbn_call &c, void *out, const void *in, const float *filt, int rows, int cols,
+                             int fs, int stride, int channels)
+{
+    DwArgs a;
+    a.out = out; a.in = in; a.filt = filt; a.scale = c.scale; a.shift = c.shift;
+    a.batch = c.batch; a.in_rows = c.in_rows; a.in_cols = c.in_cols; a.rows = rows; a.cols = cols; a.ch = channels;
+    a.pad_top = c.pad_top >= 0 ? c.pad_top : mbn_same_pad(c.in_rows, rows, fs, stride);
+    a.pad_left = c.pad_left >= 0 ? c.pad_left : mbn_same_pad(c.in_cols, cols, fs, stride);
+    a.act = c.act;
+    if (c.dtype == MBN_DT_BF16) return launch_dw<__bf16>(c, a, rows, cols, fs, stride, channels);
+    return launch_dw<float>(c, a, rows, cols, fs, stride, channels);
 }

@@ -9,8 +9,15 @@ namespace {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
+typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st4(float *p, f4 v) { *reinterpret_cast<f4 *>(p) = v; }
+__device__ __forceinline__ void st4(__bf16 *p, f4 v)
+{
+    *reinterpret_cast<bf4 *>(p) = bf4{ (__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w };   // RNE
+}
+
 struct ConvArgs {
-    float *out;
+    void *out;
     const float *in, *filt, *scale, *shift;
     int batch, rows, cols, cin, fs, stride, orow, ocol, cout, pad_top, pad_left, act;
     long total;   // batch*orow*ocol*(cout/4)
@@ -20,6 +27,7 @@ struct ConvArgs {
 // wave's store is one contiguous span of the NHWC output (the 73 % of this stage's traffic). Input taps of a pixel
 // are shared by those lanes (same-address loads, one request); the whole filter (fs*fs*cin*cout floats) sits in LDS
 // and is read as wave-broadcast float4s.
+template <typename TO>
 __global__ __launch_bounds__(256) void conv_f32_nhwc(ConvArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float wlds[];
@@ -63,7 +71,7 @@ __global__ __launch_bounds__(256) void conv_f32_nhwc(ConvArgs a)
     } else if (a.act == MBN_ACT_RELU) {
         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
     }
-    *reinterpret_cast<f4 *>(a.out + t * 4) = v;
+    st4(reinterpret_cast<TO *>(a.out) + t * 4, v);
 }
 
 // Specialisation for the network's first layer (3x3, Cin = 3, stride 2): one lane = 4 consecutive output channels of
@@ -71,6 +79,7 @@ __global__ __launch_bounds__(256) void conv_f32_nhwc(ConvArgs a)
 // as 6 aligned float4 + 3 floats (27 contiguous floats of the NHWC row; the cout/4 lanes of a pixel group read the same
 // addresses, one request), and each LDS weight float4 is reused for the 4 pixels: 432 FMAs per 21 global + 27 LDS
 // loads instead of 108 per 27 + 27. Stores stay whole 128-B lines per pixel.
+template <typename TO>
 __global__ __launch_bounds__(256) void conv3x3s2c3_f32_nhwc(ConvArgs a)
 {
     constexpr int PX = 4;
@@ -124,7 +133,7 @@ __global__ __launch_bounds__(256) void conv3x3s2c3_f32_nhwc(ConvArgs a)
     }
     const f4 sc = a.scale ? *reinterpret_cast<const f4 *>(a.scale + oc) : f4{ 1.f, 1.f, 1.f, 1.f };
     const f4 sh = a.shift ? *reinterpret_cast<const f4 *>(a.shift + oc) : f4{ 0.f, 0.f, 0.f, 0.f };
-    float *op = a.out + ((((long)n * a.orow + oy) * a.ocol + ox0) * a.cout) + oc;
+    TO *op = reinterpret_cast<TO *>(a.out) + ((((long)n * a.orow + oy) * a.ocol + ox0) * a.cout) + oc;
 #pragma unroll
     for (int p = 0; p < PX; p++) {
         f4 r = f4{ fmaf(acc[p].x, sc.x, sh.x), fmaf(acc[p].y, sc.y, sh.y), fmaf(acc[p].z, sc.z, sh.z),
@@ -135,11 +144,12 @@ __global__ __launch_bounds__(256) void conv3x3s2c3_f32_nhwc(ConvArgs a)
         } else if (a.act == MBN_ACT_RELU) {
             r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f);
         }
-        *reinterpret_cast<f4 *>(op + (long)p * a.cout) = r;
+        st4(op + (long)p * a.cout, r);
     }
 }
 
 // any cout / unaligned: one lane per output element, filter from global memory
+template <typename TO>
 __global__ __launch_bounds__(256) void conv_generic_f32_nhwc(ConvArgs a)
 {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -167,22 +177,23 @@ __global__ __launch_bounds__(256) void conv_generic_f32_nhwc(ConvArgs a)
     float v = fmaf(acc, a.scale ? a.scale[oc] : 1.f, a.shift ? a.shift[oc] : 0.f);
     if (a.act == MBN_ACT_RELU6) v = fminf(fmaxf(v, 0.f), 6.f);
     else if (a.act == MBN_ACT_RELU) v = fmaxf(v, 0.f);
-    a.out[t] = v;
+    reinterpret_cast<TO *>(a.out)[t] = (TO)v;
 }
 
 // global average pool: one lane per (image, channel); lanes run along channels (coalesced NHWC reads).
-__global__ __launch_bounds__(256) void pool_f32_nhwc(float *__restrict__ out, const float *__restrict__ in, int batch,
+template <typename T>
+__global__ __launch_bounds__(256) void pool_f32_nhwc(T *__restrict__ out, const T *__restrict__ in, int batch,
                                                      int rows, int cols, int fr, int fc, int ch)
 {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long)batch * ch) return;
     const int c = (int)(t % ch);
     const int n = (int)(t / ch);
-    const float *ip = in + (long)n * rows * cols * ch + c;
+    const T *ip = in + (long)n * rows * cols * ch + c;
     float acc = 0.f;
     for (int y = 0; y < fr; y++)
-        for (int x = 0; x < fc; x++) acc += ip[((long)y * cols + x) * ch];
-    out[t] = acc / (float)(fr * fc);
+        for (int x = 0; x < fc; x++) acc += (float)ip[((long)y * cols + x) * ch];
+    out[t] = (T)(acc / (float)(fr * fc));
 }
 
 // softmax + argmax: one 256-lane workgroup per image; wave shuffles then a 4-entry LDS combine.
@@ -235,11 +246,40 @@ __global__ __launch_bounds__(256) void normalize_u8_f32(float *__restrict__ out,
     }
 }
 
+// fp32 <-> bf16 (round to nearest even), 4 elements per lane
+__global__ __launch_bounds__(256) void convert_f32_bf16(__bf16 *__restrict__ dst, const float *__restrict__ src, size_t count)
+{
+    const size_t t = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (t + 3 < count) st4(dst + t, *reinterpret_cast<const f4 *>(src + t));
+    else for (size_t i = t; i < count; i++) dst[i] = (__bf16)src[i];
+}
+__global__ __launch_bounds__(256) void convert_bf16_f32(float *__restrict__ dst, const __bf16 *__restrict__ src, size_t count)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < count) dst[t] = (float)src[t];
+}
+
 }   // namespace
 
-int mbn_launch_f32_conv(const mbn_call &c, float *out, const float *in, const float *filt, int rows, int cols, int fs,
+int mbn_launch_convert(mbn_context *, hipStream_t s, void *dst, const void *src, size_t count, int to_bf16)
+{
+    if (to_bf16) {
+        if (((uintptr_t)dst % 8) || ((uintptr_t)src % 16)) return MBN_EINVAL;
+        hipLaunchKernelGGL(convert_f32_bf16, dim3((unsigned)(((count + 3) / 4 + 255) / 256)), dim3(256), 0, s, (__bf16 *)dst,
+                           (const float *)src, count);
+    } else {
+        hipLaunchKernelGGL(convert_bf16_f32, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, (float *)dst,
+                           (const __bf16 *)src, count);
+    }
+    return MBN_OK;
+}
+
+int mbn_launch_f32_conv(const mbn_call &c, void *out, const void *in_v, const float *filt, int rows, int cols, int fs,
                         int stride, int op_size)
 {
+    const bool bf = c.dtype == MBN_DT_BF16;
+    if (bf && !(c.io_flags & MBN_IO_IN_F32)) return MBN_EUNSUPPORTED;   // the first layer reads the fp32 image
+    const float *in = (const float *)in_v;
     ConvArgs a;
     a.out = out; a.in = in; a.filt = filt; a.scale = c.scale; a.shift = c.shift;
     a.batch = c.batch; a.rows = rows; a.cols = cols; a.cin = c.cin; a.fs = fs; a.stride = stride;
@@ -248,7 +288,7 @@ int mbn_launch_f32_conv(const mbn_call &c, float *out, const float *in, const fl
     a.pad_left = c.pad_left >= 0 ? c.pad_left : mbn_same_pad(cols, a.ocol, fs, stride);
     a.act = c.act;
     const size_t wbytes = (size_t)fs * fs * c.cin * op_size * sizeof(float);
-    const bool fast = (op_size % 4) == 0 && wbytes <= 64 * 1024 && ((uintptr_t)out % 16) == 0 &&
+    const bool fast = (op_size % 4) == 0 && wbytes <= 64 * 1024 && ((uintptr_t)out % (bf ? 8 : 16)) == 0 &&
                       ((uintptr_t)filt % 16) == 0 && (!c.scale || ((uintptr_t)c.scale % 16) == 0) &&
                       (!c.shift || ((uintptr_t)c.shift % 16) == 0);
     const bool first_layer = fast && fs == 3 && c.cin == 3 && stride == 2 && a.pad_left == 0 && (cols % 4) == 0 &&
@@ -256,24 +296,35 @@ int mbn_launch_f32_conv(const mbn_call &c, float *out, const float *in, const fl
                              g_mbn_tune.conv_variant != 1;
     if (first_layer) {
         a.total = (long)c.batch * a.orow * (a.ocol / 4) * (op_size / 4);
-        hipLaunchKernelGGL(conv3x3s2c3_f32_nhwc, dim3((unsigned)((a.total + 255) / 256)), dim3(256), wbytes, c.stream, a);
+        const dim3 grid((unsigned)((a.total + 255) / 256));
+        if (bf) hipLaunchKernelGGL(conv3x3s2c3_f32_nhwc<__bf16>, grid, dim3(256), wbytes, c.stream, a);
+        else hipLaunchKernelGGL(conv3x3s2c3_f32_nhwc<float>, grid, dim3(256), wbytes, c.stream, a);
     } else if (fast) {
         a.total = (long)c.batch * a.orow * a.ocol * (op_size / 4);
-        hipLaunchKernelGGL(conv_f32_nhwc, dim3((unsigned)((a.total + 255) / 256)), dim3(256), wbytes, c.stream, a);
+        const dim3 grid((unsigned)((a.total + 255) / 256));
+        if (bf) hipLaunchKernelGGL(conv_f32_nhwc<__bf16>, grid, dim3(256), wbytes, c.stream, a);
+        else hipLaunchKernelGGL(conv_f32_nhwc<float>, grid, dim3(256), wbytes, c.stream, a);
     } else {
         a.total = 0;
         long total = (long)c.batch * a.orow * a.ocol * op_size;
-        hipLaunchKernelGGL(conv_generic_f32_nhwc, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c.stream, a);
+        const dim3 grid((unsigned)((total + 255) / 256));
+        if (bf) hipLaunchKernelGGL(conv_generic_f32_nhwc<__bf16>, grid, dim3(256), 0, c.stream, a);
+        else hipLaunchKernelGGL(conv_generic_f32_nhwc<float>, grid, dim3(256), 0, c.stream, a);
     }
     return MBN_OK;
 }
 
-int mbn_launch_f32_pool(const mbn_call &c, float *out, const float *in, int rows, int cols, int fs, int channels)
+int mbn_launch_f32_pool(const mbn_call &c, void *out, const void *in, int rows, int cols, int fs, int channels)
 {
     const int fr = fs < rows ? fs : rows, fc = fs < cols ? fs : cols;
     const long total = (long)c.batch * channels;
-    hipLaunchKernelGGL(pool_f32_nhwc, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c.stream, out, in, c.batch,
-                       rows, cols, fr, fc, channels);
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (c.dtype == MBN_DT_BF16)
+        hipLaunchKernelGGL(pool_f32_nhwc<__bf16>, grid, dim3(256), 0, c.stream, (__bf16 *)out, (const __bf16 *)in, c.batch,
+                           rows, cols, fr, fc, channels);
+    else
+        hipLaunchKernelGGL(pool_f32_nhwc<float>, grid, dim3(256), 0, c.stream, (float *)out, (const float *)in, c.batch,
+                           rows, cols, fr, fc, channels);
     return MBN_OK;
 }
 

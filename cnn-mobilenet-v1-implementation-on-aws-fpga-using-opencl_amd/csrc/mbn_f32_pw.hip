@@ -1,23 +1,23 @@
-// mbn_f32_pw.hip — fp32 1x1 pointwise conv (and the FC layer) as an MFMA GEMM for gfx950, with the folded-BN
-// scale/shift + ReLU/ReLU6 epilogue fused. Replaces the arithmetic of the reference's `pointwise` kernel
-// (kernel.cl:94-114; reused as FC at MobileNet.c:2681-2763) in the fp32 mode the metric measures.
+// mbn_f32_pw.hip — 1x1 pointwise conv (and the FC layer) as an MFMA GEMM for gfx950, with the folded-BN scale/shift +
+// ReLU/ReLU6 epilogue fused; fp32 (the metric's mode) or bf16 storage, fp32 accumulate. Replaces the arithmetic of the
+// reference's `pointwise` kernel (kernel.cl:94-114; reused as FC at MobileNet.c:2681-2763).
 //
 //   out[m][n] = act( scale[n] * sum_k in[m][k] * filt[n][k] + shift[n] ),   m = pixel (N*H*W), n = out channel
 //
 // NHWC makes `in` a row-major [M][K] matrix and `out` a row-major [M][Cout] matrix with no data movement;
 // `filt` keeps kernel.cl's own order [oc][ic] = [Cout][K]. Both operands are therefore K-contiguous ("NT" GEMM).
 //
-// MFMA: v_mfma_f32_32x32x2_f32 — exact fp32 (bit-identical to an fmaf chain over k), 64 FLOP/clk/SIMD, the fp32
-// matrix peak of 157.3 TFLOP/s. Lane l feeds A[i=l&31][k=l>>5] and B[k=l>>5][j=l&31], one float each.
-// K order inside an 8-wide k-group is permuted so that ONE ds_read_b128 per lane feeds four MFMAs: lane half
-// h=l>>5 owns k = 8g+4h .. 8g+4h+3 and MFMA step s consumes element s of both operands' float4 (the same k on
-// both sides, so the sum over k is unchanged up to fp32 summation order).
+// MFMA, fp32: v_mfma_f32_32x32x2_f32 — exact fp32 (bit-identical to an fmaf chain over k), 64 FLOP/clk/SIMD, the fp32
+// matrix peak of 157.3 TFLOP/s. Lane l feeds A[i=l&31][k=l>>5] and B[k=l>>5][j=l&31], one float each. K order inside
+// an 8-wide k-group is permuted so that ONE ds_read_b128 per lane feeds four MFMAs: lane half h=l>>5 owns
+// k = 8g+4h .. 8g+4h+3 and MFMA step s consumes element s of both operands' float4 (the same k on both sides).
+// MFMA, bf16: v_mfma_f32_32x32x16_bf16 — lane (r=l&31, h=l>>5) holds A[r][k=8h+j], j=0..7 = the same 16-byte chunk
+// of the K-contiguous row, so the SAME LDS image (128-byte rows = 64 bf16) and the same ds_read_b128 feed one MFMA.
 //
-// LDS: tiles [rows][32 floats] (128-B rows) staged through registers with 16-B global loads; the 16-B chunk index
-// is XOR-swizzled with (row>>1)&7, which makes the ds_read_b128 of 16 consecutive rows hit 16 distinct 16-B
-// slots of the 256-B bank row (SQ_LDS_BANK_CONFLICT = 0 measured) and keeps ds_write_b128 conflict-free.
-// Double-buffered over K with one barrier per 32-deep k-tile; next tile's global loads are issued before the
-// MFMAs of the current one and written to LDS after them.
+// LDS: tiles [rows][128 bytes] staged with 16-B accesses; the 16-B chunk index is XOR-swizzled with (row>>1)&7, which
+// makes the ds_read_b128 of 16 consecutive rows hit 16 distinct 16-B slots of the 256-B bank row
+// (SQ_LDS_BANK_CONFLICT = 0 measured). Staging is direct-to-LDS (global_load_lds_dwordx4) when K is a multiple of the
+// k-tile, through registers otherwise; double-buffered over K with one barrier per k-tile.
 //
 // Scheduling: PERSISTENT workgroups. The grid is (workgroups that fit per CU) x (CUs); each workgroup walks the
 // tile list with stride gridDim, and issues the first global loads of its NEXT tile before the epilogue stores of
@@ -26,25 +26,29 @@
 // share an XCD), and same-XCD ids are mapped to consecutive tiles with the n-tile index fastest, so the workgroups
 // that share an A row-panel run on ONE XCD at the same time: the panel is fetched once and re-read from that L2.
 //
-// Measured on MI355X (profiles/r01): the bare ds_read+MFMA loop of this kernel runs at 81 % of the fp32 matrix peak
-// (89 % at the 2.18 GHz the chip holds under this load); barriers cost nothing; register staging (global load +
-// ds_write_b128) costs 11 %, epilogue stores 7 %.
+// Measured on MI355X, fp32 (profiles/r01/gemm_ablation.txt): the bare ds_read+MFMA loop runs at 81 % of the fp32
+// matrix peak (89 % at the 2.18 GHz the chip holds under this load); barriers cost nothing; register staging cost
+// 11 % (-> direct-to-LDS), epilogue stores 7 %.
 #include "mbn_internal.h"
 
 namespace {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f16v __attribute__((ext_vector_type(16)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 
 struct PwArgs {
-    float *out;
-    const float *in, *filt, *scale, *shift;
+    void *out;
+    const void *in, *filt;
+    const float *scale, *shift;
     long m;
     int k, n, act;
-    int mt, nt;   // tile counts
+    int mt, nt;     // tile counts
+    int out_f32;    // bf16 mode: write fp32 (FC logits)
 };
 
-constexpr int BK = 32;
+constexpr int BKB = 128;            // k-tile in BYTES per row (32 fp32 / 64 bf16)
+constexpr int BKF = BKB / 4;        // ... in 4-byte LDS words
 
 __device__ __forceinline__ int swz(int row, int chunk) { return (row << 5) + (((chunk ^ (row >> 1)) & 7) << 2); }
 
@@ -56,22 +60,27 @@ __device__ __forceinline__ int xcd_remap(int vb, int nwg)
     return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (vb >> 3);
 }
 
-template <int BM, int BN, int WM, int WN, int NBUF, bool KFULL, bool GLDS>
-__global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void pw_gemm_f32(PwArgs a)
+template <typename T, int BM, int BN, int WM, int WN, int NBUF, bool KFULL, bool GLDS>
+__global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void pw_gemm(PwArgs a)
 {
+    constexpr bool BF = sizeof(T) == 2;
+    constexpr int EPC = 16 / sizeof(T);                       // elements per 16-byte chunk
+    constexpr int BKE = 8 * EPC;                              // k-tile in elements (32 / 64)
     constexpr int WAVES_N = BN / WN;
     constexpr int NT = 64 * (BM / WM) * WAVES_N;              // threads per workgroup
     constexpr int MI = WM / 32, NI = WN / 32;
-    constexpr int A_LD = BM * 8 / NT, B_LD = BN * 8 / NT;     // float4 loads per thread per k-tile
+    constexpr int A_LD = BM * 8 / NT, B_LD = BN * 8 / NT;     // 16-B loads per thread per k-tile
     constexpr int ST = A_LD > B_LD ? A_LD : B_LD;
     static_assert(A_LD >= 1 && B_LD >= 1 && A_LD * NT == BM * 8 && B_LD * NT == BN * 8, "tile/threads mismatch");
-    __shared__ __attribute__((aligned(16))) float lds[NBUF * (BM + BN) * BK];
+    __shared__ __attribute__((aligned(16))) float lds[NBUF * (BM + BN) * BKF];
 
+    const T *gin = reinterpret_cast<const T *>(a.in);
+    const T *gfilt = reinterpret_cast<const T *>(a.filt);
     const int nwg = a.mt * a.nt;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave / WAVES_N) * WM, wn = (wave % WAVES_N) * WN;
     const int li = lane & 31, lh = lane >> 5;
-    const int nk = (a.k + BK - 1) / BK;
+    const int nk = (a.k + BKE - 1) / BKE;
 
     // per-thread staging coordinates inside a tile (row, 16-B chunk): fixed for the whole kernel
     const int st_ch = tid & 7;
@@ -79,8 +88,8 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void pw_gemm_f32(PwArgs
 #pragma unroll
     for (int p = 0; p < ST; p++) st_row[p] = (p * NT + tid) >> 3;
 
-    const float *a_src[A_LD];
-    const float *b_src[B_LD];
+    const T *a_src[A_LD];
+    const T *b_src[B_LD];
     f4 a_reg[A_LD], b_reg[B_LD];
     const f4 zero4 = f4{ 0.f, 0.f, 0.f, 0.f };
 
@@ -92,28 +101,28 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void pw_gemm_f32(PwArgs
         for (int p = 0; p < A_LD; p++) {
             long gm = m0 + st_row[p];
             if (gm >= a.m) gm = a.m - 1;             // clamp: rows past M are computed but never stored
-            a_src[p] = a.in + gm * a.k + (GLDS ? ((st_ch ^ (st_row[p] >> 1)) & 7) : st_ch) * 4;
+            a_src[p] = gin + gm * a.k + (GLDS ? ((st_ch ^ (st_row[p] >> 1)) & 7) : st_ch) * EPC;
         }
 #pragma unroll
         for (int p = 0; p < B_LD; p++) {
             int gn = n0 + st_row[p];
             if (gn >= a.n) gn = a.n - 1;
-            b_src[p] = a.filt + (long)gn * a.k + (GLDS ? ((st_ch ^ (st_row[p] >> 1)) & 7) : st_ch) * 4;
+            b_src[p] = gfilt + (long)gn * a.k + (GLDS ? ((st_ch ^ (st_row[p] >> 1)) & 7) : st_ch) * EPC;
         }
     };
     auto stage_load = [&](int k0) {
-        const bool ok = KFULL || (k0 + st_ch * 4 < a.k);
+        const bool ok = KFULL || (k0 + st_ch * EPC < a.k);
 #pragma unroll
         for (int p = 0; p < A_LD; p++) a_reg[p] = ok ? *reinterpret_cast<const f4 *>(a_src[p] + k0) : zero4;
 #pragma unroll
         for (int p = 0; p < B_LD; p++) b_reg[p] = ok ? *reinterpret_cast<const f4 *>(b_src[p] + k0) : zero4;
     };
     auto stage_store = [&](int buf) {
-        float *base = lds + buf * (BM + BN) * BK;
+        float *base = lds + buf * (BM + BN) * BKF;
 #pragma unroll
         for (int p = 0; p < A_LD; p++) *reinterpret_cast<f4 *>(base + swz(st_row[p], st_ch)) = a_reg[p];
 #pragma unroll
-        for (int p = 0; p < B_LD; p++) *reinterpret_cast<f4 *>(base + BM * BK + swz(st_row[p], st_ch)) = b_reg[p];
+        for (int p = 0; p < B_LD; p++) *reinterpret_cast<f4 *>(base + BM * BKF + swz(st_row[p], st_ch)) = b_reg[p];
     };
 
     // Direct-to-LDS staging (global_load_lds_dwordx4): one wave-instruction writes 1 KiB = 8 rows x 128 B linearly
@@ -121,16 +130,16 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void pw_gemm_f32(PwArgs
     // per-lane SOURCE chunk instead (set_tile). No staging VGPRs, no ds_write pass.
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     auto stage_glds = [&](int k0, int buf) {
-        float *base = lds + buf * (BM + BN) * BK;
+        float *base = lds + buf * (BM + BN) * BKF;
 #pragma unroll
         for (int p = 0; p < A_LD; p++)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a_src[p] + k0),
-                                             (__attribute__((address_space(3))) void *)(base + (p * (NT / 8) + wave_u * 8) * BK),
+                                             (__attribute__((address_space(3))) void *)(base + (p * (NT / 8) + wave_u * 8) * BKF),
                                              16, 0, 0);
 #pragma unroll
         for (int p = 0; p < B_LD; p++)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(b_src[p] + k0),
-                                             (__attribute__((address_space(3))) void *)(base + BM * BK + (p * (NT / 8) + wave_u * 8) * BK),
+                                             (__attribute__((address_space(3))) void *)(base + BM * BKF + (p * (NT / 8) + wave_u * 8) * BKF),
                                              16, 0, 0);
     };
 
@@ -152,8 +161,8 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void pw_gemm_f32(PwArgs
                 for (int r = 0; r < 16; r++) acc[mi][ni][r] = 0.f;
 
         auto compute = [&](int buf) {
-            const float *As = lds + buf * (BM + BN) * BK;
-            const float *Bs = As + BM * BK;
+            const float *As = lds + buf * (BM + BN) * BKF;
+            const float *Bs = As + BM * BKF;
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 const int chunk = 2 * g + lh;
@@ -162,13 +171,22 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void pw_gemm_f32(PwArgs
                 for (int mi = 0; mi < MI; mi++) av[mi] = *reinterpret_cast<const f4 *>(As + swz(wm + mi * 32 + li, chunk));
 #pragma unroll
                 for (int ni = 0; ni < NI; ni++) bv[ni] = *reinterpret_cast<const f4 *>(Bs + swz(wn + ni * 32 + li, chunk));
-#pragma unroll
-                for (int s = 0; s < 4; s++)
+                if constexpr (BF) {
 #pragma unroll
                     for (int mi = 0; mi < MI; mi++)
 #pragma unroll
                         for (int ni = 0; ni < NI; ni++)
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][s], bv[ni][s], acc[mi][ni], 0, 0, 0);
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                __builtin_bit_cast(bf8, av[mi]), __builtin_bit_cast(bf8, bv[ni]), acc[mi][ni], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 4; s++)
+#pragma unroll
+                        for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+                            for (int ni = 0; ni < NI; ni++)
+                                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][s], bv[ni][s], acc[mi][ni], 0, 0, 0);
+                }
             }
         };
 
@@ -178,13 +196,13 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void pw_gemm_f32(PwArgs
         if (GLDS) {
             for (int kt = 0; kt < nk; kt++) {
                 const int cur = kt & 1;
-                if (kt + 1 < nk) stage_glds((kt + 1) * BK, cur ^ 1);
+                if (kt + 1 < nk) stage_glds((kt + 1) * BKE, cur ^ 1);
                 compute(cur);
                 __syncthreads();
             }
         } else if (NBUF == 1) {
             for (int kt = 0; kt < nk; kt++) {
-                if (kt + 1 < nk) stage_load((kt + 1) * BK);
+                if (kt + 1 < nk) stage_load((kt + 1) * BKE);
                 compute(0);
                 if (kt + 1 < nk) {
                     __syncthreads();
@@ -196,7 +214,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void pw_gemm_f32(PwArgs
         } else {
             for (int kt = 0; kt < nk; kt++) {
                 const int cur = kt & 1;
-                if (kt + 1 < nk) stage_load((kt + 1) * BK);
+                if (kt + 1 < nk) stage_load((kt + 1) * BKE);
                 compute(cur);
                 if (kt + 1 < nk) stage_store(cur ^ 1);
                 __syncthreads();
@@ -215,7 +233,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void pw_gemm_f32(PwArgs
         }
 
         // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-        // One store instruction writes two 128-B row segments (full cache lines).
+        // One fp32 store instruction writes two 128-B row segments (full cache lines).
 #pragma unroll
         for (int ni = 0; ni < NI; ni++) {
             const int col = cn0 + wn + ni * 32 + li;
@@ -231,7 +249,10 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void pw_gemm_f32(PwArgs
                     float v = fmaf(acc[mi][ni][r], sc, sh);
                     if (a.act == MBN_ACT_RELU6) v = fminf(fmaxf(v, 0.f), 6.f);
                     else if (a.act == MBN_ACT_RELU) v = fmaxf(v, 0.f);
-                    if (cok && row < a.m) a.out[row * a.n + col] = v;
+                    if (cok && row < a.m) {
+                        if (!BF || a.out_f32) reinterpret_cast<float *>(a.out)[row * a.n + col] = v;
+                        else reinterpret_cast<__bf16 *>(a.out)[row * a.n + col] = (__bf16)v;
+                    }
                 }
             }
         }
@@ -240,31 +261,34 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void pw_gemm_f32(PwArgs
     }
 }
 
-// Fallback for K not a multiple of 4 or unaligned pointers: one lane per output element.
-__global__ __launch_bounds__(256) void pw_generic_f32(PwArgs a)
+// Fallback for K not a multiple of the 16-byte chunk or unaligned pointers: one lane per output element.
+template <typename T>
+__global__ __launch_bounds__(256) void pw_generic(PwArgs a)
 {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= a.m * a.n) return;
     const long row = t / a.n;
     const int col = (int)(t % a.n);
-    const float *ip = a.in + row * a.k, *fp = a.filt + (long)col * a.k;
+    const T *ip = reinterpret_cast<const T *>(a.in) + row * a.k, *fp = reinterpret_cast<const T *>(a.filt) + (long)col * a.k;
     float acc = 0.f;
-    for (int i = 0; i < a.k; i++) acc = fmaf(ip[i], fp[i], acc);
+    for (int i = 0; i < a.k; i++) acc = fmaf((float)ip[i], (float)fp[i], acc);
     float v = fmaf(acc, a.scale ? a.scale[col] : 1.f, a.shift ? a.shift[col] : 0.f);
     if (a.act == MBN_ACT_RELU6) v = fminf(fmaxf(v, 0.f), 6.f);
     else if (a.act == MBN_ACT_RELU) v = fmaxf(v, 0.f);
-    a.out[t] = v;
+    if (sizeof(T) == 4 || a.out_f32) reinterpret_cast<float *>(a.out)[t] = v;
+    else reinterpret_cast<__bf16 *>(a.out)[t] = (__bf16)v;
 }
 
-template <int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN>
 void launch_cfg(PwArgs &a, hipStream_t s, int num_cus)
 {
     constexpr int NT = 64 * (BM / WM) * (BN / WN);
+    constexpr int BKE = 8 * (16 / (int)sizeof(T));
     a.mt = (int)((a.m + BM - 1) / BM);
     a.nt = (a.n + BN - 1) / BN;
-    const int nbuf = a.k <= BK ? 1 : 2;
-    const int lds_bytes = nbuf * (BM + BN) * BK * 4;
-    // persistent grid: as many workgroups as are resident at once (LDS- and wave-limited), a multiple of 8 (XCDs)
+    const int nbuf = a.k <= BKE ? 1 : 2;
+    const int lds_bytes = nbuf * (BM + BN) * BKB;
+    // persistent grid: as many workgroups as are resident at once (LDS- and wave-limited)
     int per_cu = 160 * 1024 / lds_bytes;
     const int wave_cap = 32 / (NT / 64);                 // 32 waves per CU
     if (per_cu > wave_cap) per_cu = wave_cap;
@@ -272,37 +296,43 @@ void launch_cfg(PwArgs &a, hipStream_t s, int num_cus)
     if (g_mbn_tune.misc > 0) per_cu = g_mbn_tune.misc;   // A/B hook: workgroups per CU (1000 = one tile per workgroup)
     const long nwg = (long)a.mt * a.nt;
     long grid_l = (long)num_cus * per_cu;
-    // a single-k-tile problem (K <= 32: layer 3) is a pure streaming kernel: one tile per workgroup measured faster
+    // a single-k-tile problem (layer 3 in fp32) is a pure streaming kernel: one tile per workgroup measured faster
     if (grid_l > nwg || g_mbn_tune.misc >= 1000 || nbuf == 1) grid_l = nwg;
     const dim3 grid((unsigned)grid_l), block(NT);
-    const bool kfull = (a.k % BK) == 0;
+    const bool kfull = (a.k % BKE) == 0;
     const bool glds = kfull && nbuf == 2 && g_mbn_tune.pw_stage != 1;   // pw_stage=1: register staging (A/B hook)
     if (nbuf == 1) {
-        if (kfull) hipLaunchKernelGGL((pw_gemm_f32<BM, BN, WM, WN, 1, true, false>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((pw_gemm_f32<BM, BN, WM, WN, 1, false, false>), grid, block, 0, s, a);
+        if (kfull) hipLaunchKernelGGL((pw_gemm<T, BM, BN, WM, WN, 1, true, false>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((pw_gemm<T, BM, BN, WM, WN, 1, false, false>), grid, block, 0, s, a);
     } else {
-        if (glds) hipLaunchKernelGGL((pw_gemm_f32<BM, BN, WM, WN, 2, true, true>), grid, block, 0, s, a);
-        else if (kfull) hipLaunchKernelGGL((pw_gemm_f32<BM, BN, WM, WN, 2, true, false>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((pw_gemm_f32<BM, BN, WM, WN, 2, false, false>), grid, block, 0, s, a);
+        if (glds) hipLaunchKernelGGL((pw_gemm<T, BM, BN, WM, WN, 2, true, true>), grid, block, 0, s, a);
+        else if (kfull) hipLaunchKernelGGL((pw_gemm<T, BM, BN, WM, WN, 2, true, false>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((pw_gemm<T, BM, BN, WM, WN, 2, false, false>), grid, block, 0, s, a);
     }
 }
 
 }   // namespace
 
-int mbn_launch_f32_pointwise(const mbn_call &c, float *out, const float *in, const float *filt, long m, int cin,
+// `out`/`in`/`filt` are fp32 or bf16 according to c.dtype; scale/shift fp32. bf16 + MBN_IO_OUT_F32 writes fp32.
+int mbn_launch_f32_pointwise(const mbn_call &c, void *out, const void *in, const void *filt, long m, int cin,
                              int op_size)
 {
+    const bool bf = c.dtype == MBN_DT_BF16;
     PwArgs a;
     a.out = out; a.in = in; a.filt = filt; a.scale = c.scale; a.shift = c.shift;
     a.m = m; a.k = cin; a.n = op_size; a.act = c.act; a.mt = a.nt = 0;
+    a.out_f32 = bf && (c.io_flags & MBN_IO_OUT_F32) ? 1 : 0;
     if (m <= 0 || (long)((m + 31) / 32) * ((op_size + 31) / 32) > 0x7fffffffL) return MBN_EINVAL;
-    const bool fast = (cin % 4) == 0 && ((uintptr_t)in % 16) == 0 && ((uintptr_t)filt % 16) == 0;
+    const int epc = bf ? 8 : 4;
+    const bool fast = (cin % epc) == 0 && ((uintptr_t)in % 16) == 0 && ((uintptr_t)filt % 16) == 0;
     if (!fast) {
         long total = m * op_size;
-        hipLaunchKernelGGL(pw_generic_f32, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c.stream, a);
+        dim3 grid((unsigned)((total + 255) / 256));
+        if (bf) hipLaunchKernelGGL(pw_generic<__bf16>, grid, dim3(256), 0, c.stream, a);
+        else hipLaunchKernelGGL(pw_generic<float>, grid, dim3(256), 0, c.stream, a);
         return MBN_OK;
     }
-    // Tile choice measured per layer on MI355X (tools/layer_bench.py --tune pw_tile=1..8, profiles/r01): every
+    // Tile choice measured per layer on MI355X in fp32 (tools/layer_bench.py --tune pw_tile=1..8, profiles/r01): every
     // shape lands within a few % of each other (the loop is matrix-pipe bound), <128,64> with 3 workgroups per CU is
     // best or tied from K = 256 up, 8 waves of 32x64 win slightly for K <= 256, 64x64 for narrow outputs / small grids.
     int tile = g_mbn_tune.pw_tile;
@@ -313,15 +343,23 @@ int mbn_launch_f32_pointwise(const mbn_call &c, float *out, const float *in, con
         else tile = 2;
     }
     const int cus = c.ctx->num_cus;
+    if (bf) {                                                              // bf16: the three shipped shapes only
+        switch (tile) {
+        case 3: launch_cfg<__bf16, 64, 64, 32, 32>(a, c.stream, cus); break;
+        case 5: launch_cfg<__bf16, 128, 128, 32, 64>(a, c.stream, cus); break;
+        default: launch_cfg<__bf16, 128, 64, 64, 32>(a, c.stream, cus); break;
+        }
+        return MBN_OK;
+    }
     switch (tile) {
-    case 1: launch_cfg<128, 128, 64, 64>(a, c.stream, cus); break;   // 4 waves, 64 KB LDS, 2 WG/CU
-    case 2: launch_cfg<128, 64, 64, 32>(a, c.stream, cus); break;    // 4 waves, 48 KB LDS, 3 WG/CU
-    case 3: launch_cfg<64, 64, 32, 32>(a, c.stream, cus); break;     // 4 waves, small problems
-    case 4: launch_cfg<256, 128, 64, 64>(a, c.stream, cus); break;   // 8 waves, 96 KB LDS, 1 WG/CU
-    case 5: launch_cfg<128, 128, 32, 64>(a, c.stream, cus); break;   // 8 waves of 32x64, 2 WG/CU
-    case 6: launch_cfg<128, 256, 64, 64>(a, c.stream, cus); break;   // 8 waves, 96 KB LDS
-    case 7: launch_cfg<64, 128, 32, 64>(a, c.stream, cus); break;    // 4 waves, 48 KB LDS, 3 WG/CU
-    case 8: launch_cfg<128, 64, 32, 64>(a, c.stream, cus); break;    // 4 waves of 32x64
+    case 1: launch_cfg<float, 128, 128, 64, 64>(a, c.stream, cus); break;   // 4 waves, 64 KB LDS, 2 WG/CU
+    case 2: launch_cfg<float, 128, 64, 64, 32>(a, c.stream, cus); break;    // 4 waves, 48 KB LDS, 3 WG/CU
+    case 3: launch_cfg<float, 64, 64, 32, 32>(a, c.stream, cus); break;     // 4 waves, small problems
+    case 4: launch_cfg<float, 256, 128, 64, 64>(a, c.stream, cus); break;   // 8 waves, 96 KB LDS, 1 WG/CU
+    case 5: launch_cfg<float, 128, 128, 32, 64>(a, c.stream, cus); break;   // 8 waves of 32x64, 2 WG/CU
+    case 6: launch_cfg<float, 128, 256, 64, 64>(a, c.stream, cus); break;   // 8 waves, 96 KB LDS
+    case 7: launch_cfg<float, 64, 128, 32, 64>(a, c.stream, cus); break;    // 4 waves, 48 KB LDS, 3 WG/CU
+    case 8: launch_cfg<float, 128, 64, 32, 64>(a, c.stream, cus); break;    // 4 waves of 32x64
     default: return MBN_EINVAL;
     }
     return MBN_OK;

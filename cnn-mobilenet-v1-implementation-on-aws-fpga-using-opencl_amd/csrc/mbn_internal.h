@@ -64,6 +64,8 @@ struct mbn_call {
     int g0, g1;
     uint32_t quirks;
     const float *scale, *shift;
+    int dtype;        // MBN_DT_F32 or MBN_DT_BF16 for the NHWC launchers (storage type of activations)
+    int io_flags;     // MBN_IO_IN_F32 / MBN_IO_OUT_F32 (bf16 mode only)
 };
 
 // ---- launchers implemented in the kernel files; each returns MBN_* and launches on c.stream ----
@@ -76,14 +78,15 @@ int mbn_launch_lit_pointwise(const mbn_call &c, uint8_t *out, const uint8_t *in,
                              int cols, int cin, int op_size);
 int mbn_launch_lit_pool(const mbn_call &c, uint8_t *out, const uint8_t *in, int rows, int cols, int fs, int op_size);
 
-// F32 NHWC — mbn_f32_dw.hip / mbn_f32_pw.hip / mbn_f32_misc.hip
-int mbn_launch_f32_conv(const mbn_call &c, float *out, const float *in, const float *filt, int rows, int cols, int fs,
+// NHWC fp32 / bf16 storage (c.dtype), fp32 arithmetic — mbn_f32_dw.hip / mbn_f32_pw.hip / mbn_f32_misc.hip
+int mbn_launch_f32_conv(const mbn_call &c, void *out, const void *in, const float *filt, int rows, int cols, int fs,
                         int stride, int op_size);
-int mbn_launch_f32_depthwise(const mbn_call &c, float *out, const float *in, const float *filt, int rows, int cols,
+int mbn_launch_f32_depthwise(const mbn_call &c, void *out, const void *in, const float *filt, int rows, int cols,
                              int fs, int stride, int channels);
-int mbn_launch_f32_pointwise(const mbn_call &c, float *out, const float *in, const float *filt, long m, int cin,
+int mbn_launch_f32_pointwise(const mbn_call &c, void *out, const void *in, const void *filt, long m, int cin,
                              int op_size);
-int mbn_launch_f32_pool(const mbn_call &c, float *out, const float *in, int rows, int cols, int fs, int channels);
+int mbn_launch_f32_pool(const mbn_call &c, void *out, const void *in, int rows, int cols, int fs, int channels);
+int mbn_launch_convert(mbn_context *ctx, hipStream_t s, void *dst, const void *src, size_t count, int to_bf16);
 int mbn_launch_f32_softmax(mbn_context *ctx, hipStream_t s, float *probs, int32_t *argmax, const float *logits,
                            int batch, int classes);
 int mbn_launch_normalize(mbn_context *ctx, hipStream_t s, float *out, const uint8_t *in, size_t count, float scale,

@@ -22,6 +22,8 @@ struct mbn_net {
     int own_blob;
     void *act[2];
     int keep;
+    int dtype;                 /* MBN_DT_F32 or MBN_DT_BF16 */
+    void *bf16_filt[MBN_MAX_LAYERS];   /* bf16 copies of the pointwise / FC filters (bf16 mode) */
     void *keep_buf[MBN_MAX_LAYERS];
     void *last_out[MBN_MAX_LAYERS];
 };
@@ -38,6 +40,7 @@ static int net_alloc_common(mbn_context *ctx, const mbn_plan *plan, int max_batc
     mbn_net *net = (mbn_net *)calloc(1, sizeof(*net));
     if (!net) return MBN_ENOMEM;
     net->ctx = ctx;
+    net->dtype = MBN_DT_F32;
     net->plan = *plan;
     net->max_batch = max_batch;
     size_t bytes = (size_t)plan->max_act_floats * (size_t)max_batch * sizeof(float);
@@ -81,8 +84,10 @@ int mbn_net_destroy(mbn_net *net)
 {
     if (!net) return MBN_OK;
     mbn_sync(net->ctx);
-    for (int i = 0; i < MBN_MAX_LAYERS; i++)
+    for (int i = 0; i < MBN_MAX_LAYERS; i++) {
         if (net->keep_buf[i]) mbn_free(net->ctx, net->keep_buf[i]);
+        if (net->bf16_filt[i]) mbn_free(net->ctx, net->bf16_filt[i]);
+    }
     if (net->act[0]) mbn_free(net->ctx, net->act[0]);
     if (net->act[1]) mbn_free(net->ctx, net->act[1]);
     if (net->own_blob && net->dev_blob) mbn_free(net->ctx, net->dev_blob);
@@ -94,6 +99,29 @@ int mbn_net_plan(const mbn_net *net, mbn_plan *plan)
 {
     if (!net || !plan) return MBN_EINVAL;
     *plan = net->plan;
+    return MBN_OK;
+}
+
+int mbn_net_set_dtype(mbn_net *net, int dtype)
+{
+    if (!net || (dtype != MBN_DT_F32 && dtype != MBN_DT_BF16)) return MBN_EINVAL;
+    if (dtype == MBN_DT_BF16) {
+        for (int i = 0; i < net->plan.n_layers; i++) {
+            const mbn_layer_desc *l = &net->plan.layer[i];
+            if ((l->kind != MBN_L_PW && l->kind != MBN_L_FC) || net->bf16_filt[i]) continue;
+            int rc = mbn_alloc(net->ctx, (size_t)l->w_count * 2, &net->bf16_filt[i]);
+            if (rc == MBN_OK)
+                rc = mbn_convert_f32_to_bf16(net->ctx, net->bf16_filt[i], blob_at(net, l->w_offset), (size_t)l->w_count, NULL);
+            if (rc != MBN_OK) return rc;
+        }
+    }
+    /* kept activations change element size with the dtype: drop them */
+    if (dtype != net->dtype) {
+        mbn_sync(net->ctx);
+        for (int i = 0; i < MBN_MAX_LAYERS; i++)
+            if (net->keep_buf[i]) { mbn_free(net->ctx, net->keep_buf[i]); net->keep_buf[i] = NULL; }
+    }
+    net->dtype = dtype;
     return MBN_OK;
 }
 
@@ -116,21 +144,24 @@ int mbn_net_layer_output(mbn_net *net, int index, void **dptr, size_t *floats_pe
 /* One layer through the C-ABI: the positional arguments are kernel.cl's (see mbn.h). */
 static int run_layer(mbn_net *net, const mbn_layer_desc *l, const void *src, void *dst, int batch)
 {
+    const int bf = net->dtype == MBN_DT_BF16;
     mbn_layer_ext ext;
     memset(&ext, 0, sizeof(ext));
     ext.struct_size = sizeof(ext);
     ext.batch = batch;
-    ext.dtype = MBN_DT_F32;
+    ext.dtype = net->dtype;
     ext.layout = MBN_LAYOUT_NHWC;
     ext.act = MBN_ACT_RELU6;
     ext.pad_top = l->pad_top;
     ext.pad_left = l->pad_left;
     ext.scale = blob_at(net, l->scale_offset);
     ext.shift = blob_at(net, l->shift_offset);
-    const float *filt = blob_at(net, l->w_offset);
+    const void *filt = blob_at(net, l->w_offset);
+    if (bf && (l->kind == MBN_L_PW || l->kind == MBN_L_FC)) filt = net->bf16_filt[l->index - 1];
     switch (l->kind) {
     case MBN_L_CONV:                       /* MobileNet.c:268-292: rows/cols = input size, stride 2 */
         ext.cin = l->in_ch;
+        if (bf) ext.io_flags = MBN_IO_IN_F32;          /* the normalised image is fp32 */
         return mbn_convolute(net->ctx, dst, src, NULL, NULL, filt, l->in_rows, l->in_cols, 3, l->stride, l->out_ch, &ext);
     case MBN_L_DW:                         /* MobileNet.c:326-381 */
         ext.in_rows = l->in_rows;
@@ -143,6 +174,7 @@ static int run_layer(mbn_net *net, const mbn_layer_desc *l, const void *src, voi
         return mbn_pool(net->ctx, dst, src, l->in_rows, l->in_cols, l->in_rows, l->out_ch, &ext);
     case MBN_L_FC:                         /* MobileNet.c:2682-2739: pointwise with rows = cols = 1; bias, no ReLU (B15) */
         ext.act = MBN_ACT_NONE;
+        if (bf) ext.io_flags = MBN_IO_OUT_F32;         /* logits stay fp32 */
         return mbn_pointwise(net->ctx, dst, src, filt, 1, 1, l->in_ch, l->out_ch, &ext);
     default:
         return MBN_EINVAL;

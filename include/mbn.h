@@ -72,7 +72,7 @@ const char *mbn_strerror(int code);
 /* ------------------------------------------------------------- enumerations */
 enum { MBN_DT_U8 = 0,   /* LITERAL: uint8 act / int32 filter / int32 acc (kernel.cl) */
        MBN_DT_F32 = 1,  /* fp32 act / fp32 filter / fp32 acc                         */
-       MBN_DT_BF16 = 2  /* reserved (BASELINE config 5)                              */ };
+       MBN_DT_BF16 = 2  /* bf16 act / bf16 pointwise filter / fp32 acc (config 5)    */ };
 
 enum { MBN_LAYOUT_NCHW_PLANAR = 0,  /* plane c at offset c*rows*cols (kernel.cl:73,107) */
        MBN_LAYOUT_NHWC = 1 };
@@ -112,7 +112,14 @@ typedef struct mbn_layer_ext {
     const void *scale;     /* F32: device ptr, op_size floats, multiplies the conv sum (folded BN); NULL => 1 */
     const void *shift;     /* F32: device ptr, op_size floats, added after scale (folded BN / FC bias); NULL => 0 */
     void    *stream;       /* hipStream_t; NULL => the context's stream */
+    int32_t  io_flags;     /* MBN_DT_BF16 only: MBN_IO_* (which side of the call is fp32 instead of bf16) */
+    int32_t  reserved;
 } mbn_layer_ext;
+
+/* bf16 mode (BASELINE config 5): activations bf16 NHWC in HBM, pointwise/FC filters bf16 [Cout][Cin], everything
+ * else (conv1/depthwise filters, scale/shift, accumulation) fp32. */
+#define MBN_IO_IN_F32   0x1   /* the input tensor is fp32 (convolute: the normalised image) */
+#define MBN_IO_OUT_F32  0x2   /* the output tensor is fp32 (pointwise as FC: the logits) */
 
 typedef struct mbn_context mbn_context;   /* opaque; one per GPU */
 
@@ -192,6 +199,10 @@ int mbn_softmax_f32(mbn_context *ctx, void *probs, void *argmax_i32, const void 
  * (Keras MobileNet preprocessing is scale=1/127.5, bias=-1). */
 int mbn_normalize_u8_to_f32(mbn_context *ctx, void *out_f32, const void *in_u8, size_t count, float scale,
                             float bias, void *stream);
+
+/* fp32 <-> bf16 (round to nearest even) on device; used to build the bf16 copy of the pointwise/FC filters. */
+int mbn_convert_f32_to_bf16(mbn_context *ctx, void *dst_bf16, const void *src_f32, size_t count, void *stream);
+int mbn_convert_bf16_to_f32(mbn_context *ctx, void *dst_f32, const void *src_bf16, size_t count, void *stream);
 
 /* ------------------------------------------------------------------ loaders
  * The two reference symbols are kept with their exact signatures (CPU only). They return without
@@ -283,6 +294,9 @@ int  mbn_net_create(mbn_context *ctx, const mbn_weights *w, int max_batch, mbn_n
 int  mbn_net_create_from_device_blob(mbn_context *ctx, const mbn_plan *plan, const void *dev_blob,
                                      int max_batch, mbn_net **net);
 int  mbn_net_destroy(mbn_net *net);
+/* MBN_DT_F32 (default) or MBN_DT_BF16: in bf16 mode the net keeps a bf16 copy of the pointwise/FC filters (made on
+ * the device from the fp32 blob), activations are bf16, images stay fp32 [batch][res][res][3], logits stay fp32. */
+int  mbn_net_set_dtype(mbn_net *net, int dtype);
 /* images: device fp32 NHWC [batch][res][res][3]; logits: device fp32 [batch][classes]. Asynchronous.
  * last_layer: run layers 1..last_layer only (0 or 29 => all; 5 and 13 = BASELINE configs 1-2), in which
  * case `logits` receives that layer's NHWC activation instead. */

@@ -373,9 +373,48 @@ int orc_num_threads(void)
 #endif
 }
 
-/* MobileNet.c:240-2763: the 29 layers in order; activations ping-pong between two host buffers. */
+float orc_bf16_round(float x)
+{
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    if ((u & 0x7F800000u) == 0x7F800000u) { u &= 0xFFFF0000u; memcpy(&x, &u, 4); return x; }   /* inf/nan: truncate */
+    u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;      /* round to nearest, ties to even */
+    memcpy(&x, &u, 4);
+    return x;
+}
+
+void orc_bf16_round_array(float *x, long n)
+{
+    for (long i = 0; i < n; i++) x[i] = orc_bf16_round(x[i]);
+}
+
+static int net_forward_impl(const orc_plan *plan, const float *blob, const float *images, float *out, int batch,
+                            int last_layer, int threads, float **layer_out, int bf16);
+
 int orc_net_forward(const orc_plan *plan, const float *blob, const float *images, float *out, int batch,
                     int last_layer, int threads, float **layer_out)
+{
+    return net_forward_impl(plan, blob, images, out, batch, last_layer, threads, layer_out, 0);
+}
+
+int orc_net_forward_bf16(const orc_plan *plan, const float *blob_in, const float *images, float *out, int batch,
+                         int last_layer, int threads, float **layer_out)
+{
+    if (!plan || !blob_in) return -1;
+    float *blob = (float *)malloc(sizeof(float) * plan->blob_floats);
+    if (!blob) return -2;
+    memcpy(blob, blob_in, sizeof(float) * plan->blob_floats);
+    for (int i = 0; i < plan->n_layers; i++)                     /* pointwise / FC filters are stored as bf16 */
+        if (plan->layer[i].kind == ORC_L_PW || plan->layer[i].kind == ORC_L_FC)
+            orc_bf16_round_array(blob + plan->layer[i].w_offset, plan->layer[i].w_count);
+    int rc = net_forward_impl(plan, blob, images, out, batch, last_layer, threads, layer_out, 1);
+    free(blob);
+    return rc;
+}
+
+/* MobileNet.c:240-2763: the 29 layers in order; activations ping-pong between two host buffers. */
+static int net_forward_impl(const orc_plan *plan, const float *blob, const float *images, float *out, int batch,
+                            int last_layer, int threads, float **layer_out, int bf16)
 {
     if (!plan || !blob || !images || !out || batch <= 0) return -1;
     if (last_layer <= 0 || last_layer > plan->n_layers) last_layer = plan->n_layers;
@@ -420,6 +459,7 @@ int orc_net_forward(const orc_plan *plan, const float *blob, const float *images
             return -3;
         }
         long cnt = (long)batch * l->out_rows * l->out_cols * l->out_ch;
+        if (bf16 && l->kind != ORC_L_FC) orc_bf16_round_array(dst, cnt);    /* activations live in HBM as bf16 */
         if (layer_out && layer_out[i]) memcpy(layer_out[i], dst, sizeof(float) * cnt);
         if (i == last_layer - 1) memcpy(out, dst, sizeof(float) * cnt);
         cur = dst;

@@ -101,6 +101,15 @@ int  orc_net_forward(const orc_plan *plan, const float *blob, const float *image
 
 int  orc_num_threads(void);   /* omp_get_max_threads() or 1 */
 
+/* ---------------- bf16 mode (BASELINE config 5): emulated on the CPU ----------------
+ * Activations are bf16 in memory: every layer's output is rounded to bf16 (round-to-nearest-even) before the next
+ * layer reads it; pointwise/FC filters are bf16; depthwise/conv1 filters, scale/shift, accumulation and the FC
+ * logits stay fp32. The input image is fp32. */
+float orc_bf16_round(float x);
+void  orc_bf16_round_array(float *x, long n);
+int   orc_net_forward_bf16(const orc_plan *plan, const float *blob, const float *images, float *out, int batch,
+                           int last_layer, int threads, float **layer_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -184,7 +184,14 @@ def plan_build(alpha=1.0, res=224, classes=1000) -> OrcPlan:
     return p
 
 
-def net_forward(plan: OrcPlan, blob, images, last_layer=0, threads=1, keep_layers=False):
+def bf16_round(a):
+    """Round-to-nearest-even to bf16 precision, returned as float32."""
+    a = np.array(a, dtype=np.float32, copy=True)
+    lib().orc_bf16_round_array(_p(a), C.c_long(a.size))
+    return a
+
+
+def net_forward(plan: OrcPlan, blob, images, last_layer=0, threads=1, keep_layers=False, bf16=False):
     """Returns (out, [per-layer outputs] or None). images [N][res][res][3] fp32."""
     blob, images = _f32(blob), _f32(images)
     n = images.shape[0]
@@ -203,7 +210,8 @@ def net_forward(plan: OrcPlan, blob, images, last_layer=0, threads=1, keep_layer
                 ptrs[i] = a.ctypes.data
             else:
                 ptrs[i] = None
-    rc = lib().orc_net_forward(C.byref(plan), _p(blob), _p(images), _p(out), n, ll, threads, ptrs)
+    fn = lib().orc_net_forward_bf16 if bf16 else lib().orc_net_forward
+    rc = fn(C.byref(plan), _p(blob), _p(images), _p(out), n, ll, threads, ptrs)
     if rc != 0:
         raise RuntimeError("orc_net_forward failed: %d" % rc)
     return out, layer_arrays

@@ -449,3 +449,144 @@ def test_c_host_binary_literal_and_fp32(pkg, orc, tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     m = re.search(r"present at location (\d+) and it's value is ([0-9]+\.[0-9]+)", r.stdout)
     assert m and 1 <= int(m.group(1)) <= 1000 and 0 < float(m.group(2)) <= 1.0
+
+
+# =========================================================================== bf16 mode (BASELINE config 5)
+# Storage bf16, arithmetic fp32. One bf16 ulp is 2^-8 = 0.39 % relative; the GPU sums in fp32 (MFMA / fmaf order), the
+# oracle in double, so a result near a rounding boundary may land on the neighbouring bf16 value.
+TOL_BF16 = 1e-2        # per layer, relative to max|ref| (SURVEY §8c allows 2e-2)
+
+
+def _bf16_dev(pkg, ctx, x):
+    return ctx.to_device(pkg.f32_to_bf16_bits(x))
+
+
+def _bf16_get(pkg, buf, shape):
+    return pkg.bf16_bits_to_f32(buf.download(shape, np.uint16))
+
+
+@pytest.mark.parametrize("shape", [(2, 112, 32, 1), (2, 56, 128, 2), (3, 14, 512, 1), (2, 7, 1024, 1), (1, 9, 8, 2), (1, 10, 6, 1)])
+def test_bf16_depthwise(pkg, orc, ctx, shape):
+    n, h, ch, stride = shape
+    rng = np.random.default_rng(h + ch)
+    x = orc.bf16_round(rng.uniform(-1, 1, (n, h, h, ch)))
+    f = rng.normal(0, 0.5, (3, 3, ch)).astype(np.float32)
+    sc, sh = rng.uniform(0.5, 1.5, ch).astype(np.float32), rng.normal(0, 0.1, ch).astype(np.float32)
+    want = orc.bf16_round(orc.f32_depthwise(x, f, sc, sh, stride, 2))
+    oh = want.shape[1]
+    d_x, d_f, d_sc, d_sh = _bf16_dev(pkg, ctx, x), ctx.to_device(f), ctx.to_device(sc), ctx.to_device(sh)
+    d_o = ctx.alloc(want.size * 2)
+    ext = pkg.make_ext(batch=n, dtype=pkg.DT_BF16, act=2, in_rows=h, in_cols=h, scale=d_sc.ptr, shift=d_sh.ptr)
+    ctx.depthwise(d_o.ptr, d_x.ptr, d_f.ptr, oh, oh, 3, stride, ch, ext)
+    ctx.sync()
+    assert_close(_bf16_get(pkg, d_o, want.shape), want, TOL_BF16, "bf16 dw %s" % (shape,))
+
+
+@pytest.mark.parametrize("shape", [(2 * 56 * 56, 64, 128), (2 * 14 * 14, 512, 512), (3 * 49, 1024, 1024), (12544, 32, 64),
+                                   (130, 8, 24), (77, 72, 40), (5, 1024, 1000), (64, 6, 10)])
+def test_bf16_pointwise(pkg, orc, ctx, shape):
+    m, cin, cout = shape
+    rng = np.random.default_rng(m + cin + cout)
+    x = orc.bf16_round(rng.uniform(-1, 1, (m, cin)))
+    f = orc.bf16_round(rng.normal(0, (2.0 / cin) ** 0.5, (cout, cin)))
+    sc, sh = rng.uniform(0.5, 1.5, cout).astype(np.float32), rng.normal(0, 0.1, cout).astype(np.float32)
+    ref = orc.f32_pointwise(x, f, sc, sh, 2)
+    d_x, d_f, d_sc, d_sh = _bf16_dev(pkg, ctx, x), _bf16_dev(pkg, ctx, f), ctx.to_device(sc), ctx.to_device(sh)
+    d_o = ctx.alloc(m * cout * 4)
+    ext = pkg.make_ext(dtype=pkg.DT_BF16, act=2, scale=d_sc.ptr, shift=d_sh.ptr)
+    ctx.pointwise(d_o.ptr, d_x.ptr, d_f.ptr, m, 1, cin, cout, ext)
+    ctx.sync()
+    assert_close(_bf16_get(pkg, d_o, (m, cout)), orc.bf16_round(ref), TOL_BF16, "bf16 pw %s" % (shape,))
+    # fp32 output (the FC form): only the fp32 summation order differs from the oracle
+    ext = pkg.make_ext(dtype=pkg.DT_BF16, act=2, scale=d_sc.ptr, shift=d_sh.ptr, io_flags=pkg.IO_OUT_F32)
+    ctx.pointwise(d_o.ptr, d_x.ptr, d_f.ptr, m, 1, cin, cout, ext)
+    ctx.sync()
+    assert_close(d_o.download((m, cout), np.float32), ref, TOL_PW, "bf16 pw f32-out %s" % (shape,))
+
+
+def test_bf16_pointwise_exact_integers(pkg, ctx):
+    """Small integers are exact in bf16 and their dot products exact in fp32: checks the bf16 MFMA operand maps
+    bit-exactly with an asymmetric filter."""
+    rng = np.random.default_rng(1)
+    m, cin, cout = 200, 192, 160
+    x = rng.integers(-4, 5, (m, cin)).astype(np.float32)
+    f = rng.integers(-4, 5, (cout, cin)).astype(np.float32)
+    f[:, 0] = np.arange(cout) % 7
+    want = x.astype(np.float64) @ f.astype(np.float64).T
+    d_x, d_f, d_o = _bf16_dev(pkg, ctx, x), _bf16_dev(pkg, ctx, f), ctx.alloc(m * cout * 4)
+    ctx.pointwise(d_o.ptr, d_x.ptr, d_f.ptr, m, 1, cin, cout, pkg.make_ext(dtype=pkg.DT_BF16, act=0, io_flags=pkg.IO_OUT_F32))
+    ctx.sync()
+    assert np.array_equal(d_o.download((m, cout), np.float32).astype(np.float64), want)
+
+
+def test_bf16_convert_roundtrip(pkg, orc, ctx):
+    x = np.random.default_rng(2).normal(0, 3, 100003).astype(np.float32)
+    d_x, d_b, d_y = ctx.to_device(x), ctx.alloc(x.size * 2), ctx.alloc(x.size * 4)
+    assert ctx.lib.mbn_convert_f32_to_bf16(ctx.h, d_b.ptr, d_x.ptr, x.size, None) == 0
+    assert ctx.lib.mbn_convert_bf16_to_f32(ctx.h, d_y.ptr, d_b.ptr, x.size, None) == 0
+    ctx.sync()
+    assert np.array_equal(d_y.download((x.size,), np.float32), orc.bf16_round(x))      # same RNE rounding as the oracle
+    assert np.array_equal(d_b.download((x.size,), np.uint16), pkg.f32_to_bf16_bits(x))
+
+
+def _oracle_layer(orc, plan, blob, i, x, bf16):
+    """Layer i+1 of the plan applied to activation x by the oracle's per-layer functions."""
+    l = plan.layer[i]
+    w = blob[l.w_offset:l.w_offset + max(l.w_count, 0)]
+    sc = blob[l.scale_offset:l.scale_offset + l.out_ch] if l.scale_offset >= 0 else None
+    sh = blob[l.shift_offset:l.shift_offset + l.out_ch] if l.shift_offset >= 0 else None
+    if l.kind == orc.L_CONV:
+        y = orc.f32_conv(x, w.reshape(3, 3, 3, l.out_ch), sc, sh, l.stride, orc.ACT_RELU6)
+    elif l.kind == orc.L_DW:
+        y = orc.f32_depthwise(x, w.reshape(3, 3, l.out_ch), sc, sh, l.stride, orc.ACT_RELU6)
+    elif l.kind == orc.L_PW:
+        wm = w.reshape(l.out_ch, l.in_ch)
+        y = orc.f32_pointwise(x, orc.bf16_round(wm) if bf16 else wm, sc, sh, orc.ACT_RELU6).reshape(
+            x.shape[0], l.out_rows, l.out_cols, l.out_ch)
+    elif l.kind == orc.L_POOL:
+        y = orc.f32_pool(x).reshape(x.shape[0], 1, 1, l.out_ch)
+    else:
+        wm = w.reshape(l.out_ch, l.in_ch)
+        y = orc.f32_pointwise(x.reshape(x.shape[0], -1), orc.bf16_round(wm) if bf16 else wm, None, sh, orc.ACT_NONE)
+        return y.reshape(x.shape[0], 1, 1, l.out_ch)
+    return orc.bf16_round(y) if bf16 else y
+
+
+@pytest.mark.parametrize("cfg", [(0.5, 160, 2), (1.0, 224, 1)])
+def test_bf16_net_per_layer(pkg, orc, ctx, tmp_path, cfg):
+    """BASELINE config 5: MobileNet-V1 0.5x160 and 1.0x224 in bf16. Every layer is checked against the oracle applied to
+    the GPU's OWN previous activation (true per-layer error, no accumulated drift); the logits are also compared with the
+    oracle's all-bf16 forward, where rounding flips accumulate over 28 layers (bound stated below)."""
+    alpha, res, n = cfg
+    hw, net = _make_net(pkg, ctx, tmp_path, alpha, res, 64, n)
+    net.set_dtype(pkg.DT_BF16)
+    net.keep_activations(True)
+    imgs = np.random.default_rng(5).uniform(-1, 1, (n, res, res, 3)).astype(np.float32)
+    d_in, d_out = ctx.to_device(imgs), ctx.alloc(n * 64 * 4)
+    net.forward(d_in.ptr, d_out.ptr, n)
+    ctx.sync()
+    logits = d_out.download((n, 1, 1, 64), np.float32)
+    oplan = orc.plan_build(alpha, res, 64)
+    prev = imgs
+    for i in range(hw.plan.n_layers):
+        got = logits if i == hw.plan.n_layers - 1 else net.layer_output(i + 1, n)
+        w = hw.blob.copy()
+        if oplan.layer[i].kind == orc.L_FC:
+            l = oplan.layer[i]
+            w[l.w_offset:l.w_offset + l.w_count] = orc.bf16_round(w[l.w_offset:l.w_offset + l.w_count])
+            want = orc.f32_pointwise(prev.reshape(n, -1), w[l.w_offset:l.w_offset + l.w_count].reshape(l.out_ch, l.in_ch),
+                                     None, w[l.shift_offset:l.shift_offset + l.out_ch], orc.ACT_NONE).reshape(n, 1, 1, -1)
+            assert_close(got, want, TOL_PW, "bf16 net FC")
+        else:
+            want = _oracle_layer(orc, oplan, w, i, prev, True)
+            assert_close(got, want, TOL_BF16, "bf16 net layer %d" % (i + 1))
+        prev = got
+    full, _ = orc.net_forward(oplan, hw.blob, imgs, bf16=True)
+    assert_close(logits, full, 6e-2, "bf16 logits vs all-oracle bf16 forward (accumulated rounding flips)")
+    # and the fp32 net on the same weights agrees with bf16 to bf16 precision (sanity of the whole mode)
+    net.set_dtype(pkg.DT_F32)
+    net.forward(d_in.ptr, d_out.ptr, n)
+    ctx.sync()
+    f32 = d_out.download((n, 1, 1, 64), np.float32)
+    assert float(np.abs(f32 - logits).max()) <= 0.1 * max(1e-6, float(np.abs(f32).max()))
+    net.destroy()

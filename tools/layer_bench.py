@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--res", type=int, default=224)
     ap.add_argument("--tune", action="append", default=[], help="key=v1,v2,... : A/B over tuning values, interleaved")
     ap.add_argument("--json", action="store_true")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32")
     ap.add_argument("--custom-pw", default="", help="M,K,N[;M,K,N...]: time raw pointwise GEMMs of these shapes instead")
     args = ap.parse_args()
 
@@ -57,8 +58,13 @@ def main():
         m = min(chunk.size, tot - off)
         lib.mbn_upload(ctx.h, d_a.ptr + off * 4, chunk.ctypes.data, m * 4)
 
+    bf = args.dtype == "bf16"
+    ab = 2.0 if bf else 4.0
+
     def call(l):
-        ext = pkg.make_ext(batch=n, act=pkg.ACT_RELU6, pad_top=l.pad_top, pad_left=l.pad_left,
+        ext = pkg.make_ext(batch=n, dtype=pkg.DT_BF16 if bf else pkg.DT_F32, act=pkg.ACT_RELU6, pad_top=l.pad_top,
+                           pad_left=l.pad_left,
+                           io_flags=(pkg.IO_IN_F32 if l.kind == pkg.L_CONV else pkg.IO_OUT_F32 if l.kind == pkg.L_FC else 0) if bf else 0,
                            scale=(d_blob.ptr + 4 * l.scale_offset) if l.scale_offset >= 0 else None,
                            shift=(d_blob.ptr + 4 * l.shift_offset) if l.shift_offset >= 0 else None)
         filt = d_blob.ptr + 4 * l.w_offset
@@ -118,7 +124,7 @@ def main():
                 ctx.profile_begin(1)
                 call(l)
                 times[vi].append(ctx.profile_end(1)[0])
-        f, b = layer_work(l, n, pkg)
+        f, b = layer_work(l, n, pkg, ab)
         for vi, v in enumerate(variants):
             med = float(np.median(times[vi]))
             mn = float(np.min(times[vi]))
