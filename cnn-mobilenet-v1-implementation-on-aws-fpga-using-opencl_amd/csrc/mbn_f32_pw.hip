@@ -28,7 +28,9 @@
 //
 // Measured on MI355X, fp32 (profiles/r01/gemm_ablation.txt): the bare ds_read+MFMA loop runs at 81 % of the fp32
 // matrix peak (89 % at the 2.18 GHz the chip holds under this load); barriers cost nothing; register staging cost
-// 11 % (-> direct-to-LDS), epilogue stores 7 %.
+// 11 % (-> direct-to-LDS), epilogue stores 7 %. A B-stationary "streaming" form for the K = 32/64 layers (filter
+// resident in LDS, each wave loading 32-row A slices straight into MFMA operand registers, no barriers) was built,
+// parity-checked and measured 25-38 % SLOWER than this tiled kernel on layers 3 and 5, so it is not shipped.
 #include "mbn_internal.h"
 
 namespace {
