@@ -69,6 +69,9 @@ def main():
     ap.add_argument("--res", type=int, default=224)
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="storage type of activations and pointwise filters (arithmetic is fp32 either way)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="pipeline each step over this many sub-batches on separate HIP streams (mbn_net_set_streams)")
+    ap.add_argument("--tune", action="append", default=[], help="key=value passed to mbn_tune_set (experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=0, help="images in the CPU baseline sample (0 = auto)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the CPU baseline (cap; box share is 16)")
@@ -91,6 +94,9 @@ def main():
     import torch   # device plumbing only: RCCL broadcast, barrier, device-wide synchronize
 
     lib = pkg.load()          # raises if the HIP extension is missing: no fallback
+    for kv in args.tune:
+        k, v = kv.split("=")
+        assert lib.mbn_tune_set(k.encode(), int(v)) == 0, kv
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
@@ -114,6 +120,8 @@ def main():
 
     ctx = pkg.Context(local_rank)
     net = pkg.Net(ctx, plan, blob_t.data_ptr(), args.batch)
+    if args.streams > 1:
+        net.set_streams(args.streams, free_running=True)   # the input batch is resident before timing starts
     bf16 = args.dtype == "bf16"
     if bf16:
         net.set_dtype(pkg.DT_BF16)
@@ -140,8 +148,10 @@ def main():
     profile = not args.no_profile
     every = max(1, args.profile_every)
     sampled = [s for s in range(args.steps) if s % every == every // 2] or [0]
+    nsub = args.streams if (args.streams > 1 and args.batch >= args.streams) else 1
+    calls_per_step = n_layers * nsub            # with sub-batch streams every layer is launched once per sub-batch
     if profile:
-        ctx.profile_begin(n_layers * len(sampled))
+        ctx.profile_begin(calls_per_step * len(sampled))
         ctx.profile_pause(True)
     barrier()
     torch.cuda.synchronize()
@@ -159,9 +169,11 @@ def main():
     elapsed = t1 - t0
     layer_ms = None
     if profile:
-        ms = ctx.profile_end(n_layers * len(sampled))
-        arr = np.asarray(ms, dtype=np.float64).reshape(len(sampled), n_layers)
-        layer_ms = arr.mean(axis=0)
+        ms = ctx.profile_end(calls_per_step * len(sampled))
+        # launch order inside a step is stream-major: [sub-batch 0: layers 1..29][sub-batch 1: ...]; a layer's time is the
+        # SUM over its sub-batch launches (they overlap other streams' kernels, so this is conservative for GB/s, TFLOP/s)
+        arr = np.asarray(ms, dtype=np.float64).reshape(len(sampled), nsub, n_layers)
+        layer_ms = arr.mean(axis=0).sum(axis=0)
 
     elapsed = mdist.max_over_ranks(elapsed, dev)
 
@@ -190,7 +202,7 @@ def main():
                                                                          and args.batch == 256) else ""),
                        "global_batch": args.batch * world, "per_gpu_batch": args.batch,
                        "parallelism": "batch-sharded x%d, weights broadcast once over RCCL" % world,
-                       "device": ctx.name()},
+                       "streams": args.streams, "device": ctx.name()},
         }
         if layer_ms is not None:
             groups = {"conv1": [pkg.L_CONV], "depthwise": [pkg.L_DW], "pointwise": [pkg.L_PW], "pool": [pkg.L_POOL],
@@ -213,9 +225,10 @@ def main():
                 stages[name] = st
             pw = stages["pointwise"]
             pw_idx = [i for i in range(n_layers) if plan.layer[i].kind == pkg.L_PW]
+            out["launches_per_layer"] = nsub
             flops_per_launch = sum(layer_work(plan.layer[i], args.batch, pkg, act_bytes)[0] for i in pw_idx) / len(pw_idx)
             bytes_per_launch = sum(layer_work(plan.layer[i], args.batch, pkg, act_bytes)[1] for i in pw_idx) / len(pw_idx)
-            avg_ms = pw["ms"] / len(pw_idx)
+            avg_ms = pw["ms"] / len(pw_idx)           # per LAYER (= per launch when --streams 1)
             if bf16:       # ridge ~312 flop/B: every pointwise layer is HBM-bound in bf16
                 out["roofline"] = {
                     "kernel": "pw_gemm<bf16> (13 pointwise 1x1 conv launches per step)",

@@ -148,6 +148,13 @@ def load():
         lib.mbn_convert_f32_to_bf16.argtypes = [vp, vp, vp, C.c_size_t, vp]
         lib.mbn_convert_bf16_to_f32.argtypes = [vp, vp, vp, C.c_size_t, vp]
         lib.mbn_net_set_dtype.argtypes = [vp, ci]
+        lib.mbn_tune_set.argtypes = [C.c_char_p, ci]
+        lib.mbn_tune_get.argtypes = [C.c_char_p, C.POINTER(ci)]
+        lib.mbn_net_set_streams.argtypes = [vp, ci]
+        lib.mbn_net_set_free_running.argtypes = [vp, ci]
+        lib.mbn_stream_create.argtypes = [vp, C.POINTER(vp)]
+        lib.mbn_stream_destroy.argtypes = [vp, vp]
+        lib.mbn_stream_wait.argtypes = [vp, vp, vp]
         lib.mbn_net_create.argtypes = [vp, C.POINTER(Weights), ci, C.POINTER(vp)]
         lib.mbn_net_create_from_device_blob.argtypes = [vp, C.POINTER(Plan), vp, ci, C.POINTER(vp)]
         lib.mbn_net_destroy.argtypes = [vp]
@@ -360,6 +367,10 @@ class Net:
         ms = (C.c_float * MAX_LAYERS)()
         _chk(self.ctx.lib.mbn_net_forward_timed(self.h, images_ptr, out_ptr, batch, ms, MAX_LAYERS), self.ctx.last_error())
         return [ms[i] for i in range(self.plan.n_layers)]
+
+    def set_streams(self, n, free_running=False):
+        _chk(self.ctx.lib.mbn_net_set_streams(self.h, n), self.ctx.last_error())
+        _chk(self.ctx.lib.mbn_net_set_free_running(self.h, int(free_running)))
 
     def set_dtype(self, dtype):
         self.dtype = dtype

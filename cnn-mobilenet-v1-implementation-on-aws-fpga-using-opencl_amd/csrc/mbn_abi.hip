@@ -20,6 +20,7 @@ static int *tune_slot(const char *key)
     if (!strcmp(key, "pw_stage")) return &g_mbn_tune.pw_stage;
     if (!strcmp(key, "conv_variant")) return &g_mbn_tune.conv_variant;
     if (!strcmp(key, "misc")) return &g_mbn_tune.misc;
+    if (!strcmp(key, "net_stagger")) return &g_mbn_tune.net_stagger;
     return nullptr;
 }
 
@@ -86,6 +87,7 @@ int mbn_shutdown(mbn_context *ctx)
     for (auto &kv : ctx->allocs) (void)hipFree(kv.first);
     ctx->allocs.clear();
     for (hipEvent_t e : ctx->pool) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->sync_events) (void)hipEventDestroy(e);
     (void)hipEventDestroy(ctx->ev_start);
     (void)hipEventDestroy(ctx->ev_stop);
     (void)hipStreamDestroy(ctx->stream);
@@ -113,6 +115,43 @@ int mbn_get_stream(mbn_context *ctx, void **stream)
 {
     if (!ctx || !stream) return MBN_EINVAL;
     *stream = (void *)ctx->stream;
+    return MBN_OK;
+}
+
+int mbn_stream_create(mbn_context *ctx, void **stream)
+{
+    if (!ctx || !stream) return MBN_EINVAL;
+    (void)hipSetDevice(ctx->device);
+    hipStream_t s;
+    MBN_HIP_TRY(ctx, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = (void *)s;
+    return MBN_OK;
+}
+
+int mbn_stream_destroy(mbn_context *ctx, void *stream)
+{
+    if (!ctx || !stream) return MBN_EINVAL;
+    (void)hipSetDevice(ctx->device);
+    MBN_HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
+    MBN_HIP_TRY(ctx, hipStreamDestroy((hipStream_t)stream));
+    return MBN_OK;
+}
+
+int mbn_stream_wait(mbn_context *ctx, void *waiter, void *signaler)
+{
+    if (!ctx) return MBN_EINVAL;
+    hipStream_t w = waiter ? (hipStream_t)waiter : ctx->stream, sg = signaler ? (hipStream_t)signaler : ctx->stream;
+    if (w == sg) return MBN_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->sync_events.size() < 64) {
+        hipEvent_t e;
+        MBN_HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->sync_events.push_back(e);
+        ctx->sync_next = ctx->sync_events.size() - 1;
+    } else ctx->sync_next = (ctx->sync_next + 1) % ctx->sync_events.size();
+    hipEvent_t e = ctx->sync_events[ctx->sync_next];      // re-recording an event is legal: earlier waits keep their capture
+    MBN_HIP_TRY(ctx, hipEventRecord(e, sg));
+    MBN_HIP_TRY(ctx, hipStreamWaitEvent(w, e, 0));
     return MBN_OK;
 }
 

@@ -22,6 +22,8 @@ struct mbn_context {
     char last_error[256] = {0};
     char name[128] = {0};
     int num_cus = 256;
+    std::vector<hipEvent_t> sync_events;         // mbn_stream_wait: reusable fork/join events (round robin)
+    size_t sync_next = 0;
     std::vector<hipEvent_t> pool;                // mbn_profile_begin/end: 2 events per recorded call
     int pool_cap = 0, pool_used = 0;
     bool pool_on = false;
@@ -49,6 +51,7 @@ struct mbn_tunables {
     int pw_stage = 0;     // 1 = register staging instead of direct-to-LDS loads
     int conv_variant = 0; // conv1 kernel variant
     int misc = 0;
+    int net_stagger = 2;  // layers by which consecutive sub-batch streams are staggered (mbn_net_set_streams)
 };
 extern mbn_tunables g_mbn_tune;
 

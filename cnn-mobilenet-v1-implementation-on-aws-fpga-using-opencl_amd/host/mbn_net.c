@@ -23,6 +23,9 @@ struct mbn_net {
     void *act[2];
     int keep;
     int dtype;                 /* MBN_DT_F32 or MBN_DT_BF16 */
+    int free_running;          /* no fork dependency on the context's stream (mbn_net_set_free_running) */
+    int nstreams;              /* sub-batch pipelining (mbn_net_set_streams); 1 = everything on the context's stream */
+    void *streams[8];
     void *bf16_filt[MBN_MAX_LAYERS];   /* bf16 copies of the pointwise / FC filters (bf16 mode) */
     void *keep_buf[MBN_MAX_LAYERS];
     void *last_out[MBN_MAX_LAYERS];
@@ -41,6 +44,7 @@ static int net_alloc_common(mbn_context *ctx, const mbn_plan *plan, int max_batc
     if (!net) return MBN_ENOMEM;
     net->ctx = ctx;
     net->dtype = MBN_DT_F32;
+    net->nstreams = 1;
     net->plan = *plan;
     net->max_batch = max_batch;
     size_t bytes = (size_t)plan->max_act_floats * (size_t)max_batch * sizeof(float);
@@ -84,6 +88,8 @@ int mbn_net_destroy(mbn_net *net)
 {
     if (!net) return MBN_OK;
     mbn_sync(net->ctx);
+    for (int j = 0; j < 8; j++)
+        if (net->streams[j]) mbn_stream_destroy(net->ctx, net->streams[j]);
     for (int i = 0; i < MBN_MAX_LAYERS; i++) {
         if (net->keep_buf[i]) mbn_free(net->ctx, net->keep_buf[i]);
         if (net->bf16_filt[i]) mbn_free(net->ctx, net->bf16_filt[i]);
@@ -125,6 +131,25 @@ int mbn_net_set_dtype(mbn_net *net, int dtype)
     return MBN_OK;
 }
 
+int mbn_net_set_streams(mbn_net *net, int n)
+{
+    if (!net || n < 1 || n > 8) return MBN_EINVAL;
+    for (int j = 0; j < n; j++)
+        if (!net->streams[j]) {
+            int rc = mbn_stream_create(net->ctx, &net->streams[j]);
+            if (rc != MBN_OK) return rc;
+        }
+    net->nstreams = n;
+    return MBN_OK;
+}
+
+int mbn_net_set_free_running(mbn_net *net, int enabled)
+{
+    if (!net) return MBN_EINVAL;
+    net->free_running = enabled != 0;
+    return MBN_OK;
+}
+
 int mbn_net_set_keep_activations(mbn_net *net, int keep)
 {
     if (!net) return MBN_EINVAL;
@@ -142,7 +167,7 @@ int mbn_net_layer_output(mbn_net *net, int index, void **dptr, size_t *floats_pe
 }
 
 /* One layer through the C-ABI: the positional arguments are kernel.cl's (see mbn.h). */
-static int run_layer(mbn_net *net, const mbn_layer_desc *l, const void *src, void *dst, int batch)
+static int run_layer(mbn_net *net, const mbn_layer_desc *l, const void *src, void *dst, int batch, void *stream)
 {
     const int bf = net->dtype == MBN_DT_BF16;
     mbn_layer_ext ext;
@@ -156,6 +181,7 @@ static int run_layer(mbn_net *net, const mbn_layer_desc *l, const void *src, voi
     ext.pad_left = l->pad_left;
     ext.scale = blob_at(net, l->scale_offset);
     ext.shift = blob_at(net, l->shift_offset);
+    ext.stream = stream;
     const void *filt = blob_at(net, l->w_offset);
     if (bf && (l->kind == MBN_L_PW || l->kind == MBN_L_FC)) filt = net->bf16_filt[l->index - 1];
     switch (l->kind) {
@@ -181,37 +207,84 @@ static int run_layer(mbn_net *net, const mbn_layer_desc *l, const void *src, voi
     }
 }
 
-static int forward_impl(mbn_net *net, const void *images, void *logits, int batch, int last_layer, float *layer_ms,
-                        int n_layer_ms)
+/* bytes per element of layer i's output in the current mode (FC logits are fp32 in both) */
+static size_t out_esize(const mbn_net *net, const mbn_layer_desc *l)
 {
-    if (!net || !images || !logits || batch <= 0 || batch > net->max_batch) return MBN_EINVAL;
-    const int n = net->plan.n_layers;
-    if (last_layer <= 0 || last_layer > n) last_layer = n;
-    const void *src = images;
+    return (net->dtype == MBN_DT_BF16 && l->kind != MBN_L_FC) ? 2 : 4;
+}
+
+/* Layers 1..last_layer for images [first, first+count) on `stream` (NULL = the context's stream). Sub-batches use
+ * disjoint slices of the two ping-pong buffers, so several of them can be in flight on different streams. */
+static int forward_range(mbn_net *net, const void *images, void *logits, int first, int count, int last_layer,
+                         void *stream, float *layer_ms, int n_layer_ms, void *next_stream, int stagger)
+{
+    const size_t img_floats = (size_t)net->plan.res * net->plan.res * 3;
+    const char *src = (const char *)images + (size_t)first * img_floats * sizeof(float);
+    const size_t slot = (size_t)first * (size_t)net->plan.max_act_floats * sizeof(float);
     int which = 0;
     for (int i = 0; i < last_layer; i++) {
         const mbn_layer_desc *l = &net->plan.layer[i];
-        void *dst;
-        if (i == last_layer - 1) dst = logits;
+        const size_t per_img = (size_t)l->out_rows * l->out_cols * l->out_ch * out_esize(net, l);
+        char *dst;
+        if (i == last_layer - 1) dst = (char *)logits + (size_t)first * per_img;
         else if (net->keep) {
             if (!net->keep_buf[i]) {
                 size_t bytes = (size_t)l->out_rows * l->out_cols * l->out_ch * sizeof(float) * (size_t)net->max_batch;
                 int rc = mbn_alloc(net->ctx, bytes, &net->keep_buf[i]);
                 if (rc != MBN_OK) return rc;
             }
-            dst = net->keep_buf[i];
+            dst = (char *)net->keep_buf[i] + (size_t)first * per_img;
         } else {
-            dst = net->act[which];
+            dst = (char *)net->act[which] + slot;
             which ^= 1;
         }
-        int rc = run_layer(net, l, src, dst, batch);
+        int rc = run_layer(net, l, src, dst, count, stream);
         if (rc != MBN_OK) return rc;
         if (layer_ms && i < n_layer_ms) {
             rc = mbn_last_kernel_ms(net->ctx, &layer_ms[i]);
             if (rc != MBN_OK) return rc;
         }
-        net->last_out[i] = dst;
+        if (first == 0) net->last_out[i] = dst;
         src = dst;
+        /* stagger: the next sub-batch's stream may start only when this one has finished `stagger` layers, so the
+         * streams run a layer or two apart and unlike kernels (HBM-bound vs MFMA-bound) meet each other */
+        if (next_stream && i + 1 == stagger) {
+            rc = mbn_stream_wait(net->ctx, next_stream, stream);
+            if (rc != MBN_OK) return rc;
+        }
+    }
+    return MBN_OK;
+}
+
+static int forward_impl(mbn_net *net, const void *images, void *logits, int batch, int last_layer, float *layer_ms,
+                        int n_layer_ms)
+{
+    if (!net || !images || !logits || batch <= 0 || batch > net->max_batch) return MBN_EINVAL;
+    const int n = net->plan.n_layers;
+    if (last_layer <= 0 || last_layer > n) last_layer = n;
+    int ns = net->nstreams;
+    if (layer_ms || ns > batch) ns = 1;                /* per-layer timing serialises; tiny batches are not split */
+    if (ns <= 1) return forward_range(net, images, logits, 0, batch, last_layer, NULL, layer_ms, n_layer_ms, NULL, 0);
+    int stagger = 2;
+    (void)mbn_tune_get("net_stagger", &stagger);
+    if (stagger > last_layer) stagger = last_layer;
+    /* fork: every sub-stream starts after what is already queued on the context's stream (e.g. the producer of
+     * `images`); sub-batches are launched stream after stream, which staggers them by a layer or two so that one
+     * stream's depthwise (HBM-bound) meets another's pointwise (MFMA-bound); join: the context's stream waits for all. */
+    const int q = batch / ns, r = batch % ns;
+    int first = 0;
+    for (int j = 0; j < ns; j++) {
+        const int count = q + (j < r ? 1 : 0);
+        int rc = net->free_running ? MBN_OK : mbn_stream_wait(net->ctx, net->streams[j], NULL);
+        if (rc == MBN_OK)
+            rc = forward_range(net, images, logits, first, count, last_layer, net->streams[j], NULL, 0,
+                               j + 1 < ns ? net->streams[j + 1] : NULL, stagger);
+        if (rc != MBN_OK) return rc;
+        first += count;
+    }
+    for (int j = 0; j < ns; j++) {
+        int rc = mbn_stream_wait(net->ctx, NULL, net->streams[j]);
+        if (rc != MBN_OK) return rc;
     }
     return MBN_OK;
 }

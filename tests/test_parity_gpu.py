@@ -590,3 +590,27 @@ def test_bf16_net_per_layer(pkg, orc, ctx, tmp_path, cfg):
     f32 = d_out.download((n, 1, 1, 64), np.float32)
     assert float(np.abs(f32 - logits).max()) <= 0.1 * max(1e-6, float(np.abs(f32).max()))
     net.destroy()
+
+
+@pytest.mark.parametrize("ns", [2, 3, 8])
+def test_net_multi_stream_equals_single_stream(pkg, ctx, tmp_path, ns):
+    """mbn_net_set_streams: sub-batches on forked/joined streams give bit-identical logits, also for a batch that does
+    not divide evenly and for a following operation queued on the context's stream (join ordering)."""
+    hw, net = _make_net(pkg, ctx, tmp_path, 0.5, 96, 40, 11)
+    imgs = np.random.default_rng(6).uniform(-1, 1, (11, 96, 96, 3)).astype(np.float32)
+    d_in, d_out, d_p, d_a = ctx.to_device(imgs), ctx.alloc(11 * 40 * 4), ctx.alloc(11 * 40 * 4), ctx.alloc(11 * 4)
+    net.forward(d_in.ptr, d_out.ptr, 11)
+    ctx.sync()
+    want = d_out.download((11, 40), np.float32)
+    net.set_streams(ns)
+    for _ in range(3):
+        ctx.lib.mbn_memset(ctx.h, d_out.ptr, 0xFF, 11 * 40 * 4)       # queued on the context stream BEFORE the fork
+        net.forward(d_in.ptr, d_out.ptr, 11)
+        assert ctx.lib.mbn_softmax_f32(ctx.h, d_p.ptr, d_a.ptr, d_out.ptr, 11, 40, None) == 0   # after the join
+        ctx.sync()
+        assert np.array_equal(d_out.download((11, 40), np.float32), want)
+        assert np.array_equal(d_a.download((11,), np.int32), want.argmax(1))
+    net.forward(d_in.ptr, d_out.ptr, 2)                               # fewer images than streams
+    ctx.sync()
+    assert np.array_equal(d_out.download((2, 40), np.float32), want[:2])
+    net.destroy()
