@@ -79,6 +79,9 @@ __global__ __launch_bounds__(256) void conv_f32_nhwc(ConvArgs a)
 // as 6 aligned float4 + 3 floats (27 contiguous floats of the NHWC row; the cout/4 lanes of a pixel group read the same
 // addresses, one request), and each LDS weight float4 is reused for the 4 pixels: 432 FMAs per 21 global + 27 LDS
 // loads instead of 108 per 27 + 27. Stores stay whole 128-B lines per pixel.
+// Measured and rejected: the same layer as an im2col GEMM on the matrix cores (14 v_mfma_f32_32x32x2_f32 per 32-pixel
+// tile, operands gathered with 14 dword loads per lane, no LDS) was parity-correct but 8 % slower — the scattered
+// 4-byte gather makes it address-rate bound, not instruction bound.
 template <typename TO>
 __global__ __launch_bounds__(256) void conv3x3s2c3_f32_nhwc(ConvArgs a)
 {
