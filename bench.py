@@ -71,6 +71,7 @@ def main():
                     help="storage type of activations and pointwise filters (arithmetic is fp32 either way)")
     ap.add_argument("--streams", type=int, default=1,
                     help="pipeline each step over this many sub-batches on separate HIP streams (mbn_net_set_streams)")
+    ap.add_argument("--graph", action="store_true", help="replay each step as one hipGraph (mbn_net_set_graph)")
     ap.add_argument("--tune", action="append", default=[], help="key=value passed to mbn_tune_set (experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=0, help="images in the CPU baseline sample (0 = auto)")
@@ -120,6 +121,8 @@ def main():
 
     ctx = pkg.Context(local_rank)
     net = pkg.Net(ctx, plan, blob_t.data_ptr(), args.batch)
+    if args.graph:
+        net.set_graph(True)
     if args.streams > 1:
         net.set_streams(args.streams, free_running=True)   # the input batch is resident before timing starts
     bf16 = args.dtype == "bf16"
@@ -145,7 +148,7 @@ def main():
     ctx.sync()
 
     n_layers = plan.n_layers
-    profile = not args.no_profile
+    profile = not args.no_profile and not args.graph    # per-kernel events cannot be read back from inside a graph
     every = max(1, args.profile_every)
     sampled = [s for s in range(args.steps) if s % every == every // 2] or [0]
     nsub = args.streams if (args.streams > 1 and args.batch >= args.streams) else 1

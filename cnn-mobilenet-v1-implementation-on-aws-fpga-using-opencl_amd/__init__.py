@@ -152,6 +152,11 @@ def load():
         lib.mbn_tune_get.argtypes = [C.c_char_p, C.POINTER(ci)]
         lib.mbn_net_set_streams.argtypes = [vp, ci]
         lib.mbn_net_set_free_running.argtypes = [vp, ci]
+        lib.mbn_net_set_graph.argtypes = [vp, ci]
+        lib.mbn_graph_begin.argtypes = [vp, vp]
+        lib.mbn_graph_end.argtypes = [vp, vp, C.POINTER(vp)]
+        lib.mbn_graph_launch.argtypes = [vp, vp, vp]
+        lib.mbn_graph_destroy.argtypes = [vp, vp]
         lib.mbn_stream_create.argtypes = [vp, C.POINTER(vp)]
         lib.mbn_stream_destroy.argtypes = [vp, vp]
         lib.mbn_stream_wait.argtypes = [vp, vp, vp]
@@ -371,6 +376,9 @@ class Net:
     def set_streams(self, n, free_running=False):
         _chk(self.ctx.lib.mbn_net_set_streams(self.h, n), self.ctx.last_error())
         _chk(self.ctx.lib.mbn_net_set_free_running(self.h, int(free_running)))
+
+    def set_graph(self, enabled=True):
+        _chk(self.ctx.lib.mbn_net_set_graph(self.h, int(enabled)), self.ctx.last_error())
 
     def set_dtype(self, dtype):
         self.dtype = dtype

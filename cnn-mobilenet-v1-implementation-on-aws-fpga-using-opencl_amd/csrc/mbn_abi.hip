@@ -155,6 +155,46 @@ int mbn_stream_wait(mbn_context *ctx, void *waiter, void *signaler)
     return MBN_OK;
 }
 
+int mbn_graph_begin(mbn_context *ctx, void *stream)
+{
+    if (!ctx) return MBN_EINVAL;
+    (void)hipSetDevice(ctx->device);
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    MBN_HIP_TRY(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    return MBN_OK;
+}
+
+int mbn_graph_end(mbn_context *ctx, void *stream, void **graph_exec)
+{
+    if (!ctx || !graph_exec) return MBN_EINVAL;
+    *graph_exec = nullptr;
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    hipGraph_t g = nullptr;
+    MBN_HIP_TRY(ctx, hipStreamEndCapture(s, &g));
+    hipGraphExec_t ge = nullptr;
+    hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (e != hipSuccess) return mbn_record_hip_error(ctx, e, "hipGraphInstantiate");
+    *graph_exec = (void *)ge;
+    return MBN_OK;
+}
+
+int mbn_graph_launch(mbn_context *ctx, void *graph_exec, void *stream)
+{
+    if (!ctx || !graph_exec) return MBN_EINVAL;
+    (void)hipSetDevice(ctx->device);
+    MBN_HIP_TRY(ctx, hipGraphLaunch((hipGraphExec_t)graph_exec, stream ? (hipStream_t)stream : ctx->stream));
+    return MBN_OK;
+}
+
+int mbn_graph_destroy(mbn_context *ctx, void *graph_exec)
+{
+    if (!ctx) return MBN_EINVAL;
+    if (!graph_exec) return MBN_OK;
+    MBN_HIP_TRY(ctx, hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+    return MBN_OK;
+}
+
 int mbn_alloc(mbn_context *ctx, size_t bytes, void **dptr)
 {
     if (!ctx || !dptr || bytes == 0) return MBN_EINVAL;
@@ -284,9 +324,15 @@ struct Scope {   // hipEvent pair around one layer call when profiling is on (Mo
     mbn_context *ctx;
     hipStream_t s;
     int slot = -1;
+    bool capturing = false;
     Scope(mbn_context *c, hipStream_t st) : ctx(c), s(st)
     {
         (void)hipSetDevice(ctx->device);
+        if (ctx->profiling || ctx->pool_on) {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            capturing = hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+        }
+        if (capturing) return;
         if (ctx->profiling) (void)hipEventRecord(ctx->ev_start, s);
         if (ctx->pool_on && ctx->pool_used < ctx->pool_cap) {
             slot = ctx->pool_used++;
@@ -296,7 +342,7 @@ struct Scope {   // hipEvent pair around one layer call when profiling is on (Mo
     int finish(int rc)
     {
         if (slot >= 0) (void)hipEventRecord(ctx->pool[2 * slot + 1], s);
-        if (ctx->profiling) {
+        if (ctx->profiling && !capturing) {
             (void)hipEventRecord(ctx->ev_stop, s);
             ctx->ev_valid = true;
         }

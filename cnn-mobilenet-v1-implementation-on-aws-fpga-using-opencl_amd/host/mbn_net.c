@@ -23,6 +23,11 @@ struct mbn_net {
     void *act[2];
     int keep;
     int dtype;                 /* MBN_DT_F32 or MBN_DT_BF16 */
+    int use_graph;             /* mbn_net_set_graph */
+    void *graph;               /* instantiated hipGraph of one forward, valid for the key below */
+    const void *g_images;
+    void *g_logits;
+    int g_batch, g_last, g_dtype, g_keep;
     int free_running;          /* no fork dependency on the context's stream (mbn_net_set_free_running) */
     int nstreams;              /* sub-batch pipelining (mbn_net_set_streams); 1 = everything on the context's stream */
     void *streams[8];
@@ -88,6 +93,7 @@ int mbn_net_destroy(mbn_net *net)
 {
     if (!net) return MBN_OK;
     mbn_sync(net->ctx);
+    if (net->graph) mbn_graph_destroy(net->ctx, net->graph);
     for (int j = 0; j < 8; j++)
         if (net->streams[j]) mbn_stream_destroy(net->ctx, net->streams[j]);
     for (int i = 0; i < MBN_MAX_LAYERS; i++) {
@@ -140,6 +146,18 @@ int mbn_net_set_streams(mbn_net *net, int n)
             if (rc != MBN_OK) return rc;
         }
     net->nstreams = n;
+    return MBN_OK;
+}
+
+int mbn_net_set_graph(mbn_net *net, int enabled)
+{
+    if (!net) return MBN_EINVAL;
+    net->use_graph = enabled != 0;
+    if (!enabled && net->graph) {
+        mbn_sync(net->ctx);
+        mbn_graph_destroy(net->ctx, net->graph);
+        net->graph = NULL;
+    }
     return MBN_OK;
 }
 
@@ -264,6 +282,35 @@ static int forward_impl(mbn_net *net, const void *images, void *logits, int batc
     if (last_layer <= 0 || last_layer > n) last_layer = n;
     int ns = net->nstreams;
     if (layer_ms || ns > batch) ns = 1;                /* per-layer timing serialises; tiny batches are not split */
+    if (ns <= 1 && net->use_graph && !layer_ms) {
+        /* launch-bound batches: replay the 29 launches as one hipGraph; re-capture when the call's key changes */
+        if (net->graph && (net->g_images != images || net->g_logits != logits || net->g_batch != batch ||
+                           net->g_last != last_layer || net->g_dtype != net->dtype || net->g_keep != net->keep)) {
+            mbn_sync(net->ctx);
+            mbn_graph_destroy(net->ctx, net->graph);
+            net->graph = NULL;
+        }
+        if (!net->graph) {
+            if (net->keep)                                   /* allocations are not allowed inside a capture */
+                for (int i = 0; i < last_layer - 1; i++)
+                    if (!net->keep_buf[i]) {
+                        const mbn_layer_desc *l = &net->plan.layer[i];
+                        size_t bytes = (size_t)l->out_rows * l->out_cols * l->out_ch * sizeof(float) * (size_t)net->max_batch;
+                        int rc = mbn_alloc(net->ctx, bytes, &net->keep_buf[i]);
+                        if (rc != MBN_OK) return rc;
+                    }
+            int rc = mbn_graph_begin(net->ctx, NULL);
+            if (rc != MBN_OK) return rc;
+            rc = forward_range(net, images, logits, 0, batch, last_layer, NULL, NULL, 0, NULL, 0);
+            void *g = NULL;
+            int rc2 = mbn_graph_end(net->ctx, NULL, &g);     /* always close the capture */
+            if (rc != MBN_OK || rc2 != MBN_OK) { if (g) mbn_graph_destroy(net->ctx, g); return rc != MBN_OK ? rc : rc2; }
+            net->graph = g;
+            net->g_images = images; net->g_logits = logits; net->g_batch = batch; net->g_last = last_layer;
+            net->g_dtype = net->dtype; net->g_keep = net->keep;
+        }
+        return mbn_graph_launch(net->ctx, net->graph, NULL);
+    }
     if (ns <= 1) return forward_range(net, images, logits, 0, batch, last_layer, NULL, layer_ms, n_layer_ms, NULL, 0);
     int stagger = 2;
     (void)mbn_tune_get("net_stagger", &stagger);

@@ -139,6 +139,14 @@ int  mbn_get_stream(mbn_context *ctx, void **stream);    /* the context's hipStr
 int  mbn_stream_create(mbn_context *ctx, void **stream);
 int  mbn_stream_destroy(mbn_context *ctx, void *stream);
 int  mbn_stream_wait(mbn_context *ctx, void *waiter, void *signaler);
+/* hipGraph capture of a sequence of layer calls (launch-bound small-batch loops): everything queued on `stream`
+ * (NULL = the context's stream) between begin and end is recorded instead of executed; mbn_graph_launch replays it as
+ * one submission. Blocking calls (mbn_upload/download/sync/alloc/free) must not be made on that stream while capturing;
+ * the per-call profiling events are skipped inside a capture. */
+int  mbn_graph_begin(mbn_context *ctx, void *stream);
+int  mbn_graph_end(mbn_context *ctx, void *stream, void **graph_exec);
+int  mbn_graph_launch(mbn_context *ctx, void *graph_exec, void *stream);
+int  mbn_graph_destroy(mbn_context *ctx, void *graph_exec);
 
 /* ---------------------------------------------------- buffers (clCreateBuffer &c.) */
 int  mbn_alloc(mbn_context *ctx, size_t bytes, void **dptr);                 /* MobileNet.c:340-342 */
@@ -314,6 +322,10 @@ int  mbn_net_set_streams(mbn_net *net, int n);
  * across the step boundary (sub-batch j of step k+1 only waits for sub-batch j of step k); the join into the
  * context's stream is still queued, so mbn_sync / later work on that stream stays ordered after the results. */
 int  mbn_net_set_free_running(mbn_net *net, int enabled);
+/* 1 = capture the 29 launches of a forward into a hipGraph the first time a (images, logits, batch, last_layer)
+ * combination is seen and replay it afterwards (re-captured when any of them changes). For launch-bound batches:
+ * measured 0.285 -> see DESIGN.md ms per forward at batch 1. Ignored with more than one stream or in timed forwards. */
+int  mbn_net_set_graph(mbn_net *net, int enabled);
 /* images: device fp32 NHWC [batch][res][res][3]; logits: device fp32 [batch][classes]. Asynchronous.
  * last_layer: run layers 1..last_layer only (0 or 29 => all; 5 and 13 = BASELINE configs 1-2), in which
  * case `logits` receives that layer's NHWC activation instead. */

@@ -614,3 +614,33 @@ def test_net_multi_stream_equals_single_stream(pkg, ctx, tmp_path, ns):
     ctx.sync()
     assert np.array_equal(d_out.download((2, 40), np.float32), want[:2])
     net.destroy()
+
+
+def test_net_graph_replay_equals_eager(pkg, ctx, tmp_path):
+    """mbn_net_set_graph: the captured hipGraph replays bit-identically, follows changed INPUT CONTENTS (same
+    pointers), and is re-captured when the batch or a pointer changes."""
+    hw, net = _make_net(pkg, ctx, tmp_path, 0.25, 64, 30, 4)
+    rng = np.random.default_rng(8)
+    a, b = (rng.uniform(-1, 1, (4, 64, 64, 3)).astype(np.float32) for _ in range(2))
+    d_in, d_out, d_out2 = ctx.to_device(a), ctx.alloc(4 * 30 * 4), ctx.alloc(4 * 30 * 4)
+    net.forward(d_in.ptr, d_out.ptr, 4)
+    ctx.sync()
+    want_a = d_out.download((4, 30), np.float32)
+    net.set_graph(True)
+    for _ in range(3):                                   # capture, then two replays
+        net.forward(d_in.ptr, d_out.ptr, 4)
+        ctx.sync()
+        assert np.array_equal(d_out.download((4, 30), np.float32), want_a)
+    d_in.upload(b)                                       # new contents, same pointers -> replay must see them
+    net.forward(d_in.ptr, d_out.ptr, 4)
+    ctx.sync()
+    got_b = d_out.download((4, 30), np.float32)
+    assert not np.array_equal(got_b, want_a)
+    net.forward(d_in.ptr, d_out2.ptr, 2)                 # other batch + other output pointer -> re-capture
+    ctx.sync()
+    assert np.array_equal(d_out2.download((2, 30), np.float32), got_b[:2])
+    net.set_graph(False)
+    net.forward(d_in.ptr, d_out.ptr, 4)
+    ctx.sync()
+    assert np.array_equal(d_out.download((4, 30), np.float32), got_b)
+    net.destroy()
