@@ -340,7 +340,7 @@ int mbn_launch_f32_pointwise(const mbn_call &c, void *out, const void *in, const
     int tile = g_mbn_tune.pw_tile;
     if (tile == 0) {
         const long big_tiles = ((m + 127) / 128) * ((op_size + 63) / 64);
-        if (big_tiles < 2L * c.ctx->num_cus || op_size <= 64) tile = 3;
+        if (big_tiles < 2L * c.ctx->num_cus || op_size <= 64 || m <= 16384) tile = 3;   // 7x7 layers: finer tiles balance better
         else if (cin <= 256 && op_size >= 128) tile = 5;
         else tile = 2;
     }
