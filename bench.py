@@ -71,6 +71,8 @@ def main():
                     help="storage type of activations and pointwise filters (arithmetic is fp32 either way)")
     ap.add_argument("--streams", type=int, default=1,
                     help="pipeline each step over this many sub-batches on separate HIP streams (mbn_net_set_streams)")
+    ap.add_argument("--dist-backend", default="nccl", help="rehearsal only: 'gloo' lets several ranks share one GPU")
+    ap.add_argument("--device-override", type=int, default=-1, help="rehearsal only: every rank uses this device")
     ap.add_argument("--graph", action="store_true", help="replay each step as one hipGraph (mbn_net_set_graph)")
     ap.add_argument("--tune", action="append", default=[], help="key=value passed to mbn_tune_set (experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -101,9 +103,11 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
+    if args.device_override >= 0:
+        local_rank = args.device_override
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    mdist.init("nccl", dev)                    # nccl == RCCL on ROCm; no-op for one process
+    mdist.init(args.dist_backend, dev)         # nccl == RCCL on ROCm; no-op for one process
 
     # ---- parameters: rank 0 writes a synthetic Keras-layout .h5 and reads it back through the real loader
     plan = pkg.plan_build(args.alpha, args.res, 1000, lib=lib)
@@ -116,7 +120,12 @@ def main():
         assert hw.plan.blob_floats == plan.blob_floats
         blob_t.copy_(torch.from_numpy(hw.blob))
         hw.free()
-    mdist.broadcast_blob(blob_t, 0)            # the one collective of the path: ~17 MB over xGMI, off the timed path
+    if args.dist_backend == "gloo" and world > 1:          # rehearsal: gloo moves host tensors
+        host = blob_t.cpu()
+        mdist.broadcast_blob(host, 0)
+        blob_t.copy_(host)
+    else:
+        mdist.broadcast_blob(blob_t, 0)        # the one collective of the path: ~17 MB over xGMI, off the timed path
     torch.cuda.synchronize()
 
     ctx = pkg.Context(local_rank)
@@ -178,7 +187,7 @@ def main():
         arr = np.asarray(ms, dtype=np.float64).reshape(len(sampled), nsub, n_layers)
         layer_ms = arr.mean(axis=0).sum(axis=0)
 
-    elapsed = mdist.max_over_ranks(elapsed, dev)
+    elapsed = mdist.max_over_ranks(elapsed, "cpu" if args.dist_backend == "gloo" else dev)
 
     logits = d_out.download((args.batch, 1000), np.float32)
     if not np.isfinite(logits).all():
