@@ -126,6 +126,8 @@ int mbn_net_set_dtype(mbn_net *net, int dtype)
                 rc = mbn_convert_f32_to_bf16(net->ctx, net->bf16_filt[i], blob_at(net, l->w_offset), (size_t)l->w_count, NULL);
             if (rc != MBN_OK) return rc;
         }
+        int rc = mbn_sync(net->ctx);     /* the copies are ready before any (possibly free-running) sub-stream reads them */
+        if (rc != MBN_OK) return rc;
     }
     /* kept activations change element size with the dtype: drop them */
     if (dtype != net->dtype) {
