@@ -4,6 +4,8 @@
  *   mobilenet --h5 weights.h5 [--ppm image.ppm] [--batch N] [--res 224] [--alpha 1.0]      fp32 path
  *   mobilenet --synthetic SEED [--alpha A] [--res R] [--batch N]                              fp32, synthetic weights
  *   mobilenet --literal [--weights weights_c.txt] [--image Cat_Image0.ppm] [--ref-args]      the reference's own mode
+ *   mobilenet --inspect weights.h5                                                             list the datasets of a .h5
+ *   mobilenet --convert weights.h5 out.txt                                                     folded blob as text (one %.9g per line)
  *
  * --literal runs the 29 uint8/int32 layers exactly in MobileNet.c's order through the NULL-ext C-ABI calls, with the
  * reference's loaders (readSquezeNetKernel re-reads the same file prefix for every layer, decode_image keeps the PPM
@@ -97,8 +99,49 @@ static int run_literal(mbn_context *ctx, const char *wfile, const char *image, i
     return 0;
 }
 
+static int inspect_cb(const char *path, int ndim, const int64_t *shape, void *user)
+{
+    long *total = (long *)user, n = 1;
+    printf("%-56s (", path);
+    for (int i = 0; i < ndim; i++) { printf(i ? ", %lld" : "%lld", (long long)shape[i]); n *= (long)shape[i]; }
+    printf(")\n");
+    *total += n;
+    return 0;
+}
+
+/* Weight-format tooling (no GPU needed): what keras.py:1-8 was meant to do, done by parsing the HDF5 file. */
+static int inspect_h5(const char *path)
+{
+    mbn_h5 *h5 = NULL;
+    int rc = mbn_h5_open(path, &h5);
+    if (rc != MBN_OK) { fprintf(stderr, "Error: %s: %s\n", path, mbn_strerror(rc)); return 1; }
+    long total = 0;
+    rc = mbn_h5_visit(h5, inspect_cb, &total);
+    mbn_h5_close(h5);
+    if (rc != MBN_OK) { fprintf(stderr, "Error: walking %s: %s\n", path, mbn_strerror(rc)); return 1; }
+    printf("%ld float32 parameters\n", total);
+    return 0;
+}
+
+static int convert_h5(const char *path, const char *out)
+{
+    mbn_weights w;
+    int rc = mbn_weights_from_h5(path, 0.f, 224, &w);
+    if (rc != MBN_OK) { fprintf(stderr, "Error: %s: %s\n", path, mbn_strerror(rc)); return 1; }
+    FILE *fp = fopen(out, "w");
+    if (!fp) { mbn_weights_free(&w); return 1; }
+    fprintf(fp, "# mbn folded blob: alpha %g classes %d floats %lld\n", w.plan.alpha, w.plan.classes, (long long)w.plan.blob_floats);
+    for (int64_t i = 0; i < w.plan.blob_floats; i++) fprintf(fp, "%.9g\n", w.blob[i]);
+    fclose(fp);
+    printf("alpha %g, %d classes, %lld floats -> %s\n", w.plan.alpha, w.plan.classes, (long long)w.plan.blob_floats, out);
+    mbn_weights_free(&w);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
+    if (argc == 3 && !strcmp(argv[1], "--inspect")) return inspect_h5(argv[2]);
+    if (argc == 4 && !strcmp(argv[1], "--convert")) return convert_h5(argv[2], argv[3]);
     const char *h5 = NULL, *ppm = NULL, *wfile = "weights_c.txt", *image = "Cat_Image0.ppm";
     int literal = 0, ref_args = 0, batch = 1, res = 224, have_seed = 0;
     unsigned long long seed = 0;

@@ -429,3 +429,27 @@ def test_synthetic_weights_go_through_the_real_loader(pkg, tmp_path):
     _, g = h5_get(lib, path, "/conv_pw_13_bn/conv_pw_13_bn/gamma:0")
     assert 0.5 <= g.min() and g.max() <= 1.5
     hw.free()
+
+
+def test_c_host_weight_tooling_cli(pkg, tmp_path):
+    """`mobilenet --inspect / --convert`: the weight-format tooling of the C host runs without a GPU."""
+    import subprocess
+    exe = os.path.join(pkg.PKG_DIR, "mobilenet")
+    h5 = os.path.join(GOLD, "keras_like_earliest.h5")
+    r = subprocess.run([exe, "--inspect", h5], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "/conv_preds/conv_preds/bias:0" in r.stdout and "(3, 3, 3, 4)" in r.stdout
+    assert r.stdout.strip().endswith("61506 float32 parameters")       # raw Keras count at alpha 0.125, 10 classes
+    out = str(tmp_path / "blob.txt")
+    r = subprocess.run([exe, "--convert", h5, out], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0
+    hw = pkg.HostWeights(h5, res=224)
+    vals = np.loadtxt(out, dtype=np.float32, comments="#")
+    assert vals.shape == (hw.plan.blob_floats,) and np.array_equal(vals, hw.blob)    # %.9g round-trips fp32 exactly
+    # the text form is what the checked text loader reads back
+    back = np.zeros(100, np.float32)
+    lines = [l for l in open(out) if not l.startswith("#")]
+    (tmp_path / "w.txt").write_text("".join(lines))
+    assert pkg.host_lib().mbn_read_text_weights_f32(str(tmp_path / "w.txt").encode(), back.ctypes.data, 100, 27 * 4) == 0
+    assert np.array_equal(back, hw.blob[27 * 4:27 * 4 + 100])
+    hw.free()
+    assert subprocess.run([exe, "--inspect", "/nonexistent.h5"], capture_output=True).returncode == 1

@@ -644,3 +644,32 @@ def test_net_graph_replay_equals_eager(pkg, ctx, tmp_path):
     ctx.sync()
     assert np.array_equal(d_out.download((4, 30), np.float32), got_b)
     net.destroy()
+
+
+def test_net_full_size_batch1_every_layer(pkg, orc, ctx, tmp_path):
+    """BASELINE config 2 verbatim: full MobileNet-V1 1.0x224 fp32, batch 1, on one MI355X — per-layer numerics of all
+    29 layers (and the softmax tail) against the CPU oracle, each GPU layer fed by the GPU's own previous layer."""
+    hw, net = _make_net(pkg, ctx, tmp_path, 1.0, 224, 1000, 1)
+    imgs = np.random.default_rng(21).uniform(-1, 1, (1, 224, 224, 3)).astype(np.float32)
+    net.keep_activations(True)
+    d_in, d_out = ctx.to_device(imgs), ctx.alloc(4000)
+    net.forward(d_in.ptr, d_out.ptr, 1)
+    ctx.sync()
+    logits = d_out.download((1, 1, 1, 1000), np.float32)
+    oplan = orc.plan_build(1.0, 224, 1000)
+    prev = imgs
+    for i in range(29):
+        got = logits if i == 28 else net.layer_output(i + 1, 1)
+        want = _oracle_layer(orc, oplan, hw.blob, i, prev, False)
+        tol = TOL_PW if oplan.layer[i].kind in (orc.L_PW, orc.L_FC) else TOL_DW
+        assert_close(got, want, tol, "1.0x224 batch-1 layer %d" % (i + 1))
+        prev = got
+    full, _ = orc.net_forward(oplan, hw.blob, imgs, threads=orc.num_threads())
+    assert_close(logits, full, TOL_NET, "1.0x224 batch-1 logits")
+    d_p, d_a = ctx.alloc(4000), ctx.alloc(4)
+    assert ctx.lib.mbn_softmax_f32(ctx.h, d_p.ptr, d_a.ptr, d_out.ptr, 1, 1000, None) == 0
+    ctx.sync()
+    p_want, a_want = orc.f32_softmax(full.reshape(1, 1000))
+    assert d_a.download((1,), np.int32)[0] == a_want[0]
+    assert_close(d_p.download((1, 1000), np.float32), p_want, 1e-3, "softmax of the logits")
+    net.destroy()
