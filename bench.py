@@ -49,6 +49,16 @@ def layer_work(l, batch, pkg, act_bytes=4.0):
     return flops, in_b + out_b + w
 
 
+def layer_weight_bytes(l, pkg, act_bytes=4.0):
+    if l.kind == pkg.L_CONV:
+        return 4.0 * 27 * l.out_ch
+    if l.kind == pkg.L_DW:
+        return 4.0 * 9 * l.out_ch
+    if l.kind in (pkg.L_PW, pkg.L_FC):
+        return act_bytes * l.in_ch * l.out_ch
+    return 0.0
+
+
 def load_traffic():
     """HBM bytes per launch of the dominant kernel from the PMC counters (FETCH_SIZE x2 on gfx950 + WRITE_SIZE), measured
     in separate rocprofv3 --pmc passes of this same workload (tools/pmc_pass.sh) and committed under profiles/.
@@ -75,6 +85,7 @@ def main():
     ap.add_argument("--device-override", type=int, default=-1, help="rehearsal only: every rank uses this device")
     ap.add_argument("--graph", action="store_true", help="replay each step as one hipGraph (mbn_net_set_graph)")
     ap.add_argument("--tune", action="append", default=[], help="key=value passed to mbn_tune_set (experiments)")
+    ap.add_argument("--no-fuse-stem", action="store_true", help="run layers 1-3 as three launches instead of mbn_stem_fused")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=0, help="images in the CPU baseline sample (0 = auto)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the CPU baseline (cap; box share is 16)")
@@ -130,6 +141,8 @@ def main():
 
     ctx = pkg.Context(local_rank)
     net = pkg.Net(ctx, plan, blob_t.data_ptr(), args.batch)
+    if args.no_fuse_stem:
+        net.set_fuse_stem(False)
     if args.graph:
         net.set_graph(True)
     if args.streams > 1:
@@ -161,7 +174,12 @@ def main():
     every = max(1, args.profile_every)
     sampled = [s for s in range(args.steps) if s % every == every // 2] or [0]
     nsub = args.streams if (args.streams > 1 and args.batch >= args.streams) else 1
-    calls_per_step = n_layers * nsub            # with sub-batch streams every layer is launched once per sub-batch
+    # launches of one sub-batch pass, in order: the fused stem (layers 1-3 in one kernel, mbn_stem_fused) when the net
+    # uses it, then one launch per remaining layer
+    n_fused = 0 if (args.graph or bf16) else net.fused_layers(0)
+    launches = ([list(range(n_fused))] if n_fused else []) + [[i] for i in range(n_fused, n_layers)]
+    n_launch = len(launches)
+    calls_per_step = n_launch * nsub            # with sub-batch streams every launch is issued once per sub-batch
     if profile:
         ctx.profile_begin(calls_per_step * len(sampled))
         ctx.profile_pause(True)
@@ -184,7 +202,7 @@ def main():
         ms = ctx.profile_end(calls_per_step * len(sampled))
         # launch order inside a step is stream-major: [sub-batch 0: layers 1..29][sub-batch 1: ...]; a layer's time is the
         # SUM over its sub-batch launches (they overlap other streams' kernels, so this is conservative for GB/s, TFLOP/s)
-        arr = np.asarray(ms, dtype=np.float64).reshape(len(sampled), nsub, n_layers)
+        arr = np.asarray(ms, dtype=np.float64).reshape(len(sampled), nsub, n_launch)
         layer_ms = arr.mean(axis=0).sum(axis=0)
 
     elapsed = mdist.max_over_ranks(elapsed, "cpu" if args.dist_backend == "gloo" else dev)
@@ -217,33 +235,45 @@ def main():
                        "streams": args.streams, "device": ctx.name()},
         }
         if layer_ms is not None:
-            groups = {"conv1": [pkg.L_CONV], "depthwise": [pkg.L_DW], "pointwise": [pkg.L_PW], "pool": [pkg.L_POOL],
-                      "fc": [pkg.L_FC]}
-            stages, per_layer = {}, []
-            for i in range(n_layers):
-                l = plan.layer[i]
-                f, b = layer_work(l, args.batch, pkg, act_bytes)
-                per_layer.append({"layer": i + 1, "kind": int(l.kind), "ms": round(float(layer_ms[i]), 5),
-                                  "GBps": round(b / layer_ms[i] / 1e6, 1), "TFLOPs": round(f / layer_ms[i] / 1e9, 2)})
-            for name, kinds in groups.items():
-                idx = [i for i in range(n_layers) if plan.layer[i].kind in kinds]
+            def launch_work(idx):
+                """Algorithmic work of one launch: FLOPs of every layer in it; bytes = first layer's input + last layer's
+                output + every layer's weights (the fused stem's intermediates never reach HBM)."""
                 fl = sum(layer_work(plan.layer[i], args.batch, pkg, act_bytes)[0] for i in idx)
-                by = sum(layer_work(plan.layer[i], args.batch, pkg, act_bytes)[1] for i in idx)
-                ms_sum = float(sum(layer_ms[i] for i in idx))
-                st = {"launches": len(idx), "ms": round(ms_sum, 4), "GBps": round(by / ms_sum / 1e6, 1),
+                first, last = plan.layer[idx[0]], plan.layer[idx[-1]]
+                by = sum(layer_weight_bytes(plan.layer[i], pkg, act_bytes) for i in idx)
+                by += (4.0 if first.kind == pkg.L_CONV else act_bytes) * first.in_rows * first.in_cols * first.in_ch * args.batch
+                by += (4.0 if last.kind == pkg.L_FC else act_bytes) * last.out_rows * last.out_cols * last.out_ch * args.batch
+                return fl, by
+            kind_name = {pkg.L_CONV: "conv1", pkg.L_DW: "depthwise", pkg.L_PW: "pointwise", pkg.L_POOL: "pool", pkg.L_FC: "fc"}
+            stage_of = ["stem_fused" if len(idx) > 1 else kind_name[plan.layer[idx[0]].kind] for idx in launches]
+            stages, per_layer = {}, []
+            for j, idx in enumerate(launches):
+                f, b = launch_work(idx)
+                per_layer.append({"layers": [i + 1 for i in idx], "stage": stage_of[j], "ms": round(float(layer_ms[j]), 5),
+                                  "GBps": round(b / layer_ms[j] / 1e6, 1), "TFLOPs": round(f / layer_ms[j] / 1e9, 2)})
+            for name in ["stem_fused", "conv1", "depthwise", "pointwise", "pool", "fc"]:
+                js = [j for j in range(n_launch) if stage_of[j] == name]
+                if not js:
+                    continue
+                fl = sum(launch_work(launches[j])[0] for j in js)
+                by = sum(launch_work(launches[j])[1] for j in js)
+                ms_sum = float(sum(layer_ms[j] for j in js))
+                st = {"launches": len(js), "ms": round(ms_sum, 4), "GBps": round(by / ms_sum / 1e6, 1),
                       "TFLOPs": round(fl / ms_sum / 1e9, 2)}
                 st["frac_hbm"] = round(st["GBps"] / HBM_PEAK_GBS, 4)
                 st["frac_mfma"] = round(st["TFLOPs"] / mfma_peak, 4)
                 stages[name] = st
+            if n_fused:
+                stages["stem_fused"]["layers"] = "1-%d (conv1 + depthwise + pointwise in one kernel)" % n_fused
             pw = stages["pointwise"]
-            pw_idx = [i for i in range(n_layers) if plan.layer[i].kind == pkg.L_PW]
+            pw_idx = [launches[j][0] for j in range(n_launch) if stage_of[j] == "pointwise"]
             out["launches_per_layer"] = nsub
             flops_per_launch = sum(layer_work(plan.layer[i], args.batch, pkg, act_bytes)[0] for i in pw_idx) / len(pw_idx)
             bytes_per_launch = sum(layer_work(plan.layer[i], args.batch, pkg, act_bytes)[1] for i in pw_idx) / len(pw_idx)
             avg_ms = pw["ms"] / len(pw_idx)           # per LAYER (= per launch when --streams 1)
             if bf16:       # ridge ~312 flop/B: every pointwise layer is HBM-bound in bf16 (SURVEY §7)
                 out["roofline"] = {
-                    "kernel": "pw_gemm<bf16> (13 pointwise 1x1 conv launches per step)",
+                    "kernel": "pw_gemm<bf16> (%d pointwise 1x1 conv launches per step)" % len(pw_idx),
                     "bound": "hbm", "achieved": round(bytes_per_launch / avg_ms / 1e6, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(bytes_per_launch / avg_ms / 1e6 / HBM_PEAK_GBS, 4),
                     "traffic": None, "avg_launch_ms": round(avg_ms, 5),
@@ -251,7 +281,7 @@ def main():
                 }
             else:
                 out["roofline"] = {
-                    "kernel": "pw_gemm<float> (13 pointwise 1x1 conv launches per step)",
+                    "kernel": "pw_gemm<float> (%d pointwise 1x1 conv launches per step)" % len(pw_idx),
                     "bound": "mfma", "achieved": round(flops_per_launch / avg_ms / 1e9, 2), "peak": MFMA_F32_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(flops_per_launch / avg_ms / 1e9 / MFMA_F32_PEAK_TFLOPS, 4),
                     "traffic": load_traffic(), "avg_launch_ms": round(avg_ms, 5),

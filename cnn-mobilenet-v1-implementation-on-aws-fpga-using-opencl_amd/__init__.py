@@ -153,6 +153,9 @@ def load():
         lib.mbn_net_set_streams.argtypes = [vp, ci]
         lib.mbn_net_set_free_running.argtypes = [vp, ci]
         lib.mbn_net_set_graph.argtypes = [vp, ci]
+        lib.mbn_net_set_fuse_stem.argtypes = [vp, ci]
+        lib.mbn_net_fused_layers.argtypes = [vp, ci, C.POINTER(ci)]
+        lib.mbn_stem_fused.argtypes = [vp] + [vp] * 11 + [ci, ci, ci, ci, vp]
         lib.mbn_graph_begin.argtypes = [vp, vp]
         lib.mbn_graph_end.argtypes = [vp, vp, C.POINTER(vp)]
         lib.mbn_graph_launch.argtypes = [vp, vp, vp]
@@ -376,6 +379,14 @@ class Net:
     def set_streams(self, n, free_running=False):
         _chk(self.ctx.lib.mbn_net_set_streams(self.h, n), self.ctx.last_error())
         _chk(self.ctx.lib.mbn_net_set_free_running(self.h, int(free_running)))
+
+    def set_fuse_stem(self, enabled=True):
+        _chk(self.ctx.lib.mbn_net_set_fuse_stem(self.h, int(enabled)))
+
+    def fused_layers(self, last_layer=0) -> int:
+        n = C.c_int()
+        _chk(self.ctx.lib.mbn_net_fused_layers(self.h, last_layer, C.byref(n)))
+        return n.value
 
     def set_graph(self, enabled=True):
         _chk(self.ctx.lib.mbn_net_set_graph(self.h, int(enabled)), self.ctx.last_error())

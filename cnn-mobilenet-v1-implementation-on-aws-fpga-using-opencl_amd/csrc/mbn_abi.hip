@@ -486,6 +486,20 @@ int mbn_softmax_f32(mbn_context *ctx, void *probs, void *argmax_i32, const void 
                                             classes));
 }
 
+int mbn_stem_fused(mbn_context *ctx, void *out, const void *image, const void *w1, const void *s1, const void *b1,
+                   const void *wd, const void *s2, const void *b2, const void *wp, const void *s3, const void *b3,
+                   int batch, int res, int c1, int c3, void *stream)
+{
+    if (!ctx || !out || !image) return MBN_EINVAL;
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    // decide before opening the profiling scope so an unsupported shape does not consume an event slot
+    if (c1 != 32 || c3 != 64 || res < 32 || (res % 32) != 0 || batch <= 0) return MBN_EUNSUPPORTED;
+    Scope sc(ctx, s);
+    return sc.finish(mbn_launch_f32_stem(ctx, s, (float *)out, (const float *)image, (const float *)w1, (const float *)s1,
+                                         (const float *)b1, (const float *)wd, (const float *)s2, (const float *)b2,
+                                         (const float *)wp, (const float *)s3, (const float *)b3, batch, res, c1, c3));
+}
+
 int mbn_convert_f32_to_bf16(mbn_context *ctx, void *dst_bf16, const void *src_f32, size_t count, void *stream)
 {
     if (!ctx || !dst_bf16 || !src_f32) return MBN_EINVAL;

@@ -1,0 +1,242 @@
+// mbn_f32_stem.hip — fused "stem" of MobileNet-V1 for gfx950, fp32: layers 1-3 of the reference's sequence in ONE
+// kernel (MobileNet.c:240-498: convolute 3x3x3 s2 -> depthwise 3x3 s1 -> pointwise 1x1), each with its folded-BN
+// scale/shift and ReLU6. SURVEY.md §8f ranks the fused depthwise->pointwise block first among the "next" items; the
+// stem is where it pays most: the three layers are all HBM-bound (AI 9.8 / 2.2 / 10.7 flop/B) and unfused they move
+// 154+411, 411+411 and 411+822 MB per 256 images; fused, the 112x112x32 intermediates never leave the CU:
+// read 154 MB, write 822 MB.
+//
+// One workgroup = one tile of 8 x 16 output pixels (= 128 rows of the pointwise GEMM), persistent over tiles:
+//   A. input patch 21 x 37 x 3 floats (stride-2 footprint of the 10 x 18 conv1 halo region) -> LDS, coalesced rows,
+//      zero outside the image (TF-SAME bottom/right pad of conv1);
+//   B. conv1 + BN + ReLU6 for the 10 x 18 region -> LDS [pixel][32]; pixels outside the 112 x 112 map are written as
+//      ZERO (they are the depthwise layer's zero padding, not conv outputs); a lane computes 4 channels of 2 adjacent
+//      pixels so each LDS weight float4 feeds 8 FMAs;
+//   C. depthwise 3x3 + BN + ReLU6 for the 8 x 16 tile -> LDS as the pointwise GEMM's A tile [128][32], 16-byte chunks
+//      XOR-swizzled exactly like mbn_f32_pw.hip (conflict-free ds_read_b128 for the MFMA fragments);
+//   D. pointwise 32 -> 64 on v_mfma_f32_32x32x2_f32 (wave w owns rows 32w..32w+31, all 64 columns) + BN + ReLU6,
+//      stored as whole 128-byte lines.
+// The three filters and their scale/shift vectors stay in LDS / registers for the workgroup's lifetime.
+// Shapes: Cin 3, conv1 -> 32 channels, pointwise -> 64 channels (alpha = 1), input side a multiple of 32.
+#include "mbn_internal.h"
+
+namespace {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+constexpr int TH = 8, TW = 16;                 // output tile (pixels of the 112x112 map)
+constexpr int CR = TH + 2, CC = TW + 2;        // conv1 region incl. the depthwise halo: 10 x 18
+constexpr int PR = 2 * CR + 1, PC = 2 * CC + 1;   // input patch: 21 x 37 pixels
+constexpr int PROW = 112;                      // floats per patch row in LDS (37*3 = 111, padded)
+constexpr int C1 = 32, C3 = 64;
+
+struct StemArgs {
+    float *out;
+    const float *in, *w1, *s1, *b1, *wd, *s2, *b2, *wp, *s3, *b3;
+    int batch, res, h;          // input side, conv1/dw/pw side (res/2)
+    int tiles_y, tiles_x;
+    long ntiles;
+};
+
+__device__ __forceinline__ int swz(int row, int chunk) { return (row << 5) + (((chunk ^ (row >> 1)) & 7) << 2); }
+__device__ __forceinline__ float relu6(float v) { return fminf(fmaxf(v, 0.f), 6.f); }
+__device__ __forceinline__ f4 bn_relu6(f4 a, f4 s, f4 b)
+{
+    return f4{ relu6(fmaf(a.x, s.x, b.x)), relu6(fmaf(a.y, s.y, b.y)), relu6(fmaf(a.z, s.z, b.z)), relu6(fmaf(a.w, s.w, b.w)) };
+}
+// acc += x * w on four channels: one fused multiply-add per channel (same rounding as the unfused kernels' fmaf), written
+// on vectors so the compiler can pair channels into v_pk_fma_f32
+__device__ __forceinline__ f4 fma4(float x, f4 w, f4 acc) { return __builtin_elementwise_fma(f4{ x, x, x, x }, w, acc); }
+__device__ __forceinline__ f4 fma4v(f4 x, f4 w, f4 acc) { return __builtin_elementwise_fma(x, w, acc); }
+
+constexpr int PAIRS = PROW / 2;                // float2 per patch row (56)
+constexpr int NPF = (PR * PAIRS + 255) / 256;  // float2 prefetch registers per lane (5)
+
+// Phase A, first half: this lane's float2 pieces of tile t's input patch (rows 16ty-2 .. 16ty+18, floats 96tx-6 ..
+// 96tx+105 of each row), zero outside the image. Pair boundaries never straddle the image edge (96tx-6 and 3*res even).
+__device__ __forceinline__ void patch_load(const StemArgs &a, long t, int tid, f2 (&pf)[NPF])
+{
+    const int tx = (int)(t % a.tiles_x);
+    const long q0 = t / a.tiles_x;
+    const int ty = (int)(q0 % a.tiles_y);
+    const long n = q0 / a.tiles_y;
+    const float *img = a.in + n * a.res * a.res * 3;
+    const int iy0 = 2 * (TH * ty - 1), fx0 = 6 * (TW * tx - 1), rowf = a.res * 3;
+#pragma unroll
+    for (int k = 0; k < NPF; k++) {
+        const int i = tid + k * 256, r = i / PAIRS, j = i % PAIRS;
+        const int iy = iy0 + r, fx = fx0 + 2 * j;
+        f2 v = f2{ 0.f, 0.f };
+        if (i < PR * PAIRS && iy >= 0 && iy < a.res && fx >= 0 && fx < rowf)
+            v = *reinterpret_cast<const f2 *>(img + (long)iy * rowf + fx);
+        pf[k] = v;
+    }
+}
+__device__ __forceinline__ void patch_store(float *in_s, int tid, const f2 (&pf)[NPF])
+{
+#pragma unroll
+    for (int k = 0; k < NPF; k++) {
+        const int i = tid + k * 256;
+        if (i < PR * PAIRS) *reinterpret_cast<f2 *>(in_s + 2 * i) = pf[k];      // row r, pair j -> r*PROW + 2j = 2i
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void stem_fused_f32(StemArgs a)   // 2 waves/SIMD: two workgroups per CU
+{
+    __shared__ __attribute__((aligned(16))) float in_s[PR * PROW];        //  9.4 KB
+    __shared__ __attribute__((aligned(16))) float w1_s[27 * C1];          //  3.4 KB
+    __shared__ __attribute__((aligned(16))) float c1_s[CR * CC * C1];     // 22.5 KB
+    __shared__ __attribute__((aligned(16))) float a_s[TH * TW * 32];      // 16 KB
+    __shared__ __attribute__((aligned(16))) float b_s[C3 * 32];           //  8 KB
+    __shared__ __attribute__((aligned(16))) float sb_s[4 * C1];           // s1 | b1 | s2 | b2
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int c4 = tid & 7;                                               // this lane's channel quad in phases B, C
+
+    // ---- per-workgroup constants
+    for (int i = tid * 4; i < 27 * C1; i += 1024) *reinterpret_cast<f4 *>(w1_s + i) = *reinterpret_cast<const f4 *>(a.w1 + i);
+    for (int i = tid; i < C3 * 8; i += 256) {                             // pointwise filter [64][32] -> swizzled B tile
+        const int row = i >> 3, ch = i & 7;
+        *reinterpret_cast<f4 *>(b_s + swz(row, ch)) = *reinterpret_cast<const f4 *>(a.wp + row * 32 + ch * 4);
+    }
+    if (tid < 4 * C1) {
+        const float *src = tid < C1 ? a.s1 : tid < 2 * C1 ? a.b1 : tid < 3 * C1 ? a.s2 : a.b2;
+        sb_s[tid] = src[tid & (C1 - 1)];
+    }
+    f4 wd[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) wd[k] = *reinterpret_cast<const f4 *>(a.wd + k * C1 + c4 * 4);
+    float s3[2], b3[2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ni++) { s3[ni] = a.s3[ni * 32 + li]; b3[ni] = a.b3[ni * 32 + li]; }
+
+    f2 pf[NPF];
+    if ((long)blockIdx.x < a.ntiles) {
+        patch_load(a, blockIdx.x, tid, pf);
+        patch_store(in_s, tid, pf);
+    }
+    __syncthreads();
+
+    // phase B item of this lane: conv1 row br, pixels bc .. bc+5 (lanes 240..255 have none)
+    const int bpg = tid >> 3, br = bpg / 3, bc = (bpg % 3) * 6;
+    // phase C item: tile row cy, pixels cx .. cx+3
+    const int cy = tid >> 5, cx = ((tid >> 3) & 3) * 4;
+
+    for (long t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
+        const int tx = (int)(t % a.tiles_x);
+        const long q0 = t / a.tiles_x;
+        const int ty = (int)(q0 % a.tiles_y);
+        const long n = q0 / a.tiles_y;
+        const long tnext = t + gridDim.x;
+        if (tnext < a.ntiles) patch_load(a, tnext, tid, pf);              // in flight while phase B computes
+
+        // ---- B. conv1 (3x3x3, stride 2, pad 0 top/left) + BN + ReLU6 over the 10 x 18 region, 6 pixels x 4 ch per lane
+        if (bpg < CR * 3) {
+            f4 acc[6];
+#pragma unroll
+            for (int p = 0; p < 6; p++) acc[p] = f4{ 0.f, 0.f, 0.f, 0.f };
+#pragma unroll 1
+            for (int ky = 0; ky < 3; ky++) {                              // not unrolled: keeps the live set small
+                const float *row = in_s + (2 * br + ky) * PROW + (2 * bc) * 3;    // 13 pixels x 3 channels (+1 pad float)
+                f4 xv[10];
+#pragma unroll
+                for (int j = 0; j < 10; j++) xv[j] = *reinterpret_cast<const f4 *>(row + 4 * j);
+                const float *x = reinterpret_cast<const float *>(xv);
+#pragma unroll
+                for (int kx = 0; kx < 3; kx++)
+#pragma unroll
+                    for (int ci = 0; ci < 3; ci++) {
+                        const f4 w = *reinterpret_cast<const f4 *>(w1_s + ((ky * 3 + kx) * 3 + ci) * C1 + c4 * 4);
+#pragma unroll
+                        for (int p = 0; p < 6; p++) acc[p] = fma4(x[(2 * p + kx) * 3 + ci], w, acc[p]);
+                    }
+            }
+            const int oy = TH * ty - 1 + br, ox = TW * tx - 1 + bc;      // position in the 112x112 conv1 map
+            const bool rowok = oy >= 0 && oy < a.h;
+            const f4 s1 = *reinterpret_cast<const f4 *>(sb_s + c4 * 4), b1 = *reinterpret_cast<const f4 *>(sb_s + C1 + c4 * 4);
+#pragma unroll
+            for (int p = 0; p < 6; p++) {                                 // outside the map: the depthwise zero padding
+                const f4 v = (rowok && ox + p >= 0 && ox + p < a.h) ? bn_relu6(acc[p], s1, b1) : f4{ 0.f, 0.f, 0.f, 0.f };
+                *reinterpret_cast<f4 *>(c1_s + (br * CC + bc + p) * C1 + c4 * 4) = v;
+            }
+        }
+        __syncthreads();
+        if (tnext < a.ntiles) patch_store(in_s, tid, pf);                 // in_s was last read in B; next read after 2 barriers
+
+        // ---- C. depthwise 3x3 (stride 1, pad 1) + BN + ReLU6: 4 adjacent pixels x 4 ch per lane -> swizzled A tile
+        {
+            f4 acc[4];
+#pragma unroll
+            for (int p = 0; p < 4; p++) acc[p] = f4{ 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+            for (int dy = 0; dy < 3; dy++) {
+                f4 v[6];
+#pragma unroll
+                for (int j = 0; j < 6; j++) v[j] = *reinterpret_cast<const f4 *>(c1_s + ((cy + dy) * CC + cx + j) * C1 + c4 * 4);
+#pragma unroll
+                for (int dx = 0; dx < 3; dx++)
+#pragma unroll
+                    for (int p = 0; p < 4; p++) acc[p] = fma4v(v[p + dx], wd[dy * 3 + dx], acc[p]);
+            }
+            const f4 s2 = *reinterpret_cast<const f4 *>(sb_s + 2 * C1 + c4 * 4), b2 = *reinterpret_cast<const f4 *>(sb_s + 3 * C1 + c4 * 4);
+#pragma unroll
+            for (int p = 0; p < 4; p++) *reinterpret_cast<f4 *>(a_s + swz(cy * TW + cx + p, c4)) = bn_relu6(acc[p], s2, b2);
+        }
+        __syncthreads();
+
+        // ---- D. pointwise 32 -> 64: wave w computes rows 32w .. 32w+31 x 64 columns
+        f16v acc[2];
+#pragma unroll
+        for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[ni][r] = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const int chunk = 2 * g + lh;
+            const f4 av = *reinterpret_cast<const f4 *>(a_s + swz(wave * 32 + li, chunk));
+            f4 bv[2];
+#pragma unroll
+            for (int ni = 0; ni < 2; ni++) bv[ni] = *reinterpret_cast<const f4 *>(b_s + swz(ni * 32 + li, chunk));
+#pragma unroll
+            for (int s = 0; s < 4; s++)
+#pragma unroll
+                for (int ni = 0; ni < 2; ni++) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[ni][s], acc[ni], 0, 0, 0);
+        }
+        float *obase = a.out + ((n * a.h + TH * ty) * a.h + TW * tx) * C3;
+#pragma unroll
+        for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int q = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int y = q >> 4, x = q & 15;
+                obase[((long)y * a.h + x) * C3 + ni * 32 + li] = relu6(fmaf(acc[ni][r], s3[ni], b3[ni]));
+            }
+        // No barrier here: the next tile's B writes c1_s (last read in C, one barrier ago) and its C writes a_s only after
+        // the barrier that follows B, which every wave reaches after finishing the a_s reads above.
+    }
+}
+
+}   // namespace
+
+// Fused layers 1-3. Returns MBN_EUNSUPPORTED when the shapes are not the alpha = 1 stem (the caller then runs the three
+// layers separately).
+int mbn_launch_f32_stem(mbn_context *ctx, hipStream_t stream, float *out, const float *in, const float *w1,
+                        const float *s1, const float *b1, const float *wd, const float *s2, const float *b2,
+                        const float *wp, const float *s3, const float *b3, int batch, int res, int c1, int c3)
+{
+    if (c1 != C1 || c3 != C3 || res < 32 || (res % 32) != 0 || batch <= 0) return MBN_EUNSUPPORTED;
+    const float *ptrs[] = { w1, s1, b1, wd, s2, b2, wp, s3, b3 };
+    for (const float *p : ptrs)
+        if (!p || ((uintptr_t)p % 16) != 0) return MBN_EUNSUPPORTED;
+    if (!out || !in || ((uintptr_t)out % 16) != 0 || ((uintptr_t)in % 8) != 0) return MBN_EINVAL;
+    StemArgs a;
+    a.out = out; a.in = in; a.w1 = w1; a.s1 = s1; a.b1 = b1; a.wd = wd; a.s2 = s2; a.b2 = b2; a.wp = wp; a.s3 = s3; a.b3 = b3;
+    a.batch = batch; a.res = res; a.h = res / 2;
+    a.tiles_y = a.h / TH; a.tiles_x = a.h / TW;
+    a.ntiles = (long)batch * a.tiles_y * a.tiles_x;
+    long grid = (long)ctx->num_cus * 2;                  // 59.7 KB of LDS per workgroup: two per CU
+    if (grid > a.ntiles) grid = a.ntiles;
+    hipLaunchKernelGGL(stem_fused_f32, dim3((unsigned)grid), dim3(256), 0, stream, a);
+    return MBN_OK;
+}

@@ -23,6 +23,7 @@ struct mbn_net {
     void *act[2];
     int keep;
     int dtype;                 /* MBN_DT_F32 or MBN_DT_BF16 */
+    int fuse_stem;             /* mbn_net_set_fuse_stem (default 1) */
     int use_graph;             /* mbn_net_set_graph */
     void *graph;               /* instantiated hipGraph of one forward, valid for the key below */
     const void *g_images;
@@ -50,6 +51,7 @@ static int net_alloc_common(mbn_context *ctx, const mbn_plan *plan, int max_batc
     net->ctx = ctx;
     net->dtype = MBN_DT_F32;
     net->nstreams = 1;
+    net->fuse_stem = 1;
     net->plan = *plan;
     net->max_batch = max_batch;
     size_t bytes = (size_t)plan->max_act_floats * (size_t)max_batch * sizeof(float);
@@ -151,6 +153,30 @@ int mbn_net_set_streams(mbn_net *net, int n)
     return MBN_OK;
 }
 
+/* layers 1-3 can go through mbn_stem_fused: conv 3x3 s2 -> dw s1 -> pw with 32 -> 32 -> 64 channels, fp32, nothing kept */
+static int stem_fusable(const mbn_net *net, int last_layer)
+{
+    const mbn_layer_desc *l = net->plan.layer;
+    return net->fuse_stem && net->dtype == MBN_DT_F32 && !net->keep && last_layer >= 3 && net->plan.n_layers >= 3 &&
+           l[0].kind == MBN_L_CONV && l[1].kind == MBN_L_DW && l[2].kind == MBN_L_PW && l[0].in_ch == 3 &&
+           l[0].out_ch == 32 && l[1].stride == 1 && l[2].out_ch == 64 && (net->plan.res % 32) == 0;
+}
+
+int mbn_net_set_fuse_stem(mbn_net *net, int enabled)
+{
+    if (!net) return MBN_EINVAL;
+    net->fuse_stem = enabled != 0;
+    return MBN_OK;
+}
+
+int mbn_net_fused_layers(const mbn_net *net, int last_layer, int *count)
+{
+    if (!net || !count) return MBN_EINVAL;
+    if (last_layer <= 0 || last_layer > net->plan.n_layers) last_layer = net->plan.n_layers;
+    *count = stem_fusable(net, last_layer) ? 3 : 0;
+    return MBN_OK;
+}
+
 int mbn_net_set_graph(mbn_net *net, int enabled)
 {
     if (!net) return MBN_EINVAL;
@@ -241,8 +267,28 @@ static int forward_range(mbn_net *net, const void *images, void *logits, int fir
     const size_t img_floats = (size_t)net->plan.res * net->plan.res * 3;
     const char *src = (const char *)images + (size_t)first * img_floats * sizeof(float);
     const size_t slot = (size_t)first * (size_t)net->plan.max_act_floats * sizeof(float);
-    int which = 0;
-    for (int i = 0; i < last_layer; i++) {
+    int which = 0, i0 = 0;
+    if (!layer_ms && stem_fusable(net, last_layer)) {
+        /* layers 1-3 in one kernel; the 112x112x32 intermediates stay on chip */
+        const mbn_layer_desc *l = net->plan.layer;
+        const size_t per_img = (size_t)l[2].out_rows * l[2].out_cols * l[2].out_ch * sizeof(float);
+        char *dst = last_layer == 3 ? (char *)logits + (size_t)first * per_img : (char *)net->act[which] + slot;
+        int rc = mbn_stem_fused(net->ctx, dst, src, blob_at(net, l[0].w_offset), blob_at(net, l[0].scale_offset),
+                                blob_at(net, l[0].shift_offset), blob_at(net, l[1].w_offset), blob_at(net, l[1].scale_offset),
+                                blob_at(net, l[1].shift_offset), blob_at(net, l[2].w_offset), blob_at(net, l[2].scale_offset),
+                                blob_at(net, l[2].shift_offset), count, net->plan.res, l[0].out_ch, l[2].out_ch, stream);
+        if (rc == MBN_OK) {
+            if (last_layer != 3) which ^= 1;
+            if (first == 0) { net->last_out[0] = net->last_out[1] = NULL; net->last_out[2] = dst; }
+            src = dst;
+            i0 = 3;
+            if (next_stream && stagger >= 1 && stagger <= 3) {
+                rc = mbn_stream_wait(net->ctx, next_stream, stream);
+                if (rc != MBN_OK) return rc;
+            }
+        } else if (rc != MBN_EUNSUPPORTED) return rc;
+    }
+    for (int i = i0; i < last_layer; i++) {
         const mbn_layer_desc *l = &net->plan.layer[i];
         const size_t per_img = (size_t)l->out_rows * l->out_cols * l->out_ch * out_esize(net, l);
         char *dst;

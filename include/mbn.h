@@ -204,6 +204,16 @@ int mbn_pointwise(mbn_context *ctx, void *output, const void *inp_image, const v
 int mbn_pool(mbn_context *ctx, void *output, const void *inp_image, int rows, int cols, int filtersize,
              int op_size, const mbn_layer_ext *ext);
 
+/* Fused stem (SURVEY §8f-1 applied to the first block): layers 1-3 of the sequence — convolute 3x3x3 stride 2 ->
+ * depthwise 3x3 stride 1 -> pointwise 1x1, each followed by its folded-BN scale/shift and ReLU6 — in one kernel, so
+ * the two 112x112x32 intermediates never reach HBM (MobileNet.c:240-498 does three launches and six PCIe copies).
+ * fp32 NHWC only; image [batch][res][res][3], out [batch][res/2][res/2][c3]; filters in the layouts of the separate
+ * calls (w1 [3][3][3][c1], wd [3][3][c1], wp [c3][c1]). Returns MBN_EUNSUPPORTED unless c1 = 32, c3 = 64 and res is a
+ * multiple of 32 — callers then issue the three layer calls instead. */
+int mbn_stem_fused(mbn_context *ctx, void *out, const void *image, const void *w1, const void *s1, const void *b1,
+                   const void *wd, const void *s2, const void *b2, const void *wp, const void *s3, const void *b3,
+                   int batch, int res, int c1, int c3, void *stream);
+
 /* Classifier tail on device, fp32 (replaces the host loop MobileNet.c:2771-2792):
  * probs[n][k] = softmax(logits[n][:]) and argmax[n] (0-based). probs or argmax may be NULL. */
 int mbn_softmax_f32(mbn_context *ctx, void *probs, void *argmax_i32, const void *logits, int batch,
@@ -326,6 +336,11 @@ int  mbn_net_set_free_running(mbn_net *net, int enabled);
  * combination is seen and replay it afterwards (re-captured when any of them changes). For launch-bound batches:
  * measured 0.285 -> see DESIGN.md ms per forward at batch 1. Ignored with more than one stream or in timed forwards. */
 int  mbn_net_set_graph(mbn_net *net, int enabled);
+/* 1 (default) = run layers 1-3 through mbn_stem_fused when the plan allows it (fp32, alpha = 1, activations not
+ * kept, at least 3 layers requested); 0 = always issue the 29 separate layer calls. mbn_net_fused_layers reports how
+ * many leading layers the next forward(batch, last_layer) would fuse (0 or 3). */
+int  mbn_net_set_fuse_stem(mbn_net *net, int enabled);
+int  mbn_net_fused_layers(const mbn_net *net, int last_layer, int *count);
 /* images: device fp32 NHWC [batch][res][res][3]; logits: device fp32 [batch][classes]. Asynchronous.
  * last_layer: run layers 1..last_layer only (0 or 29 => all; 5 and 13 = BASELINE configs 1-2), in which
  * case `logits` receives that layer's NHWC activation instead. */

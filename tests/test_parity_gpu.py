@@ -673,3 +673,41 @@ def test_net_full_size_batch1_every_layer(pkg, orc, ctx, tmp_path):
     assert d_a.download((1,), np.int32)[0] == a_want[0]
     assert_close(d_p.download((1, 1000), np.float32), p_want, 1e-3, "softmax of the logits")
     net.destroy()
+
+
+@pytest.mark.parametrize("res,n", [(224, 2), (64, 3), (96, 1)])
+def test_fused_stem_equals_three_layers_and_oracle(pkg, orc, ctx, tmp_path, res, n):
+    """mbn_stem_fused (layers 1-3 in one kernel) vs the three separate layer calls (same fmaf/MFMA order -> expected
+    bit-identical) and vs the oracle's layer-3 activation. Tiles at the image border exercise the zero halo."""
+    hw, net = _make_net(pkg, ctx, tmp_path, 1.0, res, 20, n)
+    imgs = np.random.default_rng(res).uniform(-1, 1, (n, res, res, 3)).astype(np.float32)
+    h = res // 2
+    d_in, d_a, d_b = ctx.to_device(imgs), ctx.alloc(n * h * h * 64 * 4), ctx.alloc(n * h * h * 64 * 4)
+    assert net.fused_layers(3) == 3
+    net.forward(d_in.ptr, d_a.ptr, n, 3)                 # fused
+    net.set_fuse_stem(False)
+    assert net.fused_layers(3) == 0
+    net.forward(d_in.ptr, d_b.ptr, n, 3)                 # conv1, dw2, pw3 as separate launches
+    ctx.sync()
+    fused, unfused = d_a.download((n, h, h, 64), np.float32), d_b.download((n, h, h, 64), np.float32)
+    assert np.array_equal(fused, unfused)
+    want, _ = orc.net_forward(orc.plan_build(1.0, res, 20), hw.blob, imgs, last_layer=3, threads=orc.num_threads())
+    assert_close(fused, want, TOL_PW, "fused stem vs oracle")
+    # whole net with and without the fused stem
+    d_l1, d_l2 = ctx.alloc(n * 20 * 4), ctx.alloc(n * 20 * 4)
+    net.forward(d_in.ptr, d_l2.ptr, n)
+    net.set_fuse_stem(True)
+    net.forward(d_in.ptr, d_l1.ptr, n)
+    ctx.sync()
+    assert np.array_equal(d_l1.download((n, 20), np.float32), d_l2.download((n, 20), np.float32))
+    net.destroy()
+
+
+def test_fused_stem_unsupported_shapes_fall_back(pkg, ctx, tmp_path):
+    """alpha != 1 (conv1 != 32 channels): mbn_stem_fused answers MBN_EUNSUPPORTED and the runner issues the 3 calls."""
+    hw, net = _make_net(pkg, ctx, tmp_path, 0.5, 64, 10, 1)
+    assert net.fused_layers(0) == 0
+    d = ctx.alloc(1 << 20)
+    rc = ctx.lib.mbn_stem_fused(ctx.h, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, 1, 64, 16, 32, None)
+    assert rc == pkg.EUNSUPPORTED
+    net.destroy()
