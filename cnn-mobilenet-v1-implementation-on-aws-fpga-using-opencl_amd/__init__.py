@@ -156,6 +156,7 @@ def load():
         lib.mbn_net_set_fuse_stem.argtypes = [vp, ci]
         lib.mbn_net_fused_layers.argtypes = [vp, ci, C.POINTER(ci)]
         lib.mbn_stem_fused.argtypes = [vp] + [vp] * 11 + [ci, ci, ci, ci, vp]
+        lib.mbn_dwpw_fused.argtypes = [vp] + [vp] * 8 + [ci] * 10 + [vp]
         lib.mbn_graph_begin.argtypes = [vp, vp]
         lib.mbn_graph_end.argtypes = [vp, vp, C.POINTER(vp)]
         lib.mbn_graph_launch.argtypes = [vp, vp, vp]

@@ -500,6 +500,23 @@ int mbn_stem_fused(mbn_context *ctx, void *out, const void *image, const void *w
                                          (const float *)wp, (const float *)s3, (const float *)b3, batch, res, c1, c3));
 }
 
+int mbn_dwpw_fused(mbn_context *ctx, void *out, const void *in, const void *wd, const void *s2, const void *b2,
+                   const void *wp, const void *s3, const void *b3, int batch, int in_rows, int in_cols, int out_rows,
+                   int out_cols, int cin, int cout, int stride, int pad_top, int pad_left, void *stream)
+{
+    if (!ctx) return MBN_EINVAL;
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    // decide before opening the profiling scope so an unsupported shape does not consume an event slot
+    const int rc = mbn_f32_dwpw_check((const float *)out, (const float *)in, (const float *)wd, (const float *)s2,
+                                      (const float *)b2, (const float *)wp, (const float *)s3, (const float *)b3, batch,
+                                      in_rows, in_cols, out_rows, out_cols, cin, cout, stride, pad_top, pad_left);
+    if (rc != MBN_OK) return rc;
+    Scope sc(ctx, s);
+    return sc.finish(mbn_launch_f32_dwpw(ctx, s, (float *)out, (const float *)in, (const float *)wd, (const float *)s2,
+                                         (const float *)b2, (const float *)wp, (const float *)s3, (const float *)b3, batch,
+                                         in_rows, in_cols, out_rows, out_cols, cin, cout, stride, pad_top, pad_left));
+}
+
 int mbn_convert_f32_to_bf16(mbn_context *ctx, void *dst_bf16, const void *src_f32, size_t count, void *stream)
 {
     if (!ctx || !dst_bf16 || !src_f32) return MBN_EINVAL;

@@ -1,0 +1,42 @@
+// mbn_epilogue.h — accumulator -> global store of the 32x32 MFMA tiles, shared by the GEMM-shaped kernels
+// (mbn_f32_pw.hip, mbn_f32_dwpw.hip): out[row][col] = relu6(acc * scale[col] + shift[col]).
+// C/D layout of v_mfma_f32_32x32x2_f32: lane l holds column l&31 and rows (r&3) + 8*(r>>2) + 4*(l>>5), r = 0..15.
+// Stores are buffer stores: the output's descriptor sits in 4 SGPRs, the per-lane byte offset is ONE VGPR that is the
+// same for all 16*MI*NI stores, and each store's wave-uniform part (tile origin + r's row) is its scalar offset. A store
+// then costs fma + clamp + one scalar add — no per-element 64-bit address registers (which cost a whole occupancy step
+// when tried with flat stores) and no bounds branches. The output must be smaller than 4 GiB.
+#pragma once
+
+typedef float mbn_f16v __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t mbn_make_rsrc(const void *base, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
+}
+
+// FULL = true: the MI*32 x NI*32 block lies inside the matrix (no checks). row0/col0 must be wave-uniform.
+template <int MI, int NI, bool FULL>
+__device__ __forceinline__ void mbn_store_relu6_f32(__amdgpu_buffer_rsrc_t out, unsigned ldc, unsigned row0, int col0,
+                                                    int lane, const mbn_f16v (&acc)[MI][NI],
+                                                    const float *__restrict__ scale, const float *__restrict__ shift,
+                                                    unsigned m, int n)
+{
+    const int li = lane & 31, lh = lane >> 5;
+    const unsigned lane_off = ((unsigned)(4 * lh) * ldc + (unsigned)li) * 4u;          // bytes
+#pragma unroll
+    for (int ni = 0; ni < NI; ni++) {
+        const int col = col0 + ni * 32 + li;
+        const bool cok = FULL || col < n;
+        const float sc = scale[cok ? col : n - 1], sh = shift[cok ? col : n - 1];
+#pragma unroll
+        for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const unsigned ro = row0 + mi * 32 + (r & 3) + 8 * (r >> 2);           // + 4*lh per lane
+                const float v = fminf(fmaxf(fmaf(acc[mi][ni][r], sc, sh), 0.f), 6.f);
+                const unsigned soff = (ro * ldc + (unsigned)(col0 + ni * 32)) * 4u;    // wave-uniform bytes
+                if (FULL || (cok && ro + 4 * lh < m))
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), out, lane_off, soff, 0);
+            }
+    }
+}

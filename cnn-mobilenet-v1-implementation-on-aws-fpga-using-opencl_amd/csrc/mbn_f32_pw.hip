@@ -32,11 +32,12 @@
 // resident in LDS, each wave loading 32-row A slices straight into MFMA operand registers, no barriers) was built,
 // parity-checked and measured 25-38 % SLOWER than this tiled kernel on layers 3 and 5, so it is not shipped.
 #include "mbn_internal.h"
+#include "mbn_epilogue.h"
 
 namespace {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
-typedef float f16v __attribute__((ext_vector_type(16)));
+typedef mbn_f16v f16v;
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 
 struct PwArgs {
@@ -47,6 +48,7 @@ struct PwArgs {
     int k, n, act;
     int mt, nt;     // tile counts
     int out_f32;    // bf16 mode: write fp32 (FC logits)
+    int fast_epi;   // 0 = always the general epilogue (A/B hook: tune conv_variant=9)
 };
 
 constexpr int BKB = 128;            // k-tile in BYTES per row (32 fp32 / 64 bf16)
@@ -131,6 +133,9 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void pw_gemm(PwArgs a)
     // at a wave-uniform LDS base + lane*16, so the image stays [row][slot] and the XOR swizzle is applied to the
     // per-lane SOURCE chunk instead (set_tile). No staging VGPRs, no ds_write pass.
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int wm_u = (wave_u / WAVES_N) * WM, wn_u = (wave_u % WAVES_N) * WN;      // wave-uniform copies for the epilogue
+    const bool g_fast_epilogue = a.fast_epi != 0;
+    const __amdgpu_buffer_rsrc_t orsrc = mbn_make_rsrc(a.out, g_fast_epilogue ? (unsigned)(a.m * a.n * 4) : 0u);
     auto stage_glds = [&](int k0, int buf) {
         float *base = lds + buf * (BM + BN) * BKF;
 #pragma unroll
@@ -236,6 +241,12 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void pw_gemm(PwArgs a)
 
         // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
         // One fp32 store instruction writes two 128-B row segments (full cache lines).
+        if (!BF && a.act == MBN_ACT_RELU6 && a.scale && a.shift && cm0 + BM <= a.m && cn0 + BN <= a.n &&
+            g_fast_epilogue) {
+            // interior tile of a BN + ReLU6 layer (every pointwise layer of the network): lean stores, mbn_epilogue.h
+            mbn_store_relu6_f32<MI, NI, true>(orsrc, (unsigned)a.n, (unsigned)cm0 + wm_u, cn0 + wn_u, lane, acc, a.scale,
+                                              a.shift, (unsigned)a.m, a.n);
+        } else
 #pragma unroll
         for (int ni = 0; ni < NI; ni++) {
             const int col = cn0 + wn + ni * 32 + li;
@@ -324,6 +335,7 @@ int mbn_launch_f32_pointwise(const mbn_call &c, void *out, const void *in, const
     a.out = out; a.in = in; a.filt = filt; a.scale = c.scale; a.shift = c.shift;
     a.m = m; a.k = cin; a.n = op_size; a.act = c.act; a.mt = a.nt = 0;
     a.out_f32 = bf && (c.io_flags & MBN_IO_OUT_F32) ? 1 : 0;
+    a.fast_epi = (g_mbn_tune.conv_variant == 9 || (double)m * op_size * 4.0 >= 4294967296.0) ? 0 : 1;   // buffer stores: < 4 GiB
     if (m <= 0 || (long)((m + 31) / 32) * ((op_size + 31) / 32) > 0x7fffffffL) return MBN_EINVAL;
     const int epc = bf ? 8 : 4;
     const bool fast = (cin % epc) == 0 && ((uintptr_t)in % 16) == 0 && ((uintptr_t)filt % 16) == 0;

@@ -27,7 +27,7 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 
 constexpr int TH = 8, TW = 16;                 // output tile (pixels of the 112x112 map)
 constexpr int CR = TH + 2, CC = TW + 2;        // conv1 region incl. the depthwise halo: 10 x 18
-constexpr int PR = 2 * CR + 1, PC = 2 * CC + 1;   // input patch: 21 x 37 pixels
+constexpr int PR = 2 * CR + 1;                     // input patch: 21 rows x 37 pixels
 constexpr int PROW = 112;                      // floats per patch row in LDS (37*3 = 111, padded)
 constexpr int C1 = 32, C3 = 64;
 

@@ -89,6 +89,13 @@ int mbn_launch_f32_depthwise(const mbn_call &c, void *out, const void *in, const
 int mbn_launch_f32_pointwise(const mbn_call &c, void *out, const void *in, const void *filt, long m, int cin,
                              int op_size);
 int mbn_launch_f32_pool(const mbn_call &c, void *out, const void *in, int rows, int cols, int fs, int channels);
+int mbn_f32_dwpw_check(const float *out, const float *in, const float *wd, const float *s2, const float *b2,
+                       const float *wp, const float *s3, const float *b3, int batch, int in_rows, int in_cols,
+                       int out_rows, int out_cols, int cin, int cout, int stride, int pad_top, int pad_left);
+int mbn_launch_f32_dwpw(mbn_context *ctx, hipStream_t stream, float *out, const float *in, const float *wd,
+                        const float *s2, const float *b2, const float *wp, const float *s3, const float *b3, int batch,
+                        int in_rows, int in_cols, int out_rows, int out_cols, int cin, int cout, int stride, int pad_top,
+                        int pad_left);
 int mbn_launch_f32_stem(mbn_context *ctx, hipStream_t stream, float *out, const float *in, const float *w1,
                         const float *s1, const float *b1, const float *wd, const float *s2, const float *b2,
                         const float *wp, const float *s3, const float *b3, int batch, int res, int c1, int c3);

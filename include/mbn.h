@@ -214,6 +214,17 @@ int mbn_stem_fused(mbn_context *ctx, void *out, const void *image, const void *w
                    const void *wd, const void *s2, const void *b2, const void *wp, const void *s3, const void *b3,
                    int batch, int res, int c1, int c3, void *stream);
 
+/* Fused block: a depthwise 3x3 (stride 1 or 2) + pointwise 1x1 pair of the sequence (the pairs L4-5 ...
+ * L26-27, MobileNet.c:322-2599; kernel.cl:62-92 + 94-114) in one kernel, each stage followed by its folded-BN
+ * scale/shift and ReLU6; the depthwise output never reaches HBM. fp32 NHWC: in [batch][in_rows][in_cols][cin],
+ * out [batch][out_rows][out_cols][cout]; wd [3][3][cin], wp [cout][cin] as in the separate calls; pad_top/pad_left as in
+ * mbn_layer_ext (zero padding; the high side needs none stated). Bit-identical to mbn_depthwise followed by
+ * mbn_pointwise. Returns MBN_EUNSUPPORTED unless cin is a multiple of 32 and <= 256, cout a multiple of 128, out_cols
+ * even and the input under 3.75 GiB — callers then issue the two layer calls instead. */
+int mbn_dwpw_fused(mbn_context *ctx, void *out, const void *in, const void *wd, const void *s2, const void *b2,
+                   const void *wp, const void *s3, const void *b3, int batch, int in_rows, int in_cols, int out_rows,
+                   int out_cols, int cin, int cout, int stride, int pad_top, int pad_left, void *stream);
+
 /* Classifier tail on device, fp32 (replaces the host loop MobileNet.c:2771-2792):
  * probs[n][k] = softmax(logits[n][:]) and argmax[n] (0-based). probs or argmax may be NULL. */
 int mbn_softmax_f32(mbn_context *ctx, void *probs, void *argmax_i32, const void *logits, int batch,

@@ -711,3 +711,55 @@ def test_fused_stem_unsupported_shapes_fall_back(pkg, ctx, tmp_path):
     rc = ctx.lib.mbn_stem_fused(ctx.h, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, 1, 64, 16, 32, None)
     assert rc == pkg.EUNSUPPORTED
     net.destroy()
+
+
+# =========================================================================== fused depthwise -> pointwise block (§8f-1)
+
+DWPW_SHAPES = [  # (batch, in side, Cin, Cout, stride)
+    (2, 112, 64, 128, 2), (2, 56, 128, 128, 1), (2, 56, 128, 256, 2), (2, 28, 256, 256, 1),    # L4-5, L6-7, L8-9, L10-11
+    (1, 28, 256, 512, 2),                                  # L12-13: two 256-column tiles, depthwise recomputed
+    (3, 14, 32, 128, 1), (1, 6, 64, 384, 1), (5, 12, 96, 128, 2), (1, 2, 32, 256, 1),          # ragged M, 3 n-tiles, tiny maps
+]
+
+
+@pytest.mark.parametrize("shape", DWPW_SHAPES)
+def test_f32_dwpw_fused(pkg, orc, ctx, shape):
+    """mbn_dwpw_fused vs mbn_depthwise + mbn_pointwise (same arithmetic order -> bit-identical) and vs the oracle."""
+    n, h, cin, cout, stride = shape
+    rng = np.random.default_rng(h * 11 + cin + cout + stride)
+    x = rng.uniform(-1, 1, (n, h, h, cin)).astype(np.float32)
+    wd = rng.normal(0, 0.5, (3, 3, cin)).astype(np.float32)
+    wp = rng.normal(0, (2.0 / cin) ** 0.5, (cout, cin)).astype(np.float32)
+    s2, s3 = rng.uniform(0.5, 1.5, cin).astype(np.float32), rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    b2, b3 = rng.normal(0, 0.1, cin).astype(np.float32), rng.normal(0, 0.1, cout).astype(np.float32)
+    oh = (h + stride - 1) // stride
+    pad = max((oh - 1) * stride + 3 - h, 0) // 2                       # TF-SAME: 1 for stride 1, 0 for stride 2 (even h)
+    mid = orc.f32_depthwise(x, wd, s2, b2, stride, 2, pad_top=pad, pad_left=pad)
+    want = orc.f32_pointwise(mid.reshape(-1, cin), wp, s3, b3, 2).reshape(n, oh, oh, cout)
+    d = [ctx.to_device(a) for a in (x, wd, s2, b2, wp, s3, b3)]
+    d_f, d_m, d_u = ctx.alloc(want.nbytes), ctx.alloc(mid.nbytes), ctx.alloc(want.nbytes)
+    rc = ctx.lib.mbn_dwpw_fused(ctx.h, d_f.ptr, d[0].ptr, d[1].ptr, d[2].ptr, d[3].ptr, d[4].ptr, d[5].ptr, d[6].ptr,
+                                n, h, h, oh, oh, cin, cout, stride, pad, pad, None)
+    assert rc == 0, rc
+    ctx.depthwise(d_m.ptr, d[0].ptr, d[1].ptr, oh, oh, 3, stride, cin,
+                  pkg.make_ext(batch=n, act=2, pad_top=pad, pad_left=pad, in_rows=h, in_cols=h, scale=d[2].ptr, shift=d[3].ptr))
+    ctx.pointwise(d_u.ptr, d_m.ptr, d[4].ptr, n * oh * oh, 1, cin, cout, pkg.make_ext(batch=1, act=2, scale=d[5].ptr, shift=d[6].ptr))
+    ctx.sync()
+    fused, unfused = d_f.download(want.shape, np.float32), d_u.download(want.shape, np.float32)
+    assert_close(fused, want, TOL_PW, "dwpw %s vs oracle" % (shape,))
+    assert np.array_equal(fused, unfused), "fused block differs from depthwise+pointwise by %g" % np.abs(fused - unfused).max()
+    for b in d + [d_f, d_m, d_u]:
+        b.free()
+
+
+def test_f32_dwpw_fused_envelope(pkg, ctx):
+    """Shapes outside the kernel's envelope answer MBN_EUNSUPPORTED (caller falls back to two launches); null -> EINVAL."""
+    d = ctx.alloc(1 << 20)
+    call = lambda *a: ctx.lib.mbn_dwpw_fused(ctx.h, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, *a, None)
+    assert call(1, 14, 14, 7, 7, 64, 128, 2, 0, 0) == pkg.EUNSUPPORTED          # odd output width
+    assert call(1, 8, 8, 8, 8, 48, 128, 1, 1, 1) == pkg.EUNSUPPORTED            # Cin not a multiple of 32
+    assert call(1, 8, 8, 8, 8, 512, 512, 1, 1, 1) == pkg.EUNSUPPORTED           # Cin beyond the LDS-resident filter
+    assert call(1, 8, 8, 8, 8, 64, 64, 1, 1, 1) == pkg.EUNSUPPORTED             # Cout < 128
+    assert call(1, 8, 8, 8, 8, 64, 128, 3, 1, 1) == pkg.EUNSUPPORTED            # stride 3
+    assert ctx.lib.mbn_dwpw_fused(ctx.h, None, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, 1, 8, 8, 8, 8, 64, 128, 1, 1, 1, None) == pkg.EINVAL
+    d.free()
