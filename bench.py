@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay each step as one hipGraph (mbn_net_set_graph)")
     ap.add_argument("--tune", action="append", default=[], help="key=value passed to mbn_tune_set (experiments)")
     ap.add_argument("--no-fuse-stem", action="store_true", help="run layers 1-3 as three launches instead of mbn_stem_fused")
+    ap.add_argument("--fuse-blocks", type=lambda v: int(v, 0), default=None,
+                    help="mask for mbn_net_set_fuse_blocks (bit L = fuse depthwise layer L with pointwise L+1); default: library's")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=0, help="images in the CPU baseline sample (0 = auto)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the CPU baseline (cap; box share is 16)")
@@ -143,6 +145,8 @@ def main():
     net = pkg.Net(ctx, plan, blob_t.data_ptr(), args.batch)
     if args.no_fuse_stem:
         net.set_fuse_stem(False)
+    if args.fuse_blocks is not None:
+        net.set_fuse_blocks(args.fuse_blocks)
     if args.graph:
         net.set_graph(True)
     if args.streams > 1:
@@ -174,10 +178,9 @@ def main():
     every = max(1, args.profile_every)
     sampled = [s for s in range(args.steps) if s % every == every // 2] or [0]
     nsub = args.streams if (args.streams > 1 and args.batch >= args.streams) else 1
-    # launches of one sub-batch pass, in order: the fused stem (layers 1-3 in one kernel, mbn_stem_fused) when the net
-    # uses it, then one launch per remaining layer
-    n_fused = 0 if (args.graph or bf16) else net.fused_layers(0)
-    launches = ([list(range(n_fused))] if n_fused else []) + [[i] for i in range(n_fused, n_layers)]
+    # launches of one sub-batch pass, in order (mbn_net_launches): the fused stem (layers 1-3, mbn_stem_fused), fused
+    # depthwise->pointwise blocks (mbn_dwpw_fused) and single layers
+    launches = [list(range(f - 1, f - 1 + c)) for f, c in net.launches(args.batch)]
     n_launch = len(launches)
     calls_per_step = n_launch * nsub            # with sub-batch streams every launch is issued once per sub-batch
     if profile:
@@ -245,13 +248,14 @@ def main():
                 by += (4.0 if last.kind == pkg.L_FC else act_bytes) * last.out_rows * last.out_cols * last.out_ch * args.batch
                 return fl, by
             kind_name = {pkg.L_CONV: "conv1", pkg.L_DW: "depthwise", pkg.L_PW: "pointwise", pkg.L_POOL: "pool", pkg.L_FC: "fc"}
-            stage_of = ["stem_fused" if len(idx) > 1 else kind_name[plan.layer[idx[0]].kind] for idx in launches]
+            stage_of = ["stem_fused" if len(idx) == 3 else "block_fused" if len(idx) == 2 else kind_name[plan.layer[idx[0]].kind]
+                        for idx in launches]
             stages, per_layer = {}, []
             for j, idx in enumerate(launches):
                 f, b = launch_work(idx)
                 per_layer.append({"layers": [i + 1 for i in idx], "stage": stage_of[j], "ms": round(float(layer_ms[j]), 5),
                                   "GBps": round(b / layer_ms[j] / 1e6, 1), "TFLOPs": round(f / layer_ms[j] / 1e9, 2)})
-            for name in ["stem_fused", "conv1", "depthwise", "pointwise", "pool", "fc"]:
+            for name in ["stem_fused", "block_fused", "conv1", "depthwise", "pointwise", "pool", "fc"]:
                 js = [j for j in range(n_launch) if stage_of[j] == name]
                 if not js:
                     continue
@@ -263,8 +267,11 @@ def main():
                 st["frac_hbm"] = round(st["GBps"] / HBM_PEAK_GBS, 4)
                 st["frac_mfma"] = round(st["TFLOPs"] / mfma_peak, 4)
                 stages[name] = st
-            if n_fused:
-                stages["stem_fused"]["layers"] = "1-%d (conv1 + depthwise + pointwise in one kernel)" % n_fused
+            if "stem_fused" in stages:
+                stages["stem_fused"]["layers"] = "1-3 (conv1 + depthwise + pointwise in one kernel)"
+            if "block_fused" in stages:
+                stages["block_fused"]["layers"] = ", ".join("%d-%d" % (idx[0] + 1, idx[1] + 1) for idx in launches if len(idx) == 2) \
+                                                  + " (depthwise + pointwise in one kernel each)"
             pw = stages["pointwise"]
             pw_idx = [launches[j][0] for j in range(n_launch) if stage_of[j] == "pointwise"]
             out["launches_per_layer"] = nsub

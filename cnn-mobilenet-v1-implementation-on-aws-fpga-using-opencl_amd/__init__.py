@@ -155,6 +155,8 @@ def load():
         lib.mbn_net_set_graph.argtypes = [vp, ci]
         lib.mbn_net_set_fuse_stem.argtypes = [vp, ci]
         lib.mbn_net_fused_layers.argtypes = [vp, ci, C.POINTER(ci)]
+        lib.mbn_net_set_fuse_blocks.argtypes = [vp, C.c_uint]
+        lib.mbn_net_launches.argtypes = [vp, ci, ci, C.POINTER(ci), C.POINTER(ci), ci, C.POINTER(ci)]
         lib.mbn_stem_fused.argtypes = [vp] + [vp] * 11 + [ci, ci, ci, ci, vp]
         lib.mbn_dwpw_fused.argtypes = [vp] + [vp] * 8 + [ci] * 10 + [vp]
         lib.mbn_graph_begin.argtypes = [vp, vp]
@@ -388,6 +390,16 @@ class Net:
         n = C.c_int()
         _chk(self.ctx.lib.mbn_net_fused_layers(self.h, last_layer, C.byref(n)))
         return n.value
+
+    def set_fuse_blocks(self, mask):
+        _chk(self.ctx.lib.mbn_net_set_fuse_blocks(self.h, int(mask)))
+
+    def launches(self, batch, last_layer=0):
+        """[(first_layer, n_layers), ...] of the launches one forward issues per (sub-)batch."""
+        cap = 64
+        a, b, n = (C.c_int * cap)(), (C.c_int * cap)(), C.c_int()
+        _chk(self.ctx.lib.mbn_net_launches(self.h, batch, last_layer, a, b, cap, C.byref(n)))
+        return [(a[i], b[i]) for i in range(min(n.value, cap))]
 
     def set_graph(self, enabled=True):
         _chk(self.ctx.lib.mbn_net_set_graph(self.h, int(enabled)), self.ctx.last_error())

@@ -14,8 +14,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t mbn_make_rsrc(const void *base
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
 }
 
-// FULL = true: the MI*32 x NI*32 block lies inside the matrix (no checks). row0/col0 must be wave-uniform.
-template <int MI, int NI, bool FULL>
+// MODE 0: the MI*32 x NI*32 block lies inside the matrix, no checks. MODE 1: columns inside, rows may run past m — the
+// descriptor (num_records = m*ldc*4 bytes) drops them: the whole offset goes through the VGPR so the hardware range
+// check sees it. MODE 2: explicit row and column checks (ragged column tiles). row0/col0 must be wave-uniform.
+template <int MI, int NI, int MODE>
 __device__ __forceinline__ void mbn_store_relu6_f32(__amdgpu_buffer_rsrc_t out, unsigned ldc, unsigned row0, int col0,
                                                     int lane, const mbn_f16v (&acc)[MI][NI],
                                                     const float *__restrict__ scale, const float *__restrict__ shift,
@@ -26,17 +28,18 @@ __device__ __forceinline__ void mbn_store_relu6_f32(__amdgpu_buffer_rsrc_t out, 
 #pragma unroll
     for (int ni = 0; ni < NI; ni++) {
         const int col = col0 + ni * 32 + li;
-        const bool cok = FULL || col < n;
+        const bool cok = MODE != 2 || col < n;
         const float sc = scale[cok ? col : n - 1], sh = shift[cok ? col : n - 1];
 #pragma unroll
         for (int mi = 0; mi < MI; mi++)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const unsigned ro = row0 + mi * 32 + (r & 3) + 8 * (r >> 2);           // + 4*lh per lane
-                const float v = fminf(fmaxf(fmaf(acc[mi][ni][r], sc, sh), 0.f), 6.f);
+                const unsigned v = __builtin_bit_cast(unsigned, fminf(fmaxf(fmaf(acc[mi][ni][r], sc, sh), 0.f), 6.f));
                 const unsigned soff = (ro * ldc + (unsigned)(col0 + ni * 32)) * 4u;    // wave-uniform bytes
-                if (FULL || (cok && ro + 4 * lh < m))
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), out, lane_off, soff, 0);
+                if (MODE == 0) __builtin_amdgcn_raw_buffer_store_b32(v, out, lane_off, soff, 0);
+                else if (MODE == 1) __builtin_amdgcn_raw_buffer_store_b32(v, out, lane_off + soff, 0, 0);
+                else if (cok && ro + 4 * lh < m) __builtin_amdgcn_raw_buffer_store_b32(v, out, lane_off, soff, 0);
             }
     }
 }

@@ -5,16 +5,23 @@
 //
 //   out[m][n] = relu6( s3[n] * sum_c relu6( s2[c] * sum_{dy,dx} in[pix(m)+(dy,dx)][c] * wd[dy][dx][c] + b2[c] ) * wp[n][c] + b3[n] )
 //
-// Workgroup = 512 lanes (8 waves), tile = 128 consecutive output pixels (flattened n,y,x) x BN output channels.
-// K loop over 32-channel chunks, one barrier per chunk, everything double-buffered:
-//   * depthwise producer: lane (pair = tid>>3, c4 = tid&7) owns 2 horizontally adjacent output pixels x 4 channels.
-//     Its 3 x (S+3) input float4s per chunk come from buffer_load_dwordx4 with per-tile precomputed byte offsets; taps
-//     outside the image carry an out-of-range offset, for which the buffer unit returns 0 — the zero padding costs no
-//     VALU and no branches. The loads for chunk k+1 are issued before the MFMAs of chunk k and consumed after them.
-//   * pointwise filter chunk [BN][32]: global_load_lds_dwordx4 straight into the swizzled LDS image (as mbn_f32_pw.hip).
-//   * MFMA v_mfma_f32_32x32x2_f32, LDS image and swizzle identical to mbn_f32_pw.hip; the arithmetic order of both
-//     stages equals the unfused kernels', so the result is bit-identical to depthwise-then-pointwise.
-// The depthwise filter [9][Cin] and its scale/shift stay in LDS for the workgroup's (persistent) lifetime.
+// Workgroup = 16 waves, tile = 128 consecutive output pixels (flattened n,y,x) x BN output channels, persistent over
+// tiles, K loop over 32-channel chunks. The waves are SPECIALISED (wave w runs on SIMD w % 4: every SIMD hosts two
+// consumers and two producers, 128 VGPRs each):
+//   * waves 8-15, PRODUCERS (VALU + memory): a lane (pair = t>>3, c4 = t&7) owns 2 horizontally adjacent output
+//     pixels x 4 channels. Its 3 x (S+3) input float4s per chunk come from buffer_load_dwordx4 with
+//     per-tile precomputed byte offsets; taps outside the image carry an out-of-range offset, for which the buffer
+//     unit returns 0 — the zero padding costs no VALU and no branches. They compute depthwise + BN + ReLU6 for chunk
+//     g+1 into the swizzled A tile of the other LDS buffer and bring the pointwise filter chunk [BN][32] in with
+//     global_load_lds_dwordx4 while
+//   * waves 0-7, CONSUMERS (MFMA only): multiply chunk g — v_mfma_f32_32x32x2_f32 on a 64 x 64 (BN = 256) or
+//     32 x 64 (BN = 128) wave tile, LDS image and swizzle identical to mbn_f32_pw.hip.
+// One s_barrier per chunk hands buffers over; the flattened (tile, chunk) sequence is pipelined across tile
+// boundaries, and a tile's epilogue stores are issued after the barrier so the producers already work on the next
+// chunk. The producers' load latency and VALU time hide under the consumers' MFMA time (a chunk is 8192 MFMA cycles per
+// SIMD at BN = 256 against ~1000 producer VALU cycles). The arithmetic order of both stages equals the unfused
+// kernels', so the result is bit-identical to depthwise-then-pointwise.
+// The depthwise filter [9][Cin] and its scale/shift stay in LDS for the workgroup's lifetime (Cin <= 1024).
 // When Cout > BN the depthwise work is recomputed per column tile (n-tile index fastest, so the re-reads hit L2).
 #include "mbn_internal.h"
 #include "mbn_epilogue.h"
@@ -25,8 +32,10 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 typedef mbn_f16v f16v;
 typedef unsigned u4 __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 128, NT = 512, BKF = 32;
-constexpr int CMAX = 256;                      // largest Cin (depthwise constants resident in LDS)
+constexpr int BM = 128, BKF = 32;
+constexpr int NCW = 8, NPW = 8;                // consumer / producer waves: waves land on SIMD (wave % 4), so every SIMD
+constexpr int NT = 64 * (NCW + NPW);           // hosts two MFMA-issuing waves and two VALU/memory waves (128 VGPRs each)
+constexpr int CMAX = 1024;                     // largest Cin (depthwise constants resident in LDS: 44 KB)
 constexpr unsigned OOB = 0xF0000000u;          // byte offset beyond any supported tensor: the load returns zeros
 
 struct DwPwArgs {
@@ -52,112 +61,150 @@ __device__ __forceinline__ int xcd_remap(int vb, int nwg)
     return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (vb >> 3);
 }
 
-template <int S, int BN, int WM, int WN>
+template <int S, int BN>
 __global__ __launch_bounds__(NT) void dwpw_f32(DwPwArgs a)
 {
+    constexpr int WN = 64, WM = BN == 256 ? 64 : 32;   // consumer wave tile: 8 waves as 2 x 4 (BN 256) or 4 x 2 (BN 128)
     constexpr int WAVES_N = BN / WN;
-    static_assert((BM / WM) * WAVES_N == NT / 64, "8 waves");
+    static_assert((BM / WM) * WAVES_N == NCW, "8 consumer waves");
     constexpr int MI = WM / 32, NI = WN / 32;
-    constexpr int B_LD = BN * 8 / NT;                 // 16-B filter pieces per lane per chunk
-    constexpr int XC = S + 3;                         // input columns feeding 2 adjacent output pixels
-    // one LDS object, carved by hand (as in mbn_f32_pw.hip)
+    constexpr int NP = 64 * NPW;                       // producer lanes
+    constexpr int B_LD = BN * 8 / NP;                  // 16-B filter pieces per producer lane per chunk
+    constexpr int XC = S + 3;                          // input columns feeding 2 adjacent output pixels
+    constexpr int NX = 3 * XC;                         // buffer loads per producer lane per chunk
+    // one LDS object, carved by hand (as in mbn_f32_pw.hip; with separate arrays hipcc puts s_waitcnt vmcnt(0) in front
+    // of the first MFMA operand read after every direct-to-LDS load)
     __shared__ __attribute__((aligned(16))) float lds[2 * BM * BKF + 2 * BN * BKF + 11 * CMAX];
     float *const a_s0 = lds, *const b_s0 = lds + 2 * BM * BKF, *const wd_s = b_s0 + 2 * BN * BKF, *const sb_s = wd_s + 9 * CMAX;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = (wave / WAVES_N) * WM, wn = (wave % WAVES_N) * WN;
-    const int li = lane & 31, lh = lane >> 5;
-    const int c4 = tid & 7, pair = tid >> 3;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nk = a.cin / 32, nwg = a.mt * a.nt;
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const int wm_u = (wave_u / WAVES_N) * WM, wn_u = (wave_u % WAVES_N) * WN;      // wave-uniform copies for the epilogue
+    const unsigned mtot = (unsigned)a.m;
 
     for (int i = tid * 4; i < 9 * a.cin; i += NT * 4) *reinterpret_cast<f4 *>(wd_s + i) = *reinterpret_cast<const f4 *>(a.wd + i);
     for (int i = tid * 4; i < a.cin; i += NT * 4) {
         *reinterpret_cast<f4 *>(sb_s + i) = *reinterpret_cast<const f4 *>(a.s2 + i);
         *reinterpret_cast<f4 *>(sb_s + a.cin + i) = *reinterpret_cast<const f4 *>(a.b2 + i);
     }
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.in), 0, a.in_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t orsrc = mbn_make_rsrc(a.out, (unsigned)(a.m * a.cout * 4));
     __syncthreads();
+    if ((int)blockIdx.x >= nwg) return;
 
-    int vb = blockIdx.x;
-    if (vb >= nwg) return;
-    const unsigned mtot = (unsigned)a.m;
-
-    // ---- per-tile state: tile origin, this lane's two output pixels -> byte offsets of their 3 x XC input float4s
-    // (chunk 0; chunk kc adds kc*128 bytes through the scalar offset), and its pieces of the pointwise filter
-    unsigned m0;
-    int n0;
-    unsigned off[3][XC];
-    const float *b_src[B_LD];
-    auto set_tile = [&](int v) {
-        const int lid = xcd_remap(v, nwg);
-        n0 = (lid % a.nt) * BN;
-        m0 = (unsigned)(lid / a.nt) * BM;
-        const unsigned m = m0 + 2 * pair;
-        const bool mok = m < mtot;
-        const unsigned x = m % (unsigned)a.wo, q = m / (unsigned)a.wo;
-        const unsigned y = q % (unsigned)a.ho, n = q / (unsigned)a.ho;
+    if (wave_u >= NCW) {
+        // =============================================================== PRODUCERS
+        const int pw_u = wave_u - NCW;                                   // producer wave 0..7
+        const int t = pw_u * 64 + lane, c4 = t & 7, pair = t >> 3;              // pair 0..63: tile rows 2*pair, 2*pair+1
+        const __amdgpu_buffer_rsrc_t rsrc = mbn_make_rsrc(a.in, a.in_bytes);
+        unsigned off[3][XC];
+        const float *b_src[B_LD];
+        auto set_tile = [&](int v) __attribute__((always_inline)) {
+            const int lid = xcd_remap(v, nwg);
+            const int n0 = (lid % a.nt) * BN;
+            const unsigned m = (unsigned)(lid / a.nt) * BM + 2 * pair;
+            const bool mok = m < mtot;
+            const unsigned x = m % (unsigned)a.wo, q = m / (unsigned)a.wo;
+            const unsigned y = q % (unsigned)a.ho, n = q / (unsigned)a.ho;
 #pragma unroll
-        for (int dy = 0; dy < 3; dy++) {
-            const int iy = (int)y * S + dy - a.pad_top;
-            const bool rok = mok && iy >= 0 && iy < a.h;
+            for (int dy = 0; dy < 3; dy++) {
+                const int iy = (int)y * S + dy - a.pad_top;
+                const bool rok = mok && iy >= 0 && iy < a.h;
 #pragma unroll
-            for (int j = 0; j < XC; j++) {
-                const int ix = (int)x * S + j - a.pad_left;
-                const bool ok = rok && ix >= 0 && ix < a.w;
-                off[dy][j] = ok ? (((n * a.h + iy) * a.w + ix) * a.cin + c4 * 4) * 4u : OOB;
+                for (int j = 0; j < XC; j++) {
+                    const int ix = (int)x * S + j - a.pad_left;
+                    const bool ok = rok && ix >= 0 && ix < a.w;
+                    off[dy][j] = ok ? (((n * a.h + iy) * a.w + ix) * a.cin + c4 * 4) * 4u : OOB;
+                }
             }
-        }
 #pragma unroll
-        for (int p = 0; p < B_LD; p++) {
-            const int row = (p * NT + tid) >> 3;
-            b_src[p] = a.wp + (long)(n0 + row) * a.cin + ((c4 ^ (row >> 1)) & 7) * 4;
-        }
-    };
-
-    f4 xr[3][XC];
-    auto ldx = [&](int kc) {
-#pragma unroll
-        for (int dy = 0; dy < 3; dy++)
-#pragma unroll
-            for (int j = 0; j < XC; j++)
-                xr[dy][j] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[dy][j], kc * 128, 0));
-    };
-    auto glds_b = [&](int kc, int buf) {
-#pragma unroll
-        for (int p = 0; p < B_LD; p++)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(b_src[p] + kc * 32),
-                                             (__attribute__((address_space(3))) void *)(b_s0 + buf * BN * BKF + (p * (NT / 8) + wave_u * 8) * BKF),
-                                             16, 0, 0);
-    };
-    auto dw = [&](int kc, int buf) {
-        const float *wk = wd_s + kc * 32 + c4 * 4;
-        f4 acc0 = f4{ 0.f, 0.f, 0.f, 0.f }, acc1 = acc0;
-#pragma unroll
-        for (int dy = 0; dy < 3; dy++)
-#pragma unroll
-            for (int dx = 0; dx < 3; dx++) {
-                const f4 w = *reinterpret_cast<const f4 *>(wk + (dy * 3 + dx) * a.cin);
-                acc0 = __builtin_elementwise_fma(xr[dy][dx], w, acc0);
-                acc1 = __builtin_elementwise_fma(xr[dy][dx + S], w, acc1);
+            for (int p = 0; p < B_LD; p++) {
+                const int row = (p * NP + t) >> 3;
+                b_src[p] = a.wp + (long)(n0 + row) * a.cin + ((c4 ^ (row >> 1)) & 7) * 4;
             }
-        const f4 s = *reinterpret_cast<const f4 *>(sb_s + kc * 32 + c4 * 4);
-        const f4 b = *reinterpret_cast<const f4 *>(sb_s + a.cin + kc * 32 + c4 * 4);
-        *reinterpret_cast<f4 *>(a_s0 + buf * BM * BKF + swz(2 * pair, c4)) = bn_relu6(acc0, s, b);
-        *reinterpret_cast<f4 *>(a_s0 + buf * BM * BKF + swz(2 * pair + 1, c4)) = bn_relu6(acc1, s, b);
-    };
+        };
+        f4 xr[3][XC];
+        auto ldx = [&](int kc) __attribute__((always_inline)) {
+#pragma unroll
+            for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+                for (int j = 0; j < XC; j++)
+                    xr[dy][j] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[dy][j], kc * 128, 0));
+        };
+        auto glds_b = [&](int kc, int buf) __attribute__((always_inline)) {
+#pragma unroll
+            for (int p = 0; p < B_LD; p++)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(b_src[p] + kc * 32),
+                                                 (__attribute__((address_space(3))) void *)(b_s0 + buf * BN * BKF + (p * (NP / 8) + pw_u * 8) * BKF),
+                                                 16, 0, 0);
+        };
+        auto dw = [&](int kc, int buf) __attribute__((always_inline)) {
+            const float *wk = wd_s + kc * 32 + c4 * 4;
+            f4 acc0 = f4{ 0.f, 0.f, 0.f, 0.f }, acc1 = acc0;
+#pragma unroll
+            for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+                for (int dx = 0; dx < 3; dx++) {
+                    const f4 w = *reinterpret_cast<const f4 *>(wk + (dy * 3 + dx) * a.cin);
+                    acc0 = __builtin_elementwise_fma(xr[dy][dx], w, acc0);
+                    acc1 = __builtin_elementwise_fma(xr[dy][dx + S], w, acc1);
+                }
+            const f4 s = *reinterpret_cast<const f4 *>(sb_s + kc * 32 + c4 * 4);
+            const f4 b = *reinterpret_cast<const f4 *>(sb_s + a.cin + kc * 32 + c4 * 4);
+            *reinterpret_cast<f4 *>(a_s0 + buf * BM * BKF + swz(2 * pair, c4)) = bn_relu6(acc0, s, b);
+            *reinterpret_cast<f4 *>(a_s0 + buf * BM * BKF + swz(2 * pair + 1, c4)) = bn_relu6(acc1, s, b);
+        };
 
-    // ---- software pipeline over the flattened (tile, chunk) sequence: chunk g's A tile is produced, and its filter
-    // chunk fetched, during the MFMAs of chunk g-1 — also across the tile boundary, so a tile's first loads and the
-    // previous tile's epilogue stores are off the critical path. `p` = LDS buffer of the chunk being multiplied.
-    set_tile(vb);
-    ldx(0);
-    glds_b(0, 0);
-    dw(0, 0);
+        // cursor = the chunk whose input loads are in flight: (tile cvb, chunk ckc)
+        int cvb = blockIdx.x, ckc = 0;
+        auto advance = [&]() __attribute__((always_inline)) -> bool {                 // next chunk of the flattened sequence; false at the end
+            if (++ckc < nk) return true;
+            ckc = 0;
+            cvb += gridDim.x;
+            if (cvb >= nwg) return false;
+            set_tile(cvb);
+            return true;
+        };
+        set_tile(cvb);
+        ldx(0);
+        glds_b(0, 0);
+        dw(0, 0);
+        bool have = advance();
+        if (have) {
+            ldx(ckc);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NX) : "memory");     // filter chunk 0 landed; the NX newer loads may fly
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();                                                  // chunk 0 handed to the consumers
+        int p = 0;
+        while (have) {
+            // consumers multiply the chunk in buffer p; produce the cursor's chunk into buffer p^1 (free since the barrier)
+            const int kc = ckc;
+            glds_b(kc, p ^ 1);
+            dw(kc, p ^ 1);                                                // waits for this chunk's buffer loads only
+            have = advance();
+            if (have) {
+                ldx(ckc);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NX) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();
+            p ^= 1;
+        }
+        __syncthreads();                                                  // the consumers' last chunk
+        return;
+    }
+
+    // =================================================================== CONSUMERS
+    const int wm = (wave_u / WAVES_N) * WM, wn = (wave_u % WAVES_N) * WN;
+    const int li = lane & 31, lh = lane >> 5;
+    const __amdgpu_buffer_rsrc_t orsrc = mbn_make_rsrc(a.out, (unsigned)(a.m * a.cout * 4));
+    __syncthreads();                                                      // chunk 0 is in buffer 0
     int p = 0;
-    for (;;) {
+    for (int vb = blockIdx.x; vb < nwg; vb += gridDim.x) {
+        const int lid = xcd_remap(vb, nwg);
+        const int n0 = (lid % a.nt) * BN;
+        const unsigned m0 = (unsigned)(lid / a.nt) * BM;
         f16v acc[MI][NI];
 #pragma unroll
         for (int mi = 0; mi < MI; mi++)
@@ -165,54 +212,34 @@ __global__ __launch_bounds__(NT) void dwpw_f32(DwPwArgs a)
             for (int ni = 0; ni < NI; ni++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[mi][ni][r] = 0.f;
-        const unsigned cm0 = m0;
-        const int cn0 = n0;
-        const int nvb = vb + gridDim.x;
-        const bool more = nvb < nwg;
         for (int kc = 0; kc < nk; kc++) {
-            const bool last = kc + 1 == nk;
-            const int nkc = last ? 0 : kc + 1;
-            __syncthreads();                       // a_s[p] written by every lane; every wave's filter pieces of b_s[p] landed
-            if (last && more) set_tile(nvb);
-            if (!last || more) {
-                ldx(nkc);                          // in flight during the MFMAs below
-                glds_b(nkc, p ^ 1);                // b_s[p^1] was last read before this barrier
+            const float *As = a_s0 + p * BM * BKF, *Bs = b_s0 + p * BN * BKF;
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int chunk = 2 * g + lh;
+                f4 av[MI], bv[NI];
+#pragma unroll
+                for (int mi = 0; mi < MI; mi++) av[mi] = *reinterpret_cast<const f4 *>(As + swz(wm + mi * 32 + li, chunk));
+#pragma unroll
+                for (int ni = 0; ni < NI; ni++) bv[ni] = *reinterpret_cast<const f4 *>(Bs + swz(wn + ni * 32 + li, chunk));
+#pragma unroll
+                for (int s = 0; s < 4; s++)
+#pragma unroll
+                    for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ni++)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][s], bv[ni][s], acc[mi][ni], 0, 0, 0);
             }
-            {
-                const float *As = a_s0 + p * BM * BKF, *Bs = b_s0 + p * BN * BKF;
-#pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    const int chunk = 2 * g + lh;
-                    f4 av[MI], bv[NI];
-#pragma unroll
-                    for (int mi = 0; mi < MI; mi++) av[mi] = *reinterpret_cast<const f4 *>(As + swz(wm + mi * 32 + li, chunk));
-#pragma unroll
-                    for (int ni = 0; ni < NI; ni++) bv[ni] = *reinterpret_cast<const f4 *>(Bs + swz(wn + ni * 32 + li, chunk));
-#pragma unroll
-                    for (int s = 0; s < 4; s++)
-#pragma unroll
-                        for (int mi = 0; mi < MI; mi++)
-#pragma unroll
-                            for (int ni = 0; ni < NI; ni++)
-                                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][s], bv[ni][s], acc[mi][ni], 0, 0, 0);
-                }
-            }
-            if (!last || more) dw(nkc, p ^ 1);     // a_s[p^1] was last read before this barrier
+            __syncthreads();                                              // buffer p may be refilled; buffer p^1 is ready
             p ^= 1;
         }
-
-        // ---- epilogue: BN + ReLU6 (mbn_epilogue.h); only the last row tile can be ragged
-        {
-            const unsigned row0 = cm0 + wm_u;
-            if (cm0 + BM <= mtot) mbn_store_relu6_f32<MI, NI, true>(orsrc, (unsigned)a.cout, row0, cn0 + wn_u, lane, acc, a.s3, a.b3, mtot, a.cout);
-            else mbn_store_relu6_f32<MI, NI, false>(orsrc, (unsigned)a.cout, row0, cn0 + wn_u, lane, acc, a.s3, a.b3, mtot, a.cout);
-        }
-        if (!more) break;
-        vb = nvb;
+        // ---- epilogue after the hand-over barrier: BN + ReLU6 (mbn_epilogue.h); only the last row tile can be ragged
+        if (m0 + BM <= mtot) mbn_store_relu6_f32<MI, NI, 0>(orsrc, (unsigned)a.cout, m0 + wm, n0 + wn, lane, acc, a.s3, a.b3, mtot, a.cout);
+        else mbn_store_relu6_f32<MI, NI, 1>(orsrc, (unsigned)a.cout, m0 + wm, n0 + wn, lane, acc, a.s3, a.b3, mtot, a.cout);
     }
 }
 
-template <int S, int BN, int WM, int WN>
+template <int S, int BN>
 void launch(DwPwArgs &a, hipStream_t s, int num_cus)
 {
     a.mt = (int)((a.m + BM - 1) / BM);
@@ -220,7 +247,7 @@ void launch(DwPwArgs &a, hipStream_t s, int num_cus)
     const long nwg = (long)a.mt * a.nt;
     long grid = (long)num_cus * (g_mbn_tune.misc > 0 ? g_mbn_tune.misc : 1);
     if (grid > nwg) grid = nwg;
-    hipLaunchKernelGGL((dwpw_f32<S, BN, WM, WN>), dim3((unsigned)grid), dim3(NT), 0, s, a);
+    hipLaunchKernelGGL((dwpw_f32<S, BN>), dim3((unsigned)grid), dim3(NT), 0, s, a);
 }
 
 }   // namespace
@@ -264,11 +291,11 @@ int mbn_launch_f32_dwpw(mbn_context *ctx, hipStream_t stream, float *out, const 
     a.in_bytes = (unsigned)(4.0 * batch * in_rows * in_cols * cin);
     const bool wide = (cout % 256) == 0 && g_mbn_tune.pw_tile != 1;      // pw_tile=1: force the 128-column tile (A/B hook)
     if (stride == 1) {
-        if (wide) launch<1, 256, 64, 64>(a, stream, ctx->num_cus);
-        else launch<1, 128, 64, 32>(a, stream, ctx->num_cus);
+        if (wide) launch<1, 256>(a, stream, ctx->num_cus);
+        else launch<1, 128>(a, stream, ctx->num_cus);
     } else {
-        if (wide) launch<2, 256, 64, 64>(a, stream, ctx->num_cus);
-        else launch<2, 128, 64, 32>(a, stream, ctx->num_cus);
+        if (wide) launch<2, 256>(a, stream, ctx->num_cus);
+        else launch<2, 128>(a, stream, ctx->num_cus);
     }
     return MBN_OK;
 }

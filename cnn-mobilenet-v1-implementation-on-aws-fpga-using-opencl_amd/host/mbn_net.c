@@ -24,6 +24,7 @@ struct mbn_net {
     int keep;
     int dtype;                 /* MBN_DT_F32 or MBN_DT_BF16 */
     int fuse_stem;             /* mbn_net_set_fuse_stem (default 1) */
+    unsigned fuse_blocks;      /* mbn_net_set_fuse_blocks: bit L = run the depthwise layer L and the pointwise layer L+1 as one launch */
     int use_graph;             /* mbn_net_set_graph */
     void *graph;               /* instantiated hipGraph of one forward, valid for the key below */
     const void *g_images;
@@ -52,6 +53,7 @@ static int net_alloc_common(mbn_context *ctx, const mbn_plan *plan, int max_batc
     net->dtype = MBN_DT_F32;
     net->nstreams = 1;
     net->fuse_stem = 1;
+    net->fuse_blocks = MBN_FUSE_BLOCKS_DEFAULT;
     net->plan = *plan;
     net->max_batch = max_batch;
     size_t bytes = (size_t)plan->max_act_floats * (size_t)max_batch * sizeof(float);
@@ -165,6 +167,11 @@ static int stem_fusable(const mbn_net *net, int last_layer)
 int mbn_net_set_fuse_stem(mbn_net *net, int enabled)
 {
     if (!net) return MBN_EINVAL;
+    if (net->fuse_stem != (enabled != 0) && net->graph) {
+        mbn_sync(net->ctx);
+        mbn_graph_destroy(net->ctx, net->graph);
+        net->graph = NULL;
+    }
     net->fuse_stem = enabled != 0;
     return MBN_OK;
 }
@@ -174,6 +181,59 @@ int mbn_net_fused_layers(const mbn_net *net, int last_layer, int *count)
     if (!net || !count) return MBN_EINVAL;
     if (last_layer <= 0 || last_layer > net->plan.n_layers) last_layer = net->plan.n_layers;
     *count = stem_fusable(net, last_layer) ? 3 : 0;
+    return MBN_OK;
+}
+
+/* layers i+1 (depthwise) and i+2 (pointwise), 0-based index i, can go through mbn_dwpw_fused for `count` images: fp32,
+ * nothing kept, enabled in the mask, and inside the kernel's envelope (mbn.h: mbn_dwpw_fused) */
+static int block_fusable(const mbn_net *net, int i, int count, int last_layer)
+{
+    if (net->dtype != MBN_DT_F32 || net->keep || i + 2 > last_layer || i + 1 >= net->plan.n_layers || i + 1 >= 32) return 0;
+    if (!((net->fuse_blocks >> (i + 1)) & 1u)) return 0;
+    const mbn_layer_desc *d = &net->plan.layer[i], *p = &net->plan.layer[i + 1];
+    if (d->kind != MBN_L_DW || p->kind != MBN_L_PW || (d->stride != 1 && d->stride != 2)) return 0;
+    if (d->in_ch < 32 || (d->in_ch % 32) != 0 || d->in_ch > 1024 || p->out_ch < 128 || (p->out_ch % 128) != 0) return 0;
+    if ((d->out_cols & 1) || p->in_ch != d->out_ch) return 0;
+    if (4.0 * count * d->in_rows * d->in_cols * d->in_ch >= 4026531840.0) return 0;
+    if (4.0 * count * p->out_rows * p->out_cols * p->out_ch >= 4294967296.0) return 0;
+    return 1;
+}
+
+/* a captured graph bakes the launch list in: drop it when the fusion settings change */
+static void drop_graph(mbn_net *net)
+{
+    if (net->graph) {
+        mbn_sync(net->ctx);
+        mbn_graph_destroy(net->ctx, net->graph);
+        net->graph = NULL;
+    }
+}
+
+int mbn_net_set_fuse_blocks(mbn_net *net, unsigned mask)
+{
+    if (!net) return MBN_EINVAL;
+    if (net->fuse_blocks != mask) drop_graph(net);
+    net->fuse_blocks = mask;
+    return MBN_OK;
+}
+
+int mbn_net_launches(const mbn_net *net, int batch, int last_layer, int *first_layer, int *n_layers, int capacity, int *count)
+{
+    if (!net || !count || batch <= 0) return MBN_EINVAL;
+    if (last_layer <= 0 || last_layer > net->plan.n_layers) last_layer = net->plan.n_layers;
+    int ns = net->nstreams;
+    if (ns > batch) ns = 1;
+    const int sub = ns > 1 ? batch / ns + (batch % ns ? 1 : 0) : batch;      /* the largest sub-batch decides the envelope */
+    int n = 0, i = 0;
+    while (i < last_layer) {
+        int span = 1;
+        if (i == 0 && stem_fusable(net, last_layer)) span = 3;
+        else if (block_fusable(net, i, sub, last_layer)) span = 2;
+        if (first_layer && n_layers && n < capacity) { first_layer[n] = i + 1; n_layers[n] = span; }
+        n++;
+        i += span;
+    }
+    *count = n;
     return MBN_OK;
 }
 
@@ -290,6 +350,28 @@ static int forward_range(mbn_net *net, const void *images, void *logits, int fir
     }
     for (int i = i0; i < last_layer; i++) {
         const mbn_layer_desc *l = &net->plan.layer[i];
+        if (!layer_ms && block_fusable(net, i, count, last_layer)) {
+            /* depthwise + pointwise in one kernel; the depthwise output stays in LDS */
+            const mbn_layer_desc *lp = &net->plan.layer[i + 1];
+            const size_t per_img2 = (size_t)lp->out_rows * lp->out_cols * lp->out_ch * sizeof(float);
+            char *dst2 = (i + 1 == last_layer - 1) ? (char *)logits + (size_t)first * per_img2 : (char *)net->act[which] + slot;
+            int rc = mbn_dwpw_fused(net->ctx, dst2, src, blob_at(net, l->w_offset), blob_at(net, l->scale_offset),
+                                    blob_at(net, l->shift_offset), blob_at(net, lp->w_offset), blob_at(net, lp->scale_offset),
+                                    blob_at(net, lp->shift_offset), count, l->in_rows, l->in_cols, l->out_rows, l->out_cols,
+                                    l->in_ch, lp->out_ch, l->stride, l->pad_top, l->pad_left, stream);
+            if (rc == MBN_OK) {
+                if (i + 1 != last_layer - 1) which ^= 1;
+                if (first == 0) { net->last_out[i] = NULL; net->last_out[i + 1] = dst2; }
+                src = dst2;
+                if (next_stream && (i + 1 == stagger || i + 2 == stagger)) {
+                    rc = mbn_stream_wait(net->ctx, next_stream, stream);
+                    if (rc != MBN_OK) return rc;
+                }
+                i++;
+                continue;
+            }
+            if (rc != MBN_EUNSUPPORTED) return rc;
+        }
         const size_t per_img = (size_t)l->out_rows * l->out_cols * l->out_ch * out_esize(net, l);
         char *dst;
         if (i == last_layer - 1) dst = (char *)logits + (size_t)first * per_img;

@@ -219,7 +219,7 @@ int mbn_stem_fused(mbn_context *ctx, void *out, const void *image, const void *w
  * scale/shift and ReLU6; the depthwise output never reaches HBM. fp32 NHWC: in [batch][in_rows][in_cols][cin],
  * out [batch][out_rows][out_cols][cout]; wd [3][3][cin], wp [cout][cin] as in the separate calls; pad_top/pad_left as in
  * mbn_layer_ext (zero padding; the high side needs none stated). Bit-identical to mbn_depthwise followed by
- * mbn_pointwise. Returns MBN_EUNSUPPORTED unless cin is a multiple of 32 and <= 256, cout a multiple of 128, out_cols
+ * mbn_pointwise. Returns MBN_EUNSUPPORTED unless cin is a multiple of 32 and <= 1024, cout a multiple of 128, out_cols
  * even and the input under 3.75 GiB — callers then issue the two layer calls instead. */
 int mbn_dwpw_fused(mbn_context *ctx, void *out, const void *in, const void *wd, const void *s2, const void *b2,
                    const void *wp, const void *s3, const void *b3, int batch, int in_rows, int in_cols, int out_rows,
@@ -352,6 +352,16 @@ int  mbn_net_set_graph(mbn_net *net, int enabled);
  * many leading layers the next forward(batch, last_layer) would fuse (0 or 3). */
 int  mbn_net_set_fuse_stem(mbn_net *net, int enabled);
 int  mbn_net_fused_layers(const mbn_net *net, int last_layer, int *count);
+/* Fused depthwise->pointwise blocks (mbn_dwpw_fused): bit L of `mask` (L = 1-based number of a depthwise layer) lets
+ * layers L and L+1 run as one launch when the plan is fp32, activations are not kept and the shapes are inside the
+ * kernel's envelope. Default MBN_FUSE_BLOCKS_DEFAULT = the blocks measured faster fused at batch 256 on MI355X
+ * (DESIGN.md); 0 = every layer its own launch. Results are bit-identical either way. */
+#define MBN_FUSE_BLOCKS_DEFAULT ((1u << 4) | (1u << 6) | (1u << 8))
+int  mbn_net_set_fuse_blocks(mbn_net *net, unsigned mask);
+/* The launches the next forward(batch, last_layer) issues per (sub-)batch: launch j covers n_layers[j] layers starting
+ * at the 1-based layer first_layer[j] (3 = fused stem, 2 = fused block, 1 = single layer). *count = number of
+ * launches; the arrays (may be NULL) receive at most `capacity` entries. */
+int  mbn_net_launches(const mbn_net *net, int batch, int last_layer, int *first_layer, int *n_layers, int capacity, int *count);
 /* images: device fp32 NHWC [batch][res][res][3]; logits: device fp32 [batch][classes]. Asynchronous.
  * last_layer: run layers 1..last_layer only (0 or 29 => all; 5 and 13 = BASELINE configs 1-2), in which
  * case `logits` receives that layer's NHWC activation instead. */

@@ -719,6 +719,7 @@ DWPW_SHAPES = [  # (batch, in side, Cin, Cout, stride)
     (2, 112, 64, 128, 2), (2, 56, 128, 128, 1), (2, 56, 128, 256, 2), (2, 28, 256, 256, 1),    # L4-5, L6-7, L8-9, L10-11
     (1, 28, 256, 512, 2),                                  # L12-13: two 256-column tiles, depthwise recomputed
     (3, 14, 32, 128, 1), (1, 6, 64, 384, 1), (5, 12, 96, 128, 2), (1, 2, 32, 256, 1),          # ragged M, 3 n-tiles, tiny maps
+    (2, 14, 512, 512, 1), (3, 28, 512, 1024, 2), (40, 14, 64, 256, 1),                         # L14-15, Cin 512 stride 2; many tiles per workgroup
 ]
 
 
@@ -758,8 +759,44 @@ def test_f32_dwpw_fused_envelope(pkg, ctx):
     call = lambda *a: ctx.lib.mbn_dwpw_fused(ctx.h, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, *a, None)
     assert call(1, 14, 14, 7, 7, 64, 128, 2, 0, 0) == pkg.EUNSUPPORTED          # odd output width
     assert call(1, 8, 8, 8, 8, 48, 128, 1, 1, 1) == pkg.EUNSUPPORTED            # Cin not a multiple of 32
-    assert call(1, 8, 8, 8, 8, 512, 512, 1, 1, 1) == pkg.EUNSUPPORTED           # Cin beyond the LDS-resident filter
+    assert call(1, 8, 8, 8, 8, 2048, 512, 1, 1, 1) == pkg.EUNSUPPORTED          # Cin beyond the LDS-resident filter
     assert call(1, 8, 8, 8, 8, 64, 64, 1, 1, 1) == pkg.EUNSUPPORTED             # Cout < 128
     assert call(1, 8, 8, 8, 8, 64, 128, 3, 1, 1) == pkg.EUNSUPPORTED            # stride 3
     assert ctx.lib.mbn_dwpw_fused(ctx.h, None, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, 1, 8, 8, 8, 8, 64, 128, 1, 1, 1, None) == pkg.EINVAL
     d.free()
+
+
+def test_net_fused_blocks_equal_separate_layers(pkg, orc, ctx, tmp_path):
+    """Net runner with depthwise->pointwise blocks fused (mbn_net_set_fuse_blocks) vs every layer its own launch:
+    identical logits and identical partial outputs (last_layer inside/at the end of a fused block); the launch list
+    mbn_net_launches reports matches the mask; the oracle bounds the result."""
+    n, res = 3, 64
+    hw, net = _make_net(pkg, ctx, tmp_path, 1.0, res, 20, n)
+    imgs = np.random.default_rng(11).uniform(-1, 1, (n, res, res, 3)).astype(np.float32)
+    d_in = ctx.to_device(imgs)
+    assert net.launches(n)[:4] == [(1, 3), (4, 2), (6, 2), (8, 2)]            # default mask: stem + blocks 4, 6, 8
+    assert (10, 1) in net.launches(n)
+    outs = {}
+    for mask in (0xFFFFFFFE, 0):
+        net.set_fuse_blocks(mask)
+        la = net.launches(n)
+        if mask:
+            assert la == [(1, 3)] + [(l, 2) for l in range(4, 27, 2)] + [(28, 1), (29, 1)], la
+        else:
+            assert la == [(1, 3)] + [(l, 1) for l in range(4, 30)], la
+        for last in (0, 5, 7, 13, 27):
+            l = hw.plan.layer[(last or 29) - 1]
+            d_out = ctx.alloc(n * l.out_rows * l.out_cols * l.out_ch * 4)
+            net.forward(d_in.ptr, d_out.ptr, n, last)
+            ctx.sync()
+            outs[(mask, last)] = d_out.download((n, l.out_rows, l.out_cols, l.out_ch), np.float32)
+            d_out.free()
+    for last in (0, 5, 7, 13, 27):
+        assert np.array_equal(outs[(0xFFFFFFFE, last)], outs[(0, last)]), last
+    want, _ = orc.net_forward(orc.plan_build(1.0, res, 20), hw.blob, imgs, threads=orc.num_threads())
+    assert_close(outs[(0xFFFFFFFE, 0)].reshape(n, 20), np.asarray(want).reshape(n, 20), TOL_NET, "fused-block net vs oracle")
+    # kept activations force single-layer launches
+    net.set_fuse_blocks(0xFFFFFFFE)
+    net.keep_activations(True)
+    assert net.launches(n) == [(l, 1) for l in range(1, 30)]
+    net.destroy()
