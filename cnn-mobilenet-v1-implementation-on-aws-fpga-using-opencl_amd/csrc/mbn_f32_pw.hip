@@ -49,6 +49,7 @@ struct PwArgs {
     int mt, nt;     // tile counts
     int out_f32;    // bf16 mode: write fp32 (FC logits)
     int fast_epi;   // 0 = always the general epilogue (A/B hook: tune conv_variant=9)
+    int loop2;      // 1 = software-pipelined k-loop (default); 0 = plain loop (A/B hook: tune conv_variant=8)
 };
 
 constexpr int BKB = 128;            // k-tile in BYTES per row (32 fp32 / 64 bf16)
@@ -62,6 +63,19 @@ __device__ __forceinline__ int xcd_remap(int vb, int nwg)
 {
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = vb & 7;
     return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (vb >> 3);
+}
+
+// LD pieces of 8 rows x 128 B per wave: buffer_load_dwordx4 ... lds writes 1 KiB linearly at the wave-uniform LDS
+// address in M0; piece p of wave w covers tile rows p*(NT/8) + 8w .. +7. (A __device__ function, not a lambda: the host pass
+// of hipcc silently drops the kernel's launch stub when this builtin appears inside a lambda of the kernel.)
+__device__ __forceinline__ void lds_dma_rows(const void *gbase, unsigned gbytes, float *lds_tile, const unsigned *voff, int soff, int wave_u,
+                                             const int LD, const int NT)
+{
+    const __amdgpu_buffer_rsrc_t rsrc = mbn_make_rsrc(gbase, gbytes);      // 4 SGPRs, loop-invariant
+#pragma unroll
+    for (int p = 0; p < LD; p++)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(lds_tile + (p * (NT / 8) + wave_u * 8) * BKF),
+                                                 16, voff[p], soff, 0, 0);
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int NBUF, bool KFULL, bool GLDS>
@@ -92,8 +106,18 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void pw_gemm(PwArgs a)
 #pragma unroll
     for (int p = 0; p < ST; p++) st_row[p] = (p * NT + tid) >> 3;
 
+    // per-lane LDS word offsets of the four fragment groups (the swizzle is an XOR: one base per group; MFMA block and
+    // buffer offsets are then constants)
+    int fr_a[4], fr_b[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        fr_a[g] = swz(wm + li, 2 * g + lh);
+        fr_b[g] = swz(wn + li, 2 * g + lh);
+    }
+
     const T *a_src[A_LD];
     const T *b_src[B_LD];
+    unsigned a_vo[A_LD], b_vo[B_LD];              // byte offsets for the scalar-base direct-to-LDS loads
     f4 a_reg[A_LD], b_reg[B_LD];
     const f4 zero4 = f4{ 0.f, 0.f, 0.f, 0.f };
 
@@ -106,12 +130,14 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void pw_gemm(PwArgs a)
             long gm = m0 + st_row[p];
             if (gm >= a.m) gm = a.m - 1;             // clamp: rows past M are computed but never stored
             a_src[p] = gin + gm * a.k + (GLDS ? ((st_ch ^ (st_row[p] >> 1)) & 7) : st_ch) * EPC;
+            a_vo[p] = (unsigned)((gm * a.k + ((st_ch ^ (st_row[p] >> 1)) & 7) * EPC) * (long)sizeof(T));
         }
 #pragma unroll
         for (int p = 0; p < B_LD; p++) {
             int gn = n0 + st_row[p];
             if (gn >= a.n) gn = a.n - 1;
             b_src[p] = gfilt + (long)gn * a.k + (GLDS ? ((st_ch ^ (st_row[p] >> 1)) & 7) : st_ch) * EPC;
+            b_vo[p] = (unsigned)(((long)gn * a.k + ((st_ch ^ (st_row[p] >> 1)) & 7) * EPC) * (long)sizeof(T));
         }
     };
     auto stage_load = [&](int k0) {
@@ -148,6 +174,19 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void pw_gemm(PwArgs a)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(b_src[p] + k0),
                                              (__attribute__((address_space(3))) void *)(base + BM * BKF + (p * (NT / 8) + wave_u * 8) * BKF),
                                              16, 0, 0);
+    };
+
+    // Direct-to-LDS staging, buffer form (buffer_load_dwordx4 ... lds): descriptor + per-lane 32-bit byte offset fixed for
+    // the tile + scalar offset along K — no vector address arithmetic in the k-loop, and (unlike global_load_lds, which
+    // LLVM tracks as a "flat" access) an outstanding load does not turn every later LDS wait into lgkmcnt(0).
+    // Needs M*K*sizeof(T) and N*K*sizeof(T) below 4 GiB (mbn_launch_f32_pointwise checks).
+    const unsigned a_bytes = a.loop2 ? (unsigned)(a.m * a.k * (long)sizeof(T)) : 0u;
+    const unsigned b_bytes = a.loop2 ? (unsigned)((long)a.n * a.k * (long)sizeof(T)) : 0u;
+    auto stage_glds2 = [&](int k0, int buf) __attribute__((always_inline)) {
+        float *base = lds + buf * (BM + BN) * BKF;
+        const int kb = k0 * (int)sizeof(T);                      // scalar byte offset along K
+        lds_dma_rows(a.in, a_bytes, base, a_vo, kb, wave_u, A_LD, NT);
+        lds_dma_rows(a.filt, b_bytes, base + BM * BKF, b_vo, kb, wave_u, B_LD, NT);
     };
 
     long m0;
@@ -200,7 +239,76 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void pw_gemm(PwArgs a)
         // ---- K loop of this tile (registers — or, with GLDS, LDS buffer 0 in flight — hold its k-tile 0 on entry)
         if (!GLDS) stage_store(0);
         __syncthreads();              // with a glds outstanding hipcc emits s_waitcnt vmcnt(0) ahead of the barrier
-        if (GLDS) {
+        if (GLDS && a.loop2) {
+            // Software-pipelined form (default): the LDS fragments of group g+1 are requested before the MFMAs of group g
+            // — for the last group of a k-tile that is group 0 of the next buffer, right behind the hand-over barrier — so
+            // no MFMA waits for its own ds_read. The buffer index is a compile-time constant (two k-tiles per trip), which
+            // turns every fragment address into per-lane base + immediate: no VALU in the loop (VALU time does not
+            // overlap fp32 MFMA time on a SIMD, tools/micro/).
+            f4 fa[2][MI], fb[2][NI];
+            auto ldfrag = [&](const float *base, int g, int slot) __attribute__((always_inline)) {
+#pragma unroll
+                for (int mi = 0; mi < MI; mi++) fa[slot][mi] = *reinterpret_cast<const f4 *>(base + fr_a[g] + mi * 32 * BKF);
+#pragma unroll
+                for (int ni = 0; ni < NI; ni++) fb[slot][ni] = *reinterpret_cast<const f4 *>(base + BM * BKF + fr_b[g] + ni * 32 * BKF);
+            };
+            auto mfma_group = [&](int slot) __attribute__((always_inline)) {
+                if constexpr (BF) {
+#pragma unroll
+                    for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ni++)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                __builtin_bit_cast(bf8, fa[slot][mi]), __builtin_bit_cast(bf8, fb[slot][ni]), acc[mi][ni], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 4; s++)
+#pragma unroll
+                        for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+                            for (int ni = 0; ni < NI; ni++)
+                                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][mi][s], fb[slot][ni][s], acc[mi][ni], 0, 0, 0);
+                }
+            };
+            // one k-tile from buffer CUR; NEXT: stage the following k-tile into the other buffer and hand over to it.
+            // (CUR and NEXT are literal constants at every call site; the always_inline lambdas fold them. The barrier sits
+            // between the two halves in the kernel body itself: a lambda may not call __syncthreads in the host pass.)
+            auto ktile_head = [&](const int CUR, const bool NEXT, int kt) __attribute__((always_inline)) {
+                const float *base = lds + CUR * (BM + BN) * BKF;
+                if (NEXT) stage_glds2((kt + 1) * BKE, CUR ^ 1);
+#pragma unroll
+                for (int g = 0; g < 3; g++) {
+                    ldfrag(base, g + 1, (g + 1) & 1);
+                    __builtin_amdgcn_sched_barrier(0);      // keep the fragment requests ahead of the MFMAs they overlap
+                    mfma_group(g & 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            auto ktile_tail = [&](const int CUR, const bool NEXT) __attribute__((always_inline)) {
+                if (NEXT) ldfrag(lds + (CUR ^ 1) * (BM + BN) * BKF, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_group(1);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            // nk is even here (mbn_launch_f32_pointwise): steady state = two k-tiles per trip, straight-line; last pair peeled.
+            // Each barrier: the next buffer has landed (vmcnt(0) ahead of it) and this one is fully read.
+            ldfrag(lds, 0, 0);
+            int kt = 0;
+            for (; kt + 2 < nk; kt += 2) {
+                ktile_head(0, true, kt);
+                __syncthreads();
+                ktile_tail(0, true);
+                ktile_head(1, true, kt + 1);
+                __syncthreads();
+                ktile_tail(1, true);
+            }
+            ktile_head(0, true, kt);
+            __syncthreads();
+            ktile_tail(0, true);
+            ktile_head(1, false, kt + 1);
+            __syncthreads();
+            ktile_tail(1, false);
+        } else if (GLDS) {
             for (int kt = 0; kt < nk; kt++) {
                 const int cur = kt & 1;
                 if (kt + 1 < nk) stage_glds((kt + 1) * BKE, cur ^ 1);
@@ -335,6 +443,8 @@ int mbn_launch_f32_pointwise(const mbn_call &c, void *out, const void *in, const
     a.out = out; a.in = in; a.filt = filt; a.scale = c.scale; a.shift = c.shift;
     a.m = m; a.k = cin; a.n = op_size; a.act = c.act; a.mt = a.nt = 0;
     a.out_f32 = bf && (c.io_flags & MBN_IO_OUT_F32) ? 1 : 0;
+    a.loop2 = (g_mbn_tune.conv_variant == 8 || ((cin / (bf ? 64 : 32)) & 1) || (cin % (bf ? 64 : 32)) ||
+               (double)m * cin * (bf ? 2 : 4) >= 4294967296.0 || (double)op_size * cin * (bf ? 2 : 4) >= 4294967296.0) ? 0 : 1;
     a.fast_epi = (g_mbn_tune.conv_variant == 9 || (double)m * op_size * 4.0 >= 4294967296.0) ? 0 : 1;   // buffer stores: < 4 GiB
     if (m <= 0 || (long)((m + 31) / 32) * ((op_size + 31) / 32) > 0x7fffffffL) return MBN_EINVAL;
     const int epc = bf ? 8 : 4;
