@@ -59,12 +59,16 @@ def layer_weight_bytes(l, pkg, act_bytes=4.0):
     return 0.0
 
 
-def load_traffic():
+def load_traffic(layers=None):
     """HBM bytes per launch of the dominant kernel from the PMC counters (FETCH_SIZE x2 on gfx950 + WRITE_SIZE), measured
     in separate rocprofv3 --pmc passes of this same workload (tools/pmc_pass.sh) and committed under profiles/.
-    bench.py cannot run the profiler on itself, so it reports the committed measurement, or null when there is none."""
+    bench.py cannot run the profiler on itself, so it reports the committed measurement — averaged over the pointwise
+    layers that are separate launches in this run — or null when there is none."""
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["pointwise_avg_bytes_per_launch"]
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        if layers:
+            return sum(t["pointwise_layers"][str(l)]["bytes"] for l in layers) / len(layers)
+        return t["pointwise_avg_bytes_per_launch"]
     except Exception:
         return None
 
@@ -291,7 +295,7 @@ def main():
                     "kernel": "pw_gemm<float> (%d pointwise 1x1 conv launches per step)" % len(pw_idx),
                     "bound": "mfma", "achieved": round(flops_per_launch / avg_ms / 1e9, 2), "peak": MFMA_F32_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(flops_per_launch / avg_ms / 1e9 / MFMA_F32_PEAK_TFLOPS, 4),
-                    "traffic": load_traffic(), "avg_launch_ms": round(avg_ms, 5),
+                    "traffic": load_traffic([i + 1 for i in pw_idx]), "avg_launch_ms": round(avg_ms, 5),
                     "algorithmic_flops_per_launch": flops_per_launch,
                     "algorithmic_bytes_per_launch": bytes_per_launch,
                 }

@@ -456,13 +456,15 @@ int mbn_launch_f32_pointwise(const mbn_call &c, void *out, const void *in, const
         else hipLaunchKernelGGL(pw_generic<float>, grid, dim3(256), 0, c.stream, a);
         return MBN_OK;
     }
-    // Tile choice measured per layer on MI355X in fp32 (tools/layer_bench.py --tune pw_tile=1..8, profiles/r01): every
-    // shape lands within a few % of each other (the loop is matrix-pipe bound), <128,64> with 3 workgroups per CU is
-    // best or tied from K = 256 up, 8 waves of 32x64 win slightly for K <= 256, 64x64 for narrow outputs / small grids.
+    // Tile choice measured per layer on MI355X in fp32 with the software-pipelined loop (tools/layer_bench.py --tune
+    // pw_tile=1..8, profiles/r01/e_gemm_tile_sweep_pipelined.txt): 64x64 tiles at 4 workgroups per CU are best from
+    // K = 512 up and for K = 256 with wide outputs (133 TFLOP/s = 85 % of the fp32 matrix peak on the 512 -> 512 layers),
+    // 8 waves of 32x64 on a 128x128 tile win slightly for K <= 256, <128,64> in between; small grids take 64x64 too.
     int tile = g_mbn_tune.pw_tile;
     if (tile == 0) {
         const long big_tiles = ((m + 127) / 128) * ((op_size + 63) / 64);
         if (big_tiles < 2L * c.ctx->num_cus || op_size <= 64 || m <= 16384) tile = 3;   // 7x7 layers: finer tiles balance better
+        else if (!bf && (cin >= 512 || (cin >= 256 && op_size >= 512))) tile = 3;
         else if (cin <= 256 && op_size >= 128) tile = 5;
         else tile = 2;
     }

@@ -22,7 +22,18 @@ def per_dispatch(d, counter):
     return [(r["Kernel_Name"].split("(")[0][-60:], float(r["Counter_Value"])) for r in rows]
 
 
+def combine():
+    """make_traffic.py combine <pointwise.json> <depthwise.json> > profiles/traffic.json"""
+    pw, dw = json.load(open(sys.argv[2])), json.load(open(sys.argv[3]))
+    print(json.dumps({"workload": "MobileNet-V1 1.0x224 fp32, batch 256 (tools/layer_bench.py), MI355X", "method": pw["method"],
+                      "pointwise_avg_bytes_per_launch": pw["avg_bytes_per_launch"],
+                      "depthwise_avg_bytes_per_launch": dw["avg_bytes_per_launch"],
+                      "pointwise_layers": pw["layers"], "depthwise_layers": dw["layers"]}, indent=1))
+
+
 def main():
+    if sys.argv[1] == "combine":
+        return combine()
     fdir, wdir, layers, per = sys.argv[1], sys.argv[2], [int(x) for x in sys.argv[3].split(",")], int(sys.argv[4])
     fe, wr = per_dispatch(fdir, "FETCH_SIZE"), per_dispatch(wdir, "WRITE_SIZE")
     assert len(fe) == len(wr) == per * len(layers), (len(fe), len(wr), per, len(layers))
