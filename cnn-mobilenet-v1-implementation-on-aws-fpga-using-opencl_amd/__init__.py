@@ -24,7 +24,7 @@ HEADER = os.path.join(REPO_ROOT, "include", "mbn.h")
 OK, EINVAL, ENOMEM, EDEVICE, EIO, EFORMAT, ENOTFOUND, ESHAPE, EUNSUPPORTED, ENODEVICE = 0, -1, -2, -3, -4, -5, -6, -7, -8, -9
 DT_U8, DT_F32, DT_BF16 = 0, 1, 2
 LAYOUT_NCHW_PLANAR, LAYOUT_NHWC = 0, 1
-IO_IN_F32, IO_OUT_F32 = 1, 2
+IO_IN_F32, IO_OUT_F32, IO_IN_U8 = 1, 2, 4
 ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
 Q_CARRY_SUM, Q_DW_PLANE0, Q_LITERAL_INDEX, Q_POOL_DIV49 = 1, 2, 4, 8
 QUIRKS_NONE, QUIRKS_KERNEL_CL = 0, 0xF
@@ -156,9 +156,14 @@ def load():
         lib.mbn_net_set_fuse_stem.argtypes = [vp, ci]
         lib.mbn_net_fused_layers.argtypes = [vp, ci, C.POINTER(ci)]
         lib.mbn_net_set_fuse_blocks.argtypes = [vp, C.c_uint]
+        lib.mbn_net_classify.argtypes = [vp, vp, ci, ci, vp, vp]
         lib.mbn_net_launches.argtypes = [vp, ci, ci, C.POINTER(ci), C.POINTER(ci), ci, C.POINTER(ci)]
         lib.mbn_stem_fused.argtypes = [vp] + [vp] * 11 + [ci, ci, ci, ci, vp]
+        lib.mbn_stem_fused_u8.argtypes = [vp] + [vp] * 11 + [ci, ci, ci, ci, vp]
+        lib.mbn_net_set_input_u8.argtypes = [vp, ci]
         lib.mbn_dwpw_fused.argtypes = [vp] + [vp] * 8 + [ci] * 10 + [vp]
+        lib.mbn_softmax_topk_f32.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, vp]
+        lib.mbn_classifier_tail.argtypes = [vp] * 9 + [ci] * 6 + [vp]
         lib.mbn_graph_begin.argtypes = [vp, vp]
         lib.mbn_graph_end.argtypes = [vp, vp, C.POINTER(vp)]
         lib.mbn_graph_launch.argtypes = [vp, vp, vp]
@@ -390,6 +395,12 @@ class Net:
         n = C.c_int()
         _chk(self.ctx.lib.mbn_net_fused_layers(self.h, last_layer, C.byref(n)))
         return n.value
+
+    def classify(self, images_dev, batch, k, topk_idx_dev, topk_prob_dev):
+        _chk(self.ctx.lib.mbn_net_classify(self.h, images_dev, batch, k, topk_idx_dev, topk_prob_dev), self.ctx.last_error())
+
+    def set_input_u8(self, enabled=True):
+        _chk(self.ctx.lib.mbn_net_set_input_u8(self.h, int(enabled)))
 
     def set_fuse_blocks(self, mask):
         _chk(self.ctx.lib.mbn_net_set_fuse_blocks(self.h, int(mask)))

@@ -370,9 +370,10 @@ int resolve(mbn_context *ctx, const mbn_layer_ext *ext, mbn_call *c, int *dtype)
     if (ext->dtype != MBN_DT_U8 && ext->dtype != MBN_DT_F32 && ext->dtype != MBN_DT_BF16) return MBN_EINVAL;
     if (ext->dtype == MBN_DT_U8 && ext->layout != MBN_LAYOUT_NCHW_PLANAR) return MBN_EUNSUPPORTED;
     if (ext->dtype != MBN_DT_U8 && ext->layout != MBN_LAYOUT_NHWC) return MBN_EUNSUPPORTED;
-    if (ext->io_flags & ~(MBN_IO_IN_F32 | MBN_IO_OUT_F32)) return MBN_EINVAL;
+    if (ext->io_flags & ~(MBN_IO_IN_F32 | MBN_IO_OUT_F32 | MBN_IO_IN_U8)) return MBN_EINVAL;
     c->dtype = ext->dtype;
-    c->io_flags = ext->dtype == MBN_DT_BF16 ? ext->io_flags : 0;
+    // IN_F32 / OUT_F32 only mean something in bf16 mode; IN_U8 (raw image into convolute) applies to fp32 and bf16
+    c->io_flags = ext->dtype == MBN_DT_BF16 ? ext->io_flags : (ext->io_flags & MBN_IO_IN_U8);
     if (ext->batch < 0) return MBN_EINVAL;
     c->batch = ext->batch > 0 ? ext->batch : 1;
     if (ext->act < MBN_ACT_NONE || ext->act > MBN_ACT_RELU6) return MBN_EINVAL;
@@ -486,9 +487,43 @@ int mbn_softmax_f32(mbn_context *ctx, void *probs, void *argmax_i32, const void 
                                             classes));
 }
 
-int mbn_stem_fused(mbn_context *ctx, void *out, const void *image, const void *w1, const void *s1, const void *b1,
-                   const void *wd, const void *s2, const void *b2, const void *wp, const void *s3, const void *b3,
-                   int batch, int res, int c1, int c3, void *stream)
+int mbn_softmax_topk_f32(mbn_context *ctx, void *probs, void *topk_idx_i32, void *topk_prob_f32, const void *logits,
+                         int batch, int classes, int k, void *stream)
+{
+    if (!ctx || !logits || !topk_idx_i32 || !topk_prob_f32 || batch <= 0 || classes <= 0 || k < 1 || k > 8) return MBN_EINVAL;
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    Scope sc(ctx, s);
+    return sc.finish(mbn_launch_f32_softmax_topk(ctx, s, (float *)probs, (int32_t *)topk_idx_i32, (float *)topk_prob_f32,
+                                                 (const float *)logits, batch, classes, k));
+}
+
+int mbn_classifier_tail(mbn_context *ctx, void *topk_idx_i32, void *topk_prob_f32, void *probs, void *logits_scratch,
+                        void *pooled_scratch, const void *in, const void *fc_w, const void *fc_bias, int batch, int rows,
+                        int cols, int channels, int classes, int k, void *stream)
+{
+    if (!ctx || !topk_idx_i32 || !topk_prob_f32 || !logits_scratch || !pooled_scratch || !in || !fc_w || batch <= 0 ||
+        rows <= 0 || rows != cols || channels <= 0 || classes <= 0 || k < 1 || k > 8)
+        return MBN_EINVAL;
+    mbn_layer_ext e;
+    memset(&e, 0, sizeof e);
+    e.struct_size = sizeof e;
+    e.batch = batch;
+    e.dtype = MBN_DT_F32;
+    e.layout = MBN_LAYOUT_NHWC;
+    e.act = MBN_ACT_NONE;
+    e.pad_top = e.pad_left = -1;
+    e.stream = stream;
+    int rc = mbn_pool(ctx, pooled_scratch, in, rows, cols, rows, channels, &e);           // MobileNet.c:2603-2656
+    if (rc != MBN_OK) return rc;
+    e.shift = fc_bias;                                                                     // bias, no ReLU (B15)
+    rc = mbn_pointwise(ctx, logits_scratch, pooled_scratch, fc_w, 1, 1, channels, classes, &e);   // MobileNet.c:2682-2739
+    if (rc != MBN_OK) return rc;
+    return mbn_softmax_topk_f32(ctx, probs, topk_idx_i32, topk_prob_f32, logits_scratch, batch, classes, k, stream);
+}
+
+static int stem_fused_impl(mbn_context *ctx, void *out, const void *image, const void *w1, const void *s1, const void *b1,
+                           const void *wd, const void *s2, const void *b2, const void *wp, const void *s3, const void *b3,
+                           int batch, int res, int c1, int c3, void *stream, int in_u8)
 {
     if (!ctx || !out || !image) return MBN_EINVAL;
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
@@ -497,7 +532,21 @@ int mbn_stem_fused(mbn_context *ctx, void *out, const void *image, const void *w
     Scope sc(ctx, s);
     return sc.finish(mbn_launch_f32_stem(ctx, s, (float *)out, (const float *)image, (const float *)w1, (const float *)s1,
                                          (const float *)b1, (const float *)wd, (const float *)s2, (const float *)b2,
-                                         (const float *)wp, (const float *)s3, (const float *)b3, batch, res, c1, c3));
+                                         (const float *)wp, (const float *)s3, (const float *)b3, batch, res, c1, c3, in_u8));
+}
+
+int mbn_stem_fused(mbn_context *ctx, void *out, const void *image, const void *w1, const void *s1, const void *b1,
+                   const void *wd, const void *s2, const void *b2, const void *wp, const void *s3, const void *b3,
+                   int batch, int res, int c1, int c3, void *stream)
+{
+    return stem_fused_impl(ctx, out, image, w1, s1, b1, wd, s2, b2, wp, s3, b3, batch, res, c1, c3, stream, 0);
+}
+
+int mbn_stem_fused_u8(mbn_context *ctx, void *out, const void *image_u8, const void *w1, const void *s1, const void *b1,
+                      const void *wd, const void *s2, const void *b2, const void *wp, const void *s3, const void *b3,
+                      int batch, int res, int c1, int c3, void *stream)
+{
+    return stem_fused_impl(ctx, out, image_u8, w1, s1, b1, wd, s2, b2, wp, s3, b3, batch, res, c1, c3, stream, 1);
 }
 
 int mbn_dwpw_fused(mbn_context *ctx, void *out, const void *in, const void *wd, const void *s2, const void *b2,

@@ -21,7 +21,14 @@ struct ConvArgs {
     const float *in, *filt, *scale, *shift;
     int batch, rows, cols, cin, fs, stride, orow, ocol, cout, pad_top, pad_left, act;
     long total;   // batch*orow*ocol*(cout/4)
+    const uint8_t *in8;   // MBN_IO_IN_U8: the raw uint8 HWC image instead of `in`, normalised at load (x/127.5 - 1)
 };
+
+// Input element i of the image tensor: fp32 as stored, or uint8 with the Keras MobileNet preprocessing applied — the same
+// fmaf as normalize_u8_f32, so conv(u8) == conv(normalize(u8)) bit for bit.
+constexpr float NORM_SCALE = 1.0f / 127.5f, NORM_BIAS = -1.0f;
+__device__ __forceinline__ float norm_u8(unsigned v) { return fmaf((float)v, NORM_SCALE, NORM_BIAS); }
+__device__ __forceinline__ float ld_in(const ConvArgs &a, long i) { return a.in8 ? norm_u8(a.in8[i]) : a.in[i]; }
 
 // One lane = 4 consecutive output channels of one output pixel; the cout/4 lanes of a pixel are adjacent, so a
 // wave's store is one contiguous span of the NHWC output (the 73 % of this stage's traffic). Input taps of a pixel
@@ -44,7 +51,7 @@ __global__ __launch_bounds__(256) void conv_f32_nhwc(ConvArgs a)
     q /= a.ocol;
     const int oy = (int)(q % a.orow);
     const int n = (int)(q / a.orow);
-    const float *img = a.in + (long)n * a.rows * a.cols * a.cin;
+    const long img = (long)n * a.rows * a.cols * a.cin;
     f4 acc = f4{ 0.f, 0.f, 0.f, 0.f };
     for (int ky = 0; ky < a.fs; ky++) {
         const int iy = oy * a.stride + ky - a.pad_top;
@@ -52,10 +59,10 @@ __global__ __launch_bounds__(256) void conv_f32_nhwc(ConvArgs a)
         for (int kx = 0; kx < a.fs; kx++) {
             const int ix = ox * a.stride + kx - a.pad_left;
             if (ix < 0 || ix >= a.cols) continue;
-            const float *ip = img + ((long)iy * a.cols + ix) * a.cin;
+            const long ip = img + ((long)iy * a.cols + ix) * a.cin;
             const float *wp = wlds + (long)((ky * a.fs + kx) * a.cin) * a.cout + oc;
             for (int ci = 0; ci < a.cin; ci++) {
-                const float v = ip[ci];
+                const float v = ld_in(a, ip + ci);
                 const f4 w = *reinterpret_cast<const f4 *>(wp + (long)ci * a.cout);
                 acc.x = fmaf(v, w.x, acc.x); acc.y = fmaf(v, w.y, acc.y);
                 acc.z = fmaf(v, w.z, acc.z); acc.w = fmaf(v, w.w, acc.w);
@@ -101,7 +108,7 @@ __global__ __launch_bounds__(256) void conv3x3s2c3_f32_nhwc(ConvArgs a)
     q /= gcols;
     const int oy = (int)(q % a.orow);
     const int n = (int)(q / a.orow);
-    const float *img = a.in + (long)n * a.rows * a.cols * 3;
+    const long img = (long)n * a.rows * a.cols * 3;
     const int ix0 = ox0 * 2;                       // pad_left == 0 on this path
     const bool last_ok = ix0 + 2 * PX < a.cols;    // the 9th pixel is the right zero-pad column for the last group
     f4 acc[PX];
@@ -111,16 +118,30 @@ __global__ __launch_bounds__(256) void conv3x3s2c3_f32_nhwc(ConvArgs a)
     for (int ky = 0; ky < 3; ky++) {
         const int iy = oy * 2 + ky - a.pad_top;
         if (iy < 0 || iy >= a.rows) continue;      // wave-uniform except across the oy boundary of a wave
-        const float *row = img + ((long)iy * a.cols + ix0) * 3;
+        const long rowi = img + ((long)iy * a.cols + ix0) * 3;
         float v[27];
+        if (a.in8) {                               // 27 contiguous bytes: 6 aligned dwords (cols % 4 == 0) + 3 bytes
+            const uint8_t *row8 = a.in8 + rowi;
 #pragma unroll
-        for (int j = 0; j < 6; j++) {
-            const f4 x = *reinterpret_cast<const f4 *>(row + 4 * j);
-            v[4 * j] = x.x; v[4 * j + 1] = x.y; v[4 * j + 2] = x.z; v[4 * j + 3] = x.w;
+            for (int j = 0; j < 6; j++) {
+                const unsigned x = *reinterpret_cast<const unsigned *>(row8 + 4 * j);
+                v[4 * j] = norm_u8(x & 0xff); v[4 * j + 1] = norm_u8((x >> 8) & 0xff);
+                v[4 * j + 2] = norm_u8((x >> 16) & 0xff); v[4 * j + 3] = norm_u8(x >> 24);
+            }
+            v[24] = last_ok ? norm_u8(row8[24]) : 0.f;
+            v[25] = last_ok ? norm_u8(row8[25]) : 0.f;
+            v[26] = last_ok ? norm_u8(row8[26]) : 0.f;
+        } else {
+            const float *row = a.in + rowi;
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                const f4 x = *reinterpret_cast<const f4 *>(row + 4 * j);
+                v[4 * j] = x.x; v[4 * j + 1] = x.y; v[4 * j + 2] = x.z; v[4 * j + 3] = x.w;
+            }
+            v[24] = last_ok ? row[24] : 0.f;
+            v[25] = last_ok ? row[25] : 0.f;
+            v[26] = last_ok ? row[26] : 0.f;
         }
-        v[24] = last_ok ? row[24] : 0.f;
-        v[25] = last_ok ? row[25] : 0.f;
-        v[26] = last_ok ? row[26] : 0.f;
 #pragma unroll
         for (int kx = 0; kx < 3; kx++)
 #pragma unroll
@@ -164,7 +185,7 @@ __global__ __launch_bounds__(256) void conv_generic_f32_nhwc(ConvArgs a)
     q /= a.ocol;
     const int oy = (int)(q % a.orow);
     const int n = (int)(q / a.orow);
-    const float *img = a.in + (long)n * a.rows * a.cols * a.cin;
+    const long img = (long)n * a.rows * a.cols * a.cin;
     float acc = 0.f;
     for (int ky = 0; ky < a.fs; ky++) {
         const int iy = oy * a.stride + ky - a.pad_top;
@@ -173,7 +194,7 @@ __global__ __launch_bounds__(256) void conv_generic_f32_nhwc(ConvArgs a)
             const int ix = ox * a.stride + kx - a.pad_left;
             if (ix < 0 || ix >= a.cols) continue;
             for (int ci = 0; ci < a.cin; ci++)
-                acc = fmaf(img[((long)iy * a.cols + ix) * a.cin + ci],
+                acc = fmaf(ld_in(a, img + ((long)iy * a.cols + ix) * a.cin + ci),
                            a.filt[((long)(ky * a.fs + kx) * a.cin + ci) * a.cout + oc], acc);
         }
     }
@@ -235,6 +256,59 @@ __global__ __launch_bounds__(256) void softmax_f32(float *__restrict__ probs, in
     if (argmax && tid == 0) argmax[n] = am;
 }
 
+// softmax + top-k per image (k <= 8): one workgroup per image. The k winners are found by k block-wide arg-max passes
+// over the logits in the total order (value descending, index ascending) — pass j only admits entries strictly after
+// pass j-1's winner in that order, so ties resolve to the lowest index like the oracle's strict '>' scan and no
+// "taken" list is needed. probs (may be NULL) gets the full distribution; topk_prob the winners' probabilities.
+__global__ __launch_bounds__(256) void softmax_topk_f32(float *__restrict__ probs, int *__restrict__ topk_idx,
+                                                        float *__restrict__ topk_prob, const float *__restrict__ logits,
+                                                        int classes, int k)
+{
+    __shared__ float s_val[4];
+    __shared__ int s_idx[4];
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *l = logits + (long)n * classes;
+    float pv = INFINITY, mx = 0.f, sum = 0.f;     // previous winner (value, index); +inf admits everything
+    int pi = -1;
+    for (int j = 0; j < k; j++) {
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int c = tid; c < classes; c += 256) {
+            const float v = l[c];
+            const bool admitted = v < pv || (v == pv && c > pi);
+            if (admitted && (v > bv || (v == bv && c < bi))) { bv = v; bi = c; }
+        }
+        for (int d = 32; d >= 1; d >>= 1) {
+            const float ov = __shfl_xor(bv, d, 64);
+            const int oi = __shfl_xor(bi, d, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { s_val[wave] = bv; s_idx[wave] = bi; }
+        __syncthreads();
+        bv = s_val[0]; bi = s_idx[0];
+        for (int w = 1; w < 4; w++)
+            if (s_val[w] > bv || (s_val[w] == bv && s_idx[w] < bi)) { bv = s_val[w]; bi = s_idx[w]; }
+        __syncthreads();
+        if (j == 0) {                              // the first winner is the maximum: normaliser of the softmax
+            mx = bv;
+            for (int c = tid; c < classes; c += 256) sum += expf(l[c] - mx);
+            for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
+            if (lane == 0) s_val[wave] = sum;
+            __syncthreads();
+            sum = s_val[0] + s_val[1] + s_val[2] + s_val[3];
+            __syncthreads();
+            if (probs)
+                for (int c = tid; c < classes; c += 256) probs[(long)n * classes + c] = expf(l[c] - mx) / sum;
+        }
+        if (tid == 0) {
+            const bool found = bi != 0x7fffffff;   // fewer than k classes
+            topk_idx[(long)n * k + j] = found ? bi : -1;
+            topk_prob[(long)n * k + j] = found ? expf(bv - mx) / sum : 0.f;
+        }
+        pv = bv; pi = bi;
+    }
+}
+
 __global__ __launch_bounds__(256) void normalize_u8_f32(float *__restrict__ out, const uint8_t *__restrict__ in,
                                                         size_t count, float scale, float bias)
 {
@@ -281,9 +355,11 @@ int mbn_launch_f32_conv(const mbn_call &c, void *out, const void *in_v, const fl
                         int stride, int op_size)
 {
     const bool bf = c.dtype == MBN_DT_BF16;
-    if (bf && !(c.io_flags & MBN_IO_IN_F32)) return MBN_EUNSUPPORTED;   // the first layer reads the fp32 image
+    const bool u8in = (c.io_flags & MBN_IO_IN_U8) != 0;
+    if (bf && !(c.io_flags & (MBN_IO_IN_F32 | MBN_IO_IN_U8))) return MBN_EUNSUPPORTED;   // the first layer reads the fp32 or raw image
     const float *in = (const float *)in_v;
     ConvArgs a;
+    a.in8 = u8in ? (const uint8_t *)in_v : nullptr;
     a.out = out; a.in = in; a.filt = filt; a.scale = c.scale; a.shift = c.shift;
     a.batch = c.batch; a.rows = rows; a.cols = cols; a.cin = c.cin; a.fs = fs; a.stride = stride;
     a.orow = (rows + stride - 1) / stride; a.ocol = (cols + stride - 1) / stride; a.cout = op_size;
@@ -295,7 +371,7 @@ int mbn_launch_f32_conv(const mbn_call &c, void *out, const void *in_v, const fl
                       ((uintptr_t)filt % 16) == 0 && (!c.scale || ((uintptr_t)c.scale % 16) == 0) &&
                       (!c.shift || ((uintptr_t)c.shift % 16) == 0);
     const bool first_layer = fast && fs == 3 && c.cin == 3 && stride == 2 && a.pad_left == 0 && (cols % 4) == 0 &&
-                             (a.ocol % 4) == 0 && 2 * a.ocol == cols && ((uintptr_t)in % 16) == 0 &&
+                             (a.ocol % 4) == 0 && 2 * a.ocol == cols && ((uintptr_t)in % (u8in ? 4 : 16)) == 0 &&
                              g_mbn_tune.conv_variant != 1;
     if (first_layer) {
         a.total = (long)c.batch * a.orow * (a.ocol / 4) * (op_size / 4);
@@ -335,6 +411,14 @@ int mbn_launch_f32_softmax(mbn_context *, hipStream_t s, float *probs, int32_t *
                            int classes)
 {
     hipLaunchKernelGGL(softmax_f32, dim3(batch), dim3(256), 0, s, probs, argmax, logits, classes);
+    return MBN_OK;
+}
+
+int mbn_launch_f32_softmax_topk(mbn_context *, hipStream_t s, float *probs, int32_t *topk_idx, float *topk_prob,
+                                const float *logits, int batch, int classes, int k)
+{
+    if (k < 1 || k > 8) return MBN_EINVAL;
+    hipLaunchKernelGGL(softmax_topk_f32, dim3((unsigned)batch), dim3(256), 0, s, probs, topk_idx, topk_prob, logits, classes, k);
     return MBN_OK;
 }
 

@@ -34,6 +34,7 @@ constexpr int C1 = 32, C3 = 64;
 struct StemArgs {
     float *out;
     const float *in, *w1, *s1, *b1, *wd, *s2, *b2, *wp, *s3, *b3;
+    const uint8_t *in8;         // raw uint8 HWC image instead of `in`: normalised at load, x/127.5 - 1 (MBN_IO_IN_U8)
     int batch, res, h;          // input side, conv1/dw/pw side (res/2)
     int tiles_y, tiles_x;
     long ntiles;
@@ -61,15 +62,20 @@ __device__ __forceinline__ void patch_load(const StemArgs &a, long t, int tid, f
     const long q0 = t / a.tiles_x;
     const int ty = (int)(q0 % a.tiles_y);
     const long n = q0 / a.tiles_y;
-    const float *img = a.in + n * a.res * a.res * 3;
+    const long img = n * a.res * a.res * 3;
     const int iy0 = 2 * (TH * ty - 1), fx0 = 6 * (TW * tx - 1), rowf = a.res * 3;
 #pragma unroll
     for (int k = 0; k < NPF; k++) {
         const int i = tid + k * 256, r = i / PAIRS, j = i % PAIRS;
         const int iy = iy0 + r, fx = fx0 + 2 * j;
-        f2 v = f2{ 0.f, 0.f };
-        if (i < PR * PAIRS && iy >= 0 && iy < a.res && fx >= 0 && fx < rowf)
-            v = *reinterpret_cast<const f2 *>(img + (long)iy * rowf + fx);
+        f2 v = f2{ 0.f, 0.f };                                            // the zero padding is zero AFTER normalisation
+        if (i < PR * PAIRS && iy >= 0 && iy < a.res && fx >= 0 && fx < rowf) {
+            const long e = img + (long)iy * rowf + fx;
+            if (a.in8) {                                                  // same fmaf as normalize_u8_f32: bit-identical
+                const unsigned u = *reinterpret_cast<const unsigned short *>(a.in8 + e);
+                v = f2{ fmaf((float)(u & 0xff), 1.0f / 127.5f, -1.0f), fmaf((float)(u >> 8), 1.0f / 127.5f, -1.0f) };
+            } else v = *reinterpret_cast<const f2 *>(a.in + e);
+        }
         pf[k] = v;
     }
 }
@@ -223,14 +229,15 @@ __global__ __launch_bounds__(256, 2) void stem_fused_f32(StemArgs a)   // 2 wave
 // layers separately).
 int mbn_launch_f32_stem(mbn_context *ctx, hipStream_t stream, float *out, const float *in, const float *w1,
                         const float *s1, const float *b1, const float *wd, const float *s2, const float *b2,
-                        const float *wp, const float *s3, const float *b3, int batch, int res, int c1, int c3)
+                        const float *wp, const float *s3, const float *b3, int batch, int res, int c1, int c3, int in_u8)
 {
     if (c1 != C1 || c3 != C3 || res < 32 || (res % 32) != 0 || batch <= 0) return MBN_EUNSUPPORTED;
     const float *ptrs[] = { w1, s1, b1, wd, s2, b2, wp, s3, b3 };
     for (const float *p : ptrs)
         if (!p || ((uintptr_t)p % 16) != 0) return MBN_EUNSUPPORTED;
-    if (!out || !in || ((uintptr_t)out % 16) != 0 || ((uintptr_t)in % 8) != 0) return MBN_EINVAL;
+    if (!out || !in || ((uintptr_t)out % 16) != 0 || ((uintptr_t)in % (in_u8 ? 2 : 8)) != 0) return MBN_EINVAL;
     StemArgs a;
+    a.in8 = in_u8 ? (const uint8_t *)in : nullptr;
     a.out = out; a.in = in; a.w1 = w1; a.s1 = s1; a.b1 = b1; a.wd = wd; a.s2 = s2; a.b2 = b2; a.wp = wp; a.s3 = s3; a.b3 = b3;
     a.batch = batch; a.res = res; a.h = res / 2;
     a.tiles_y = a.h / TH; a.tiles_x = a.h / TW;

@@ -68,7 +68,7 @@ struct mbn_call {
     uint32_t quirks;
     const float *scale, *shift;
     int dtype;        // MBN_DT_F32 or MBN_DT_BF16 for the NHWC launchers (storage type of activations)
-    int io_flags;     // MBN_IO_IN_F32 / MBN_IO_OUT_F32 (bf16 mode only)
+    int io_flags;     // MBN_IO_IN_F32 / MBN_IO_OUT_F32 (bf16 mode only), MBN_IO_IN_U8 (convolute)
 };
 
 // ---- launchers implemented in the kernel files; each returns MBN_* and launches on c.stream ----
@@ -98,10 +98,12 @@ int mbn_launch_f32_dwpw(mbn_context *ctx, hipStream_t stream, float *out, const 
                         int pad_left);
 int mbn_launch_f32_stem(mbn_context *ctx, hipStream_t stream, float *out, const float *in, const float *w1,
                         const float *s1, const float *b1, const float *wd, const float *s2, const float *b2,
-                        const float *wp, const float *s3, const float *b3, int batch, int res, int c1, int c3);
+                        const float *wp, const float *s3, const float *b3, int batch, int res, int c1, int c3, int in_u8);
 int mbn_launch_convert(mbn_context *ctx, hipStream_t s, void *dst, const void *src, size_t count, int to_bf16);
 int mbn_launch_f32_softmax(mbn_context *ctx, hipStream_t s, float *probs, int32_t *argmax, const float *logits,
                            int batch, int classes);
+int mbn_launch_f32_softmax_topk(mbn_context *ctx, hipStream_t s, float *probs, int32_t *topk_idx, float *topk_prob,
+                                const float *logits, int batch, int classes, int k);
 int mbn_launch_normalize(mbn_context *ctx, hipStream_t s, float *out, const uint8_t *in, size_t count, float scale,
                          float bias);
 

@@ -24,6 +24,7 @@ struct mbn_net {
     int keep;
     int dtype;                 /* MBN_DT_F32 or MBN_DT_BF16 */
     int fuse_stem;             /* mbn_net_set_fuse_stem (default 1) */
+    int input_u8;              /* mbn_net_set_input_u8: images are raw uint8 HWC */
     unsigned fuse_blocks;      /* mbn_net_set_fuse_blocks: bit L = run the depthwise layer L and the pointwise layer L+1 as one launch */
     int use_graph;             /* mbn_net_set_graph */
     void *graph;               /* instantiated hipGraph of one forward, valid for the key below */
@@ -35,6 +36,7 @@ struct mbn_net {
     void *streams[8];
     void *bf16_filt[MBN_MAX_LAYERS];   /* bf16 copies of the pointwise / FC filters (bf16 mode) */
     void *keep_buf[MBN_MAX_LAYERS];
+    void *logits_buf;          /* mbn_net_classify: [max_batch][classes] fp32 */
     void *last_out[MBN_MAX_LAYERS];
 };
 
@@ -98,6 +100,7 @@ int mbn_net_destroy(mbn_net *net)
     if (!net) return MBN_OK;
     mbn_sync(net->ctx);
     if (net->graph) mbn_graph_destroy(net->ctx, net->graph);
+    if (net->logits_buf) mbn_free(net->ctx, net->logits_buf);
     for (int j = 0; j < 8; j++)
         if (net->streams[j]) mbn_stream_destroy(net->ctx, net->streams[j]);
     for (int i = 0; i < MBN_MAX_LAYERS; i++) {
@@ -209,6 +212,14 @@ static void drop_graph(mbn_net *net)
     }
 }
 
+int mbn_net_set_input_u8(mbn_net *net, int enabled)
+{
+    if (!net) return MBN_EINVAL;
+    if (net->input_u8 != (enabled != 0)) drop_graph(net);
+    net->input_u8 = enabled != 0;
+    return MBN_OK;
+}
+
 int mbn_net_set_fuse_blocks(mbn_net *net, unsigned mask)
 {
     if (!net) return MBN_EINVAL;
@@ -294,6 +305,7 @@ static int run_layer(mbn_net *net, const mbn_layer_desc *l, const void *src, voi
     case MBN_L_CONV:                       /* MobileNet.c:268-292: rows/cols = input size, stride 2 */
         ext.cin = l->in_ch;
         if (bf) ext.io_flags = MBN_IO_IN_F32;          /* the normalised image is fp32 */
+        if (net->input_u8) ext.io_flags = MBN_IO_IN_U8; /* raw image, normalised at load */
         return mbn_convolute(net->ctx, dst, src, NULL, NULL, filt, l->in_rows, l->in_cols, 3, l->stride, l->out_ch, &ext);
     case MBN_L_DW:                         /* MobileNet.c:326-381 */
         ext.in_rows = l->in_rows;
@@ -325,7 +337,7 @@ static int forward_range(mbn_net *net, const void *images, void *logits, int fir
                          void *stream, float *layer_ms, int n_layer_ms, void *next_stream, int stagger)
 {
     const size_t img_floats = (size_t)net->plan.res * net->plan.res * 3;
-    const char *src = (const char *)images + (size_t)first * img_floats * sizeof(float);
+    const char *src = (const char *)images + (size_t)first * img_floats * (net->input_u8 ? 1 : sizeof(float));
     const size_t slot = (size_t)first * (size_t)net->plan.max_act_floats * sizeof(float);
     int which = 0, i0 = 0;
     if (!layer_ms && stem_fusable(net, last_layer)) {
@@ -333,7 +345,7 @@ static int forward_range(mbn_net *net, const void *images, void *logits, int fir
         const mbn_layer_desc *l = net->plan.layer;
         const size_t per_img = (size_t)l[2].out_rows * l[2].out_cols * l[2].out_ch * sizeof(float);
         char *dst = last_layer == 3 ? (char *)logits + (size_t)first * per_img : (char *)net->act[which] + slot;
-        int rc = mbn_stem_fused(net->ctx, dst, src, blob_at(net, l[0].w_offset), blob_at(net, l[0].scale_offset),
+        int rc = (net->input_u8 ? mbn_stem_fused_u8 : mbn_stem_fused)(net->ctx, dst, src, blob_at(net, l[0].w_offset), blob_at(net, l[0].scale_offset),
                                 blob_at(net, l[0].shift_offset), blob_at(net, l[1].w_offset), blob_at(net, l[1].scale_offset),
                                 blob_at(net, l[1].shift_offset), blob_at(net, l[2].w_offset), blob_at(net, l[2].scale_offset),
                                 blob_at(net, l[2].shift_offset), count, net->plan.res, l[0].out_ch, l[2].out_ch, stream);
@@ -469,6 +481,20 @@ static int forward_impl(mbn_net *net, const void *images, void *logits, int batc
 int mbn_net_forward(mbn_net *net, const void *images, void *logits, int batch, int last_layer)
 {
     return forward_impl(net, images, logits, batch, last_layer, NULL, 0);
+}
+
+int mbn_net_classify(mbn_net *net, const void *images, int batch, int k, void *topk_idx_i32, void *topk_prob_f32)
+{
+    if (!net || !images || !topk_idx_i32 || !topk_prob_f32 || batch <= 0 || batch > net->max_batch || k < 1 || k > 8)
+        return MBN_EINVAL;
+    const mbn_layer_desc *fc = &net->plan.layer[net->plan.n_layers - 1];
+    if (!net->logits_buf) {
+        int rc = mbn_alloc(net->ctx, (size_t)net->max_batch * fc->out_ch * sizeof(float), &net->logits_buf);
+        if (rc != MBN_OK) return rc;
+    }
+    int rc = forward_impl(net, images, net->logits_buf, batch, 0, NULL, 0);
+    if (rc != MBN_OK) return rc;
+    return mbn_softmax_topk_f32(net->ctx, NULL, topk_idx_i32, topk_prob_f32, net->logits_buf, batch, fc->out_ch, k, NULL);
 }
 
 int mbn_net_forward_timed(mbn_net *net, const void *images, void *logits, int batch, float *layer_ms, int n_layer_ms)

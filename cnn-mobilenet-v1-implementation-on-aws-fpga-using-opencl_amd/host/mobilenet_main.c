@@ -198,28 +198,32 @@ int main(int argc, char **argv)
         unsigned long long s = 0xC0FFEEULL;
         for (size_t i = 0; i < img_count; i++) { s = s * 6364136223846793005ULL + 1442695040888963407ULL; u8[i] = (unsigned char)(s >> 56); }
     }
-    void *d_u8, *d_img, *d_logits, *d_probs, *d_arg;
+    void *d_u8, *d_logits, *d_probs, *d_arg;
     CHECK(mbn_alloc(ctx, img_count, &d_u8));
-    CHECK(mbn_alloc(ctx, img_count * sizeof(float), &d_img));
     CHECK(mbn_alloc(ctx, (size_t)batch * classes * sizeof(float), &d_logits));
     CHECK(mbn_alloc(ctx, (size_t)batch * classes * sizeof(float), &d_probs));
-    CHECK(mbn_alloc(ctx, (size_t)batch * sizeof(int), &d_arg));
+    CHECK(mbn_alloc(ctx, (size_t)batch * 8 * sizeof(int), &d_arg));
     CHECK(mbn_upload(ctx, d_u8, u8, img_count));
-    CHECK(mbn_normalize_u8_to_f32(ctx, d_img, d_u8, img_count, 1.0f / 127.5f, -1.0f, NULL));   /* Keras x/127.5 - 1 */
+    CHECK(mbn_net_set_input_u8(net, 1));   /* layer 1 reads the raw image and applies the Keras x/127.5 - 1 at load */
     float ms[MBN_MAX_LAYERS];
-    CHECK(mbn_net_forward_timed(net, d_img, d_logits, batch, ms, MBN_MAX_LAYERS));
+    CHECK(mbn_net_forward_timed(net, d_u8, d_logits, batch, ms, MBN_MAX_LAYERS));
     for (int i = 0; i < w.plan.n_layers; i++) {
         if (w.plan.layer[i].kind == MBN_L_FC) printf("Kernel Execution time for Fully Connected Layer: %f\n", ms[i] / 1000.0);
         else printf("Kernel Execution time for Layer %d: %f\n", i + 1, ms[i] / 1000.0);
     }
-    CHECK(mbn_softmax_f32(ctx, d_probs, d_arg, d_logits, batch, classes, NULL));
-    int *arg = malloc(sizeof(int) * (size_t)batch);
-    float *probs = malloc(sizeof(float) * (size_t)batch * classes);
+    /* classifier read-out on the device: only the 5 best (index, probability) pairs per image cross PCIe, instead of the
+     * reference's 1000 logits + host exp loop (MobileNet.c:2744-2792) */
+    const int topk = classes < 5 ? classes : 5;
+    CHECK(mbn_softmax_topk_f32(ctx, NULL, d_arg, d_probs, d_logits, batch, classes, topk, NULL));
+    int *arg = malloc(sizeof(int) * (size_t)batch * topk);
+    float *probs = malloc(sizeof(float) * (size_t)batch * topk);
     if (!arg || !probs) return 1;
-    CHECK(mbn_download(ctx, arg, d_arg, sizeof(int) * (size_t)batch));
-    CHECK(mbn_download(ctx, probs, d_probs, sizeof(float) * (size_t)batch * classes));
-    printf("Highest Probability of the element is present at location %d and it's value is %f.\n", arg[0] + 1,
-           probs[arg[0]]);
+    CHECK(mbn_download(ctx, arg, d_arg, sizeof(int) * (size_t)batch * topk));
+    CHECK(mbn_download(ctx, probs, d_probs, sizeof(float) * (size_t)batch * topk));
+    printf("Highest Probability of the element is present at location %d and it's value is %f.\n", arg[0] + 1, probs[0]);
+    printf("top-%d:", topk);
+    for (int j = 0; j < topk; j++) printf(" %d (%f)", arg[j] + 1, probs[j]);
+    printf("\n");
     mbn_net_destroy(net);
     mbn_weights_free(&w);
     mbn_shutdown(ctx);

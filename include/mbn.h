@@ -120,6 +120,9 @@ typedef struct mbn_layer_ext {
  * else (conv1/depthwise filters, scale/shift, accumulation) fp32. */
 #define MBN_IO_IN_F32   0x1   /* the input tensor is fp32 (convolute: the normalised image) */
 #define MBN_IO_OUT_F32  0x2   /* the output tensor is fp32 (pointwise as FC: the logits) */
+#define MBN_IO_IN_U8    0x4   /* convolute, fp32/bf16 mode: the input is the raw uint8 HWC image (what decode_image /
+                               * mbn_read_ppm produce, MobileNet.c:49-57); the Keras MobileNet preprocessing x/127.5 - 1
+                               * is applied at load — SURVEY §8f-2, replaces a separate mbn_normalize_u8_to_f32 pass */
 
 typedef struct mbn_context mbn_context;   /* opaque; one per GPU */
 
@@ -213,6 +216,11 @@ int mbn_pool(mbn_context *ctx, void *output, const void *inp_image, int rows, in
 int mbn_stem_fused(mbn_context *ctx, void *out, const void *image, const void *w1, const void *s1, const void *b1,
                    const void *wd, const void *s2, const void *b2, const void *wp, const void *s3, const void *b3,
                    int batch, int res, int c1, int c3, void *stream);
+/* The same with the raw uint8 HWC image [batch][res][res][3] as input: x/127.5 - 1 is applied while the
+ * input patch is loaded, bit-identical to mbn_normalize_u8_to_f32 followed by mbn_stem_fused. */
+int mbn_stem_fused_u8(mbn_context *ctx, void *out, const void *image_u8, const void *w1, const void *s1, const void *b1,
+                      const void *wd, const void *s2, const void *b2, const void *wp, const void *s3, const void *b3,
+                      int batch, int res, int c1, int c3, void *stream);
 
 /* Fused block: a depthwise 3x3 (stride 1 or 2) + pointwise 1x1 pair of the sequence (the pairs L4-5 ...
  * L26-27, MobileNet.c:322-2599; kernel.cl:62-92 + 94-114) in one kernel, each stage followed by its folded-BN
@@ -230,6 +238,20 @@ int mbn_dwpw_fused(mbn_context *ctx, void *out, const void *in, const void *wd, 
 int mbn_softmax_f32(mbn_context *ctx, void *probs, void *argmax_i32, const void *logits, int batch,
                     int classes, void *stream);
 
+/* softmax + top-k on device: for every image the k <= 8 most probable classes, most probable first
+ * (ties -> lowest index), topk_idx [batch][k] int32 (0-based, -1 when classes < k) and topk_prob [batch][k] fp32;
+ * probs (may be NULL) additionally receives the full [batch][classes] distribution. Only 2k values per image have to
+ * cross PCIe instead of the 1000 logits of MobileNet.c:2744 + the host exp loop :2771-2792. */
+int mbn_softmax_topk_f32(mbn_context *ctx, void *probs, void *topk_idx_i32, void *topk_prob_f32, const void *logits,
+                         int batch, int classes, int k, void *stream);
+/* The classifier tail of the sequence as one call (MobileNet.c:2601-2792): global average pool (kernel.cl:116) ->
+ * FC = pointwise with rows = cols = 1 (kernel.cl:94; bias, no ReLU: B15) -> softmax + top-k. fp32 NHWC,
+ * in [batch][rows][cols][channels], fc_w [classes][channels], fc_bias [classes] or NULL; pooled_scratch
+ * [batch][channels] and logits_scratch [batch][classes] are caller-provided device buffers (the logits stay readable
+ * there). Three launches on `stream`. */
+int mbn_classifier_tail(mbn_context *ctx, void *topk_idx_i32, void *topk_prob_f32, void *probs, void *logits_scratch,
+                        void *pooled_scratch, const void *in, const void *fc_w, const void *fc_bias, int batch, int rows,
+                        int cols, int channels, int classes, int k, void *stream);
 /* Input front-end on device: uint8 HWC [N][rows][cols][3] -> fp32 NHWC x*scale+bias
  * (Keras MobileNet preprocessing is scale=1/127.5, bias=-1). */
 int mbn_normalize_u8_to_f32(mbn_context *ctx, void *out_f32, const void *in_u8, size_t count, float scale,
@@ -351,6 +373,9 @@ int  mbn_net_set_graph(mbn_net *net, int enabled);
  * kept, at least 3 layers requested); 0 = always issue the 29 separate layer calls. mbn_net_fused_layers reports how
  * many leading layers the next forward(batch, last_layer) would fuse (0 or 3). */
 int  mbn_net_set_fuse_stem(mbn_net *net, int enabled);
+/* 1 = the `images` handed to mbn_net_forward / _timed / _classify are raw uint8 HWC [batch][res][res][3] (device);
+ * layer 1 (or the fused stem) normalises them at load (MBN_IO_IN_U8). 0 (default) = fp32 NHWC, already normalised. */
+int  mbn_net_set_input_u8(mbn_net *net, int enabled);
 int  mbn_net_fused_layers(const mbn_net *net, int last_layer, int *count);
 /* Fused depthwise->pointwise blocks (mbn_dwpw_fused): bit L of `mask` (L = 1-based number of a depthwise layer) lets
  * layers L and L+1 run as one launch when the plan is fp32, activations are not kept and the shapes are inside the
@@ -366,6 +391,10 @@ int  mbn_net_launches(const mbn_net *net, int batch, int last_layer, int *first_
  * last_layer: run layers 1..last_layer only (0 or 29 => all; 5 and 13 = BASELINE configs 1-2), in which
  * case `logits` receives that layer's NHWC activation instead. */
 int  mbn_net_forward(mbn_net *net, const void *images, void *logits, int batch, int last_layer);
+/* forward + classifier read-out on device: the k <= 8 most probable classes per image (mbn_softmax_topk_f32 over the
+ * net's own logits buffer): topk_idx [batch][k] int32, topk_prob [batch][k] fp32, device pointers. What MobileNet.c:2744-2792
+ * does with a 1000-byte D2H and a host loop, with 2k values per image to download. */
+int  mbn_net_classify(mbn_net *net, const void *images, int batch, int k, void *topk_idx_i32, void *topk_prob_f32);
 /* Per-layer milliseconds of the most recent mbn_net_forward_timed call (hipEvents between layers). */
 int  mbn_net_forward_timed(mbn_net *net, const void *images, void *logits, int batch, float *layer_ms,
                            int n_layer_ms);

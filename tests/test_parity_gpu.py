@@ -800,3 +800,117 @@ def test_net_fused_blocks_equal_separate_layers(pkg, orc, ctx, tmp_path):
     net.keep_activations(True)
     assert net.launches(n) == [(l, 1) for l in range(1, 30)]
     net.destroy()
+
+
+# =========================================================================== classifier tail (§8f-3)
+
+def _topk_ref(logits, k):
+    """Oracle-side top-k: softmax from the oracle, order = (value descending, index ascending) like its strict '>' scan."""
+    n, c = logits.shape
+    idx = np.full((n, k), -1, np.int32)
+    for i in range(n):
+        order = sorted(range(c), key=lambda j: (-float(logits[i, j]), j))[:k]
+        idx[i, :len(order)] = order
+    return idx
+
+
+def test_softmax_topk_and_classifier_tail(pkg, orc, ctx):
+    rng = np.random.default_rng(21)
+    n, classes, k = 6, 1000, 5
+    logits = rng.normal(0, 3, (n, classes)).astype(np.float32)
+    logits[1, 7] = logits[1, 900] = logits[1, 3] = 40.0          # three-way tie for the maximum -> indices 3, 7, 900 in order
+    logits[2, :] = 0.25                                            # all equal -> 0, 1, 2, 3, 4
+    want_p, want_a = orc.f32_softmax(logits)
+    want_i = _topk_ref(logits, k)
+    d_l, d_p, d_i, d_v = ctx.to_device(logits), ctx.alloc(logits.nbytes), ctx.alloc(n * k * 4), ctx.alloc(n * k * 4)
+    assert ctx.lib.mbn_softmax_topk_f32(ctx.h, d_p.ptr, d_i.ptr, d_v.ptr, d_l.ptr, n, classes, k, None) == 0
+    ctx.sync()
+    got_i, got_v = d_i.download((n, k), np.int32), d_v.download((n, k), np.float32)
+    assert np.array_equal(got_i, want_i)
+    assert np.array_equal(got_i[:, 0], want_a)
+    assert_close(d_p.download((n, classes), np.float32), want_p, 1e-5, "softmax")
+    assert_close(got_v, np.take_along_axis(want_p, want_i.astype(np.int64), axis=1), 1e-5, "top-k probabilities")
+    # fewer classes than k: padded with -1 / 0
+    small = rng.normal(0, 1, (2, 3)).astype(np.float32)
+    d_s = ctx.to_device(small)
+    assert ctx.lib.mbn_softmax_topk_f32(ctx.h, None, d_i.ptr, d_v.ptr, d_s.ptr, 2, 3, 5, None) == 0
+    ctx.sync()
+    gi = d_i.download((n, k), np.int32)[:2]
+    assert np.array_equal(gi.reshape(-1)[:10].reshape(2, 5)[:, 3:], -np.ones((2, 2), np.int32))
+    assert ctx.lib.mbn_softmax_topk_f32(ctx.h, None, d_i.ptr, d_v.ptr, d_s.ptr, 2, 3, 9, None) == pkg.EINVAL
+    # whole tail: pool -> FC(+bias) -> softmax/top-k against the oracle's three stages
+    ch, h, classes2 = 1024, 7, 1000
+    x = rng.uniform(0, 6, (n, h, h, ch)).astype(np.float32)
+    w = rng.normal(0, (1.0 / ch) ** 0.5, (classes2, ch)).astype(np.float32)
+    b = rng.normal(0, 0.5, classes2).astype(np.float32)
+    pooled = orc.f32_pool(x)
+    ref_logits = orc.f32_pointwise(pooled.reshape(n, ch), w, None, b, 0)
+    ref_p, _ = orc.f32_softmax(ref_logits)
+    d_x, d_w, d_b = ctx.to_device(x), ctx.to_device(w), ctx.to_device(b)
+    d_lg, d_po = ctx.alloc(n * classes2 * 4), ctx.alloc(n * ch * 4)
+    assert ctx.lib.mbn_classifier_tail(ctx.h, d_i.ptr, d_v.ptr, None, d_lg.ptr, d_po.ptr, d_x.ptr, d_w.ptr, d_b.ptr,
+                                       n, h, h, ch, classes2, k, None) == 0
+    ctx.sync()
+    got_logits = d_lg.download((n, classes2), np.float32)
+    assert_close(got_logits, ref_logits, TOL_PW, "tail logits")
+    got_i = d_i.download((n, k), np.int32)
+    assert np.array_equal(got_i, _topk_ref(got_logits, k))                     # order decided on the device's own logits
+    assert_close(d_v.download((n, k), np.float32), np.take_along_axis(ref_p, got_i.astype(np.int64), axis=1), 1e-3, "tail top-k probs")
+
+
+def test_net_classify_matches_forward(pkg, orc, ctx, tmp_path):
+    n, res = 4, 64
+    hw, net = _make_net(pkg, ctx, tmp_path, 0.5, res, 30, n)
+    imgs = np.random.default_rng(2).uniform(-1, 1, (n, res, res, 3)).astype(np.float32)
+    d_in, d_out = ctx.to_device(imgs), ctx.alloc(n * 30 * 4)
+    d_i, d_v = ctx.alloc(n * 3 * 4), ctx.alloc(n * 3 * 4)
+    net.forward(d_in.ptr, d_out.ptr, n)
+    net.classify(d_in.ptr, n, 3, d_i.ptr, d_v.ptr)
+    ctx.sync()
+    logits = d_out.download((n, 30), np.float32)
+    assert np.array_equal(d_i.download((n, 3), np.int32), _topk_ref(logits, 3))
+    p, _ = orc.f32_softmax(logits)
+    assert_close(d_v.download((n, 3), np.float32), np.take_along_axis(p, _topk_ref(logits, 3).astype(np.int64), axis=1), 1e-5, "classify")
+    net.destroy()
+
+
+# =========================================================================== uint8 front-end (§8f-2)
+
+def test_u8_input_conv1_stem_and_net(pkg, orc, ctx, tmp_path):
+    """MBN_IO_IN_U8: conv1 / the fused stem / the whole net fed with the raw uint8 HWC image == the same fed with
+    mbn_normalize_u8_to_f32's output (bit-identical: same fmaf), and within tolerance of the oracle on x/127.5 - 1."""
+    rng = np.random.default_rng(8)
+    for (n, h, cout) in [(2, 64, 32), (1, 33, 8), (2, 20, 6)]:          # fast first-layer kernel, LDS-weights kernel, generic
+        u8 = rng.integers(0, 256, (n, h, h, 3), dtype=np.uint8)
+        xf = (u8.astype(np.float32) * np.float32(1 / 127.5) + np.float32(-1)).astype(np.float32)
+        f = rng.normal(0, 0.3, (3, 3, 3, cout)).astype(np.float32)
+        sc, sh = rng.uniform(0.5, 1.5, cout).astype(np.float32), rng.normal(0, 0.1, cout).astype(np.float32)
+        want = orc.f32_conv(xf, f, sc, sh, 2, 2)
+        d_u, d_f, d_sc, d_sh = (ctx.to_device(a) for a in (u8, f, sc, sh))
+        d_n, d_a, d_b = ctx.alloc(xf.nbytes), ctx.alloc(want.nbytes), ctx.alloc(want.nbytes)
+        assert ctx.lib.mbn_normalize_u8_to_f32(ctx.h, d_n.ptr, d_u.ptr, u8.size, 1 / 127.5, -1.0, None) == 0
+        ctx.convolute(d_a.ptr, d_u.ptr, None, None, d_f.ptr, h, h, 3, 2, cout,
+                      pkg.make_ext(batch=n, act=2, cin=3, scale=d_sc.ptr, shift=d_sh.ptr, io_flags=pkg.IO_IN_U8))
+        ctx.convolute(d_b.ptr, d_n.ptr, None, None, d_f.ptr, h, h, 3, 2, cout,
+                      pkg.make_ext(batch=n, act=2, cin=3, scale=d_sc.ptr, shift=d_sh.ptr))
+        ctx.sync()
+        got = d_a.download(want.shape, np.float32)
+        assert np.array_equal(got, d_b.download(want.shape, np.float32)), (n, h, cout)
+        assert_close(got, want, TOL_DW, "conv1 from uint8")
+    # whole net (fused stem path and separate-layer path)
+    n, res = 2, 64
+    hw, net = _make_net(pkg, ctx, tmp_path, 1.0, res, 20, n)
+    u8 = rng.integers(0, 256, (n, res, res, 3), dtype=np.uint8)
+    d_u, d_n = ctx.to_device(u8), ctx.alloc(u8.size * 4)
+    assert ctx.lib.mbn_normalize_u8_to_f32(ctx.h, d_n.ptr, d_u.ptr, u8.size, 1 / 127.5, -1.0, None) == 0
+    d_o1, d_o2, d_o3 = ctx.alloc(n * 80), ctx.alloc(n * 80), ctx.alloc(n * 80)
+    net.forward(d_n.ptr, d_o1.ptr, n)
+    net.set_input_u8(True)
+    assert net.fused_layers(0) == 3
+    net.forward(d_u.ptr, d_o2.ptr, n)                     # mbn_stem_fused_u8
+    net.set_fuse_stem(False)
+    net.forward(d_u.ptr, d_o3.ptr, n)                     # mbn_convolute with MBN_IO_IN_U8
+    ctx.sync()
+    a, b, c = (d.download((n, 20), np.float32) for d in (d_o1, d_o2, d_o3))
+    assert np.array_equal(a, b) and np.array_equal(a, c)
+    net.destroy()
