@@ -129,6 +129,112 @@ __global__ __launch_bounds__(256) void dw3x3_nhwc(DwArgs a)
     }
 }
 
+// bf16 storage, 8 channels (16 bytes) per lane: the fp32 kernel's decomposition with 4-channel lanes moves 8 bytes per
+// lane-load in bf16 and is instruction-bound at ~2.2 TB/s (27 % of HBM); here a lane loads whole 16-byte vectors, widens
+// them to fp32 once (a shift / a mask per element) and keeps the 3 x NC window in fp32 registers. Weights, scale, shift stay fp32 in registers; arithmetic and rounding are the 4-channel kernel's.
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+typedef float f8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ f8 widen8(u4v p)
+{
+    f8 r;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        r[2 * i] = __builtin_bit_cast(float, p[i] << 16);
+        r[2 * i + 1] = __builtin_bit_cast(float, p[i] & 0xffff0000u);
+    }
+    return r;
+}
+__device__ __forceinline__ f8 ld8f(const float *p)
+{
+    const f4 a = *reinterpret_cast<const f4 *>(p), b = *reinterpret_cast<const f4 *>(p + 4);
+    return f8{ a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w };
+}
+
+template <int NC>
+__device__ __forceinline__ void load_row8(const DwArgs &a, const __bf16 *img, int iy, int ix0, int c, f8 (&rf)[NC])
+{
+    u4v r[NC];
+    const bool rowok = iy >= 0 && iy < a.in_rows;
+    const __bf16 *row = img + ((long)iy * a.in_cols) * a.ch + c;
+#pragma unroll
+    for (int j = 0; j < NC; j++) {
+        const int ix = ix0 + j;
+        r[j] = (rowok && ix >= 0 && ix < a.in_cols) ? *reinterpret_cast<const u4v *>(row + (long)ix * a.ch) : u4v{ 0u, 0u, 0u, 0u };
+    }
+#pragma unroll
+    for (int j = 0; j < NC; j++) rf[j] = widen8(r[j]);          // each element is widened once, not once per tap
+}
+
+template <int STRIDE, int TW>
+__global__ __launch_bounds__(256) void dw3x3_nhwc_bf16x8(DwArgs a)
+{
+    constexpr int NC = TW * STRIDE + 2;
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.total) return;
+    const int cl = (int)(t % a.cw);                  // a.cw = lanes along channels inside a slab (8 channels each)
+    long q = t / a.cw;
+    const int lc = (int)(q % a.lcols);
+    q /= a.lcols;
+    const int slab = (int)(q % a.nslab);
+    q /= a.nslab;
+    const int seg = (int)(q % a.nseg);
+    const int n = (int)(q / a.nseg);
+    const int c = (slab * a.cw + cl) << 3;
+    const int ox0 = lc * TW;
+
+    f8 w[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) w[k] = ld8f(a.filt + (long)k * a.ch + c);
+    const f8 one = f8{ 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f }, zero = one - one;
+    const f8 sc = a.scale ? ld8f(a.scale + c) : one;
+    const f8 sh = a.shift ? ld8f(a.shift + c) : zero;
+
+    const __bf16 *img = reinterpret_cast<const __bf16 *>(a.in) + (long)n * a.in_rows * a.in_cols * a.ch;
+    __bf16 *op = reinterpret_cast<__bf16 *>(a.out) + (((long)n * a.rows) * a.cols + ox0) * a.ch + c;
+    const int oy0 = seg * a.seg_rows;
+    const int oy1 = min(oy0 + a.seg_rows, a.rows);
+    const int ix0 = ox0 * STRIDE - a.pad_left;
+
+    f8 r0[NC], r1[NC], r2[NC];
+    int iy = oy0 * STRIDE - a.pad_top;
+    load_row8<NC>(a, img, iy, ix0, c, r0);
+    if (STRIDE == 1) load_row8<NC>(a, img, iy + 1, ix0, c, r1);
+
+    for (int oy = oy0; oy < oy1; oy++) {
+        iy = oy * STRIDE - a.pad_top;
+        if (STRIDE == 2) load_row8<NC>(a, img, iy + 1, ix0, c, r1);
+        load_row8<NC>(a, img, iy + 2, ix0, c, r2);
+#pragma unroll
+        for (int p = 0; p < TW; p++) {
+            const int j = p * STRIDE;
+            f8 acc = zero;                                     // same tap order as the 4-channel kernel
+            acc = __builtin_elementwise_fma(r0[j], w[0], acc);
+            acc = __builtin_elementwise_fma(r0[j + 1], w[1], acc);
+            acc = __builtin_elementwise_fma(r0[j + 2], w[2], acc);
+            acc = __builtin_elementwise_fma(r1[j], w[3], acc);
+            acc = __builtin_elementwise_fma(r1[j + 1], w[4], acc);
+            acc = __builtin_elementwise_fma(r1[j + 2], w[5], acc);
+            acc = __builtin_elementwise_fma(r2[j], w[6], acc);
+            acc = __builtin_elementwise_fma(r2[j + 1], w[7], acc);
+            acc = __builtin_elementwise_fma(r2[j + 2], w[8], acc);
+            acc = __builtin_elementwise_fma(acc, sc, sh);
+            if (TW == 1 || ox0 + p < a.cols) {
+                __bf16 *o = op + ((long)oy * a.cols + p) * a.ch;
+                const f4 lo = act4(f4{ acc[0], acc[1], acc[2], acc[3] }, a.act), hi = act4(f4{ acc[4], acc[5], acc[6], acc[7] }, a.act);
+                typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
+                *reinterpret_cast<bf8v *>(o) = bf8v{ (__bf16)lo.x, (__bf16)lo.y, (__bf16)lo.z, (__bf16)lo.w,
+                                                    (__bf16)hi.x, (__bf16)hi.y, (__bf16)hi.z, (__bf16)hi.w };   // RNE
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NC; j++) {
+            if (STRIDE == 1) { r0[j] = r1[j]; r1[j] = r2[j]; }
+            else r0[j] = r2[j];
+        }
+    }
+}
+
 // Generic fallback (any stride / filtersize / channel count): one lane per output element.
 template <typename T>
 __global__ __launch_bounds__(256) void dw_generic_nhwc(DwArgs a, int fs, int stride)
@@ -173,8 +279,40 @@ int launch_dw(const mbn_call &c, DwArgs &a, int rows, int cols, int fs, int stri
         hipLaunchKernelGGL(dw_generic_nhwc<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c.stream, a, fs, stride);
         return MBN_OK;
     }
-    // variant: bits 0..1 = TW (0 = default 2), bit 4 = lanes across the full C instead of 64-channel slabs
+    // variant: bits 0..1 = TW (0 = default 2), bit 4 = lanes across the full C instead of 64-channel slabs,
+    // bit 5 = bf16 with 4-channel lanes (the first bf16 version; A/B hook)
     const int var = g_mbn_tune.dw_variant;
+    if (sizeof(T) == 2 && !(var & 32) && (channels % 8) == 0 && ((uintptr_t)a.in % 16) == 0 && ((uintptr_t)a.out % 16) == 0) {
+        const int c8 = channels / 8;
+        int cw = c8 > 8 ? 8 : c8;                    // slab = 8 lanes x 8 channels = 64 channels = 128 B per pixel
+        while (c8 % cw) cw--;
+        a.cw = cw;
+        a.nslab = c8 / cw;
+        const int tw8 = (var & 3) == 1 ? 1 : 2;      // 2 columns per lane measured faster on every layer (tune dw_variant=1: one)
+        a.lcols = (cols + tw8 - 1) / tw8;
+        const long row_lanes = (long)c.batch * a.lcols * c8;
+        const long target = (long)c.ctx->num_cus * 64 * (stride == 1 ? 12 : 6);
+        int nseg = 1;
+        if (g_mbn_tune.dw_nseg > 0) nseg = g_mbn_tune.dw_nseg;
+        else if (row_lanes < target) {
+            nseg = (int)((target + row_lanes - 1) / row_lanes);
+            int max_seg = rows / 4 > 0 ? rows / 4 : 1;
+            if (nseg > max_seg) nseg = max_seg;
+        }
+        if (nseg > rows) nseg = rows;
+        a.seg_rows = (rows + nseg - 1) / nseg;
+        a.nseg = (rows + a.seg_rows - 1) / a.seg_rows;
+        a.total = row_lanes * a.nseg;
+        dim3 grid((unsigned)((a.total + 255) / 256));
+        if (stride == 1) {
+            if (tw8 == 2) hipLaunchKernelGGL((dw3x3_nhwc_bf16x8<1, 2>), grid, dim3(256), 0, c.stream, a);
+            else hipLaunchKernelGGL((dw3x3_nhwc_bf16x8<1, 1>), grid, dim3(256), 0, c.stream, a);
+        } else {
+            if (tw8 == 2) hipLaunchKernelGGL((dw3x3_nhwc_bf16x8<2, 2>), grid, dim3(256), 0, c.stream, a);
+            else hipLaunchKernelGGL((dw3x3_nhwc_bf16x8<2, 1>), grid, dim3(256), 0, c.stream, a);
+        }
+        return MBN_OK;
+    }
     int tw = (var & 3) ? (var & 3) : 2;
     if (tw > 2) tw = 2;
     const int c4 = channels / 4;
