@@ -465,7 +465,7 @@ int mbn_launch_f32_pointwise(const mbn_call &c, void *out, const void *in, const
         const long big_tiles = ((m + 127) / 128) * ((op_size + 63) / 64);
         if (big_tiles < 2L * c.ctx->num_cus || op_size <= 64 || m <= 16384) tile = 3;   // 7x7 layers: finer tiles balance better
         else if (!bf && (cin >= 512 || (cin >= 256 && op_size >= 512))) tile = 3;
-        else if (cin <= 256 && op_size >= 128) tile = 5;
+        else if ((bf || cin <= 256) && op_size >= 128) tile = 5;   // bf16: 128x128 wins at every K (HBM-bound, fewest B re-reads)
         else tile = 2;
     }
     const int cus = c.ctx->num_cus;
