@@ -914,3 +914,23 @@ def test_u8_input_conv1_stem_and_net(pkg, orc, ctx, tmp_path):
     a, b, c = (d.download((n, 20), np.float32) for d in (d_o1, d_o2, d_o3))
     assert np.array_equal(a, b) and np.array_equal(a, c)
     net.destroy()
+
+
+def test_f32_dwpw_fused_top_left_padding(pkg, orc, ctx):
+    """Stride 2 with pad_top = pad_left = 1 — the reference's own top/left-only convention (kernel.cl:16-20, B6) — through
+    the fused block: the buffer-load zero padding must follow the explicit pads, not TF-SAME."""
+    rng = np.random.default_rng(77)
+    n, h, cin, cout = 2, 12, 64, 128
+    x = rng.uniform(-1, 1, (n, h, h, cin)).astype(np.float32)
+    wd = rng.normal(0, 0.5, (3, 3, cin)).astype(np.float32)
+    wp = rng.normal(0, (2.0 / cin) ** 0.5, (cout, cin)).astype(np.float32)
+    s2, s3 = rng.uniform(0.5, 1.5, cin).astype(np.float32), rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    b2, b3 = rng.normal(0, 0.1, cin).astype(np.float32), rng.normal(0, 0.1, cout).astype(np.float32)
+    mid = orc.f32_depthwise(x, wd, s2, b2, 2, 2, out_rows=6, out_cols=6, pad_top=1, pad_left=1)
+    want = orc.f32_pointwise(mid.reshape(-1, cin), wp, s3, b3, 2).reshape(n, 6, 6, cout)
+    d = [ctx.to_device(a) for a in (x, wd, s2, b2, wp, s3, b3)]
+    d_f = ctx.alloc(want.nbytes)
+    assert ctx.lib.mbn_dwpw_fused(ctx.h, d_f.ptr, d[0].ptr, d[1].ptr, d[2].ptr, d[3].ptr, d[4].ptr, d[5].ptr, d[6].ptr,
+                                  n, h, h, 6, 6, cin, cout, 2, 1, 1, None) == 0
+    ctx.sync()
+    assert_close(d_f.download(want.shape, np.float32), want, TOL_PW, "dwpw top/left padding")
