@@ -90,9 +90,9 @@ __global__ __launch_bounds__(NT) void dwpw_f32(DwPwArgs a)
     __syncthreads();
     if ((int)blockIdx.x >= nwg) return;
 
-    if (wave_u >= NCW) {
+    if (wave_u < NPW) {          // producers are the OLDER waves: VALU issue between co-resident waves is arbitrated by age
         // =============================================================== PRODUCERS
-        const int pw_u = wave_u - NCW;                                   // producer wave 0..7
+        const int pw_u = wave_u;                                         // producer wave 0..7
         const int t = pw_u * 64 + lane, c4 = t & 7, pair = t >> 3;              // pair 0..63: tile rows 2*pair, 2*pair+1
         const __amdgpu_buffer_rsrc_t rsrc = mbn_make_rsrc(a.in, a.in_bytes);
         unsigned off[3][XC];
@@ -196,7 +196,8 @@ __global__ __launch_bounds__(NT) void dwpw_f32(DwPwArgs a)
     }
 
     // =================================================================== CONSUMERS
-    const int wm = (wave_u / WAVES_N) * WM, wn = (wave_u % WAVES_N) * WN;
+    const int cw_u = wave_u - NPW;                                        // consumer wave 0..7
+    const int wm = (cw_u / WAVES_N) * WM, wn = (cw_u % WAVES_N) * WN;
     const int li = lane & 31, lh = lane >> 5;
     const __amdgpu_buffer_rsrc_t orsrc = mbn_make_rsrc(a.out, (unsigned)(a.m * a.cout * 4));
     __syncthreads();                                                      // chunk 0 is in buffer 0

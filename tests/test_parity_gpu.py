@@ -774,8 +774,8 @@ def test_net_fused_blocks_equal_separate_layers(pkg, orc, ctx, tmp_path):
     hw, net = _make_net(pkg, ctx, tmp_path, 1.0, res, 20, n)
     imgs = np.random.default_rng(11).uniform(-1, 1, (n, res, res, 3)).astype(np.float32)
     d_in = ctx.to_device(imgs)
-    assert net.launches(n)[:4] == [(1, 3), (4, 2), (6, 2), (8, 2)]            # default mask: stem + blocks 4, 6, 8
-    assert (10, 1) in net.launches(n)
+    assert net.launches(n)[:5] == [(1, 3), (4, 2), (6, 2), (8, 2), (10, 2)]   # default mask: stem + blocks 4, 6, 8, 10
+    assert (12, 1) in net.launches(n)
     outs = {}
     for mask in (0xFFFFFFFE, 0):
         net.set_fuse_blocks(mask)
