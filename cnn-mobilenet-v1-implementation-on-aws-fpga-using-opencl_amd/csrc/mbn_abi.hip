@@ -523,7 +523,7 @@ int mbn_classifier_tail(mbn_context *ctx, void *topk_idx_i32, void *topk_prob_f3
 
 static int stem_fused_impl(mbn_context *ctx, void *out, const void *image, const void *w1, const void *s1, const void *b1,
                            const void *wd, const void *s2, const void *b2, const void *wp, const void *s3, const void *b3,
-                           int batch, int res, int c1, int c3, void *stream, int in_u8)
+                           int batch, int res, int c1, int c3, void *stream, int in_u8, int bf16)
 {
     if (!ctx || !out || !image) return MBN_EINVAL;
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
@@ -532,21 +532,30 @@ static int stem_fused_impl(mbn_context *ctx, void *out, const void *image, const
     Scope sc(ctx, s);
     return sc.finish(mbn_launch_f32_stem(ctx, s, (float *)out, (const float *)image, (const float *)w1, (const float *)s1,
                                          (const float *)b1, (const float *)wd, (const float *)s2, (const float *)b2,
-                                         (const float *)wp, (const float *)s3, (const float *)b3, batch, res, c1, c3, in_u8));
+                                         (const float *)wp, (const float *)s3, (const float *)b3, batch, res, c1, c3, in_u8, bf16));
 }
 
 int mbn_stem_fused(mbn_context *ctx, void *out, const void *image, const void *w1, const void *s1, const void *b1,
                    const void *wd, const void *s2, const void *b2, const void *wp, const void *s3, const void *b3,
                    int batch, int res, int c1, int c3, void *stream)
 {
-    return stem_fused_impl(ctx, out, image, w1, s1, b1, wd, s2, b2, wp, s3, b3, batch, res, c1, c3, stream, 0);
+    return stem_fused_impl(ctx, out, image, w1, s1, b1, wd, s2, b2, wp, s3, b3, batch, res, c1, c3, stream, 0, 0);
 }
 
 int mbn_stem_fused_u8(mbn_context *ctx, void *out, const void *image_u8, const void *w1, const void *s1, const void *b1,
                       const void *wd, const void *s2, const void *b2, const void *wp, const void *s3, const void *b3,
                       int batch, int res, int c1, int c3, void *stream)
 {
-    return stem_fused_impl(ctx, out, image_u8, w1, s1, b1, wd, s2, b2, wp, s3, b3, batch, res, c1, c3, stream, 1);
+    return stem_fused_impl(ctx, out, image_u8, w1, s1, b1, wd, s2, b2, wp, s3, b3, batch, res, c1, c3, stream, 1, 0);
+}
+
+int mbn_stem_fused_ex(mbn_context *ctx, void *out, const void *image, const void *w1, const void *s1, const void *b1,
+                      const void *wd, const void *s2, const void *b2, const void *wp, const void *s3, const void *b3,
+                      int batch, int res, int c1, int c3, int flags, void *stream)
+{
+    if (flags & ~(MBN_STEM_IN_U8 | MBN_STEM_BF16)) return MBN_EINVAL;
+    return stem_fused_impl(ctx, out, image, w1, s1, b1, wd, s2, b2, wp, s3, b3, batch, res, c1, c3, stream,
+                           (flags & MBN_STEM_IN_U8) != 0, (flags & MBN_STEM_BF16) != 0);
 }
 
 int mbn_dwpw_fused(mbn_context *ctx, void *out, const void *in, const void *wd, const void *s2, const void *b2,

@@ -88,6 +88,13 @@ __device__ __forceinline__ void patch_store(float *in_s, int tid, const f2 (&pf)
     }
 }
 
+// BF = bf16 mode of the network (BASELINE config 5): storage bf16, arithmetic fp32. Every layer OUTPUT is rounded to bf16
+// (RNE) — here that means the two on-chip intermediates are rounded before they are written to LDS, exactly where the
+// separate launches would store them — the pointwise filter is the bf16 copy, and the result is stored as bf16.
+__device__ __forceinline__ float rbf(float v) { return (float)(__bf16)v; }
+__device__ __forceinline__ f4 rbf4(f4 v) { return f4{ rbf(v.x), rbf(v.y), rbf(v.z), rbf(v.w) }; }
+
+template <bool BF>
 __global__ __launch_bounds__(256, 2) void stem_fused_f32(StemArgs a)   // 2 waves/SIMD: two workgroups per CU
 {
     __shared__ __attribute__((aligned(16))) float in_s[PR * PROW];        //  9.4 KB
@@ -104,7 +111,11 @@ __global__ __launch_bounds__(256, 2) void stem_fused_f32(StemArgs a)   // 2 wave
     for (int i = tid * 4; i < 27 * C1; i += 1024) *reinterpret_cast<f4 *>(w1_s + i) = *reinterpret_cast<const f4 *>(a.w1 + i);
     for (int i = tid; i < C3 * 8; i += 256) {                             // pointwise filter [64][32] -> swizzled B tile
         const int row = i >> 3, ch = i & 7;
-        *reinterpret_cast<f4 *>(b_s + swz(row, ch)) = *reinterpret_cast<const f4 *>(a.wp + row * 32 + ch * 4);
+        if (BF) {
+            typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+            const bf4 w = *reinterpret_cast<const bf4 *>(reinterpret_cast<const __bf16 *>(a.wp) + row * 32 + ch * 4);
+            *reinterpret_cast<f4 *>(b_s + swz(row, ch)) = f4{ (float)w.x, (float)w.y, (float)w.z, (float)w.w };
+        } else *reinterpret_cast<f4 *>(b_s + swz(row, ch)) = *reinterpret_cast<const f4 *>(a.wp + row * 32 + ch * 4);
     }
     if (tid < 4 * C1) {
         const float *src = tid < C1 ? a.s1 : tid < 2 * C1 ? a.b1 : tid < 3 * C1 ? a.s2 : a.b2;
@@ -163,7 +174,8 @@ __global__ __launch_bounds__(256, 2) void stem_fused_f32(StemArgs a)   // 2 wave
             const f4 s1 = *reinterpret_cast<const f4 *>(sb_s + c4 * 4), b1 = *reinterpret_cast<const f4 *>(sb_s + C1 + c4 * 4);
 #pragma unroll
             for (int p = 0; p < 6; p++) {                                 // outside the map: the depthwise zero padding
-                const f4 v = (rowok && ox + p >= 0 && ox + p < a.h) ? bn_relu6(acc[p], s1, b1) : f4{ 0.f, 0.f, 0.f, 0.f };
+                f4 v = (rowok && ox + p >= 0 && ox + p < a.h) ? bn_relu6(acc[p], s1, b1) : f4{ 0.f, 0.f, 0.f, 0.f };
+                if (BF) v = rbf4(v);
                 *reinterpret_cast<f4 *>(c1_s + (br * CC + bc + p) * C1 + c4 * 4) = v;
             }
         }
@@ -187,7 +199,11 @@ __global__ __launch_bounds__(256, 2) void stem_fused_f32(StemArgs a)   // 2 wave
             }
             const f4 s2 = *reinterpret_cast<const f4 *>(sb_s + 2 * C1 + c4 * 4), b2 = *reinterpret_cast<const f4 *>(sb_s + 3 * C1 + c4 * 4);
 #pragma unroll
-            for (int p = 0; p < 4; p++) *reinterpret_cast<f4 *>(a_s + swz(cy * TW + cx + p, c4)) = bn_relu6(acc[p], s2, b2);
+            for (int p = 0; p < 4; p++) {
+                f4 v = bn_relu6(acc[p], s2, b2);
+                if (BF) v = rbf4(v);
+                *reinterpret_cast<f4 *>(a_s + swz(cy * TW + cx + p, c4)) = v;
+            }
         }
         __syncthreads();
 
@@ -216,7 +232,9 @@ __global__ __launch_bounds__(256, 2) void stem_fused_f32(StemArgs a)   // 2 wave
             for (int r = 0; r < 16; r++) {
                 const int q = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 const int y = q >> 4, x = q & 15;
-                obase[((long)y * a.h + x) * C3 + ni * 32 + li] = relu6(fmaf(acc[ni][r], s3[ni], b3[ni]));
+                const float v = relu6(fmaf(acc[ni][r], s3[ni], b3[ni]));
+                if (BF) reinterpret_cast<__bf16 *>(a.out)[(((n * a.h + TH * ty) * a.h + TW * tx) + (long)y * a.h + x) * C3 + ni * 32 + li] = (__bf16)v;
+                else obase[((long)y * a.h + x) * C3 + ni * 32 + li] = v;
             }
         // No barrier here: the next tile's B writes c1_s (last read in C, one barrier ago) and its C writes a_s only after
         // the barrier that follows B, which every wave reaches after finishing the a_s reads above.
@@ -229,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void stem_fused_f32(StemArgs a)   // 2 wave
 // layers separately).
 int mbn_launch_f32_stem(mbn_context *ctx, hipStream_t stream, float *out, const float *in, const float *w1,
                         const float *s1, const float *b1, const float *wd, const float *s2, const float *b2,
-                        const float *wp, const float *s3, const float *b3, int batch, int res, int c1, int c3, int in_u8)
+                        const float *wp, const float *s3, const float *b3, int batch, int res, int c1, int c3, int in_u8, int bf16)
 {
     if (c1 != C1 || c3 != C3 || res < 32 || (res % 32) != 0 || batch <= 0) return MBN_EUNSUPPORTED;
     const float *ptrs[] = { w1, s1, b1, wd, s2, b2, wp, s3, b3 };
@@ -244,6 +262,7 @@ int mbn_launch_f32_stem(mbn_context *ctx, hipStream_t stream, float *out, const 
     a.ntiles = (long)batch * a.tiles_y * a.tiles_x;
     long grid = (long)ctx->num_cus * 2;                  // 59.7 KB of LDS per workgroup: two per CU
     if (grid > a.ntiles) grid = a.ntiles;
-    hipLaunchKernelGGL(stem_fused_f32, dim3((unsigned)grid), dim3(256), 0, stream, a);
+    if (bf16) hipLaunchKernelGGL(stem_fused_f32<true>, dim3((unsigned)grid), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(stem_fused_f32<false>, dim3((unsigned)grid), dim3(256), 0, stream, a);
     return MBN_OK;
 }

@@ -98,7 +98,7 @@ int mbn_launch_f32_dwpw(mbn_context *ctx, hipStream_t stream, float *out, const 
                         int pad_left);
 int mbn_launch_f32_stem(mbn_context *ctx, hipStream_t stream, float *out, const float *in, const float *w1,
                         const float *s1, const float *b1, const float *wd, const float *s2, const float *b2,
-                        const float *wp, const float *s3, const float *b3, int batch, int res, int c1, int c3, int in_u8);
+                        const float *wp, const float *s3, const float *b3, int batch, int res, int c1, int c3, int in_u8, int bf16);
 int mbn_launch_convert(mbn_context *ctx, hipStream_t s, void *dst, const void *src, size_t count, int to_bf16);
 int mbn_launch_f32_softmax(mbn_context *ctx, hipStream_t s, float *probs, int32_t *argmax, const float *logits,
                            int batch, int classes);

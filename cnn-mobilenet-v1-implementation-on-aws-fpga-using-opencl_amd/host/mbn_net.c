@@ -162,7 +162,8 @@ int mbn_net_set_streams(mbn_net *net, int n)
 static int stem_fusable(const mbn_net *net, int last_layer)
 {
     const mbn_layer_desc *l = net->plan.layer;
-    return net->fuse_stem && net->dtype == MBN_DT_F32 && !net->keep && last_layer >= 3 && net->plan.n_layers >= 3 &&
+    return net->fuse_stem && !net->keep && last_layer >= 3 && net->plan.n_layers >= 3 &&
+           (net->dtype == MBN_DT_F32 || (net->dtype == MBN_DT_BF16 && net->bf16_filt[2])) &&
            l[0].kind == MBN_L_CONV && l[1].kind == MBN_L_DW && l[2].kind == MBN_L_PW && l[0].in_ch == 3 &&
            l[0].out_ch == 32 && l[1].stride == 1 && l[2].out_ch == 64 && (net->plan.res % 32) == 0;
 }
@@ -343,12 +344,14 @@ static int forward_range(mbn_net *net, const void *images, void *logits, int fir
     if (!layer_ms && stem_fusable(net, last_layer)) {
         /* layers 1-3 in one kernel; the 112x112x32 intermediates stay on chip */
         const mbn_layer_desc *l = net->plan.layer;
-        const size_t per_img = (size_t)l[2].out_rows * l[2].out_cols * l[2].out_ch * sizeof(float);
+        const int bf = net->dtype == MBN_DT_BF16;
+        const size_t per_img = (size_t)l[2].out_rows * l[2].out_cols * l[2].out_ch * (bf ? 2 : sizeof(float));
         char *dst = last_layer == 3 ? (char *)logits + (size_t)first * per_img : (char *)net->act[which] + slot;
-        int rc = (net->input_u8 ? mbn_stem_fused_u8 : mbn_stem_fused)(net->ctx, dst, src, blob_at(net, l[0].w_offset), blob_at(net, l[0].scale_offset),
-                                blob_at(net, l[0].shift_offset), blob_at(net, l[1].w_offset), blob_at(net, l[1].scale_offset),
-                                blob_at(net, l[1].shift_offset), blob_at(net, l[2].w_offset), blob_at(net, l[2].scale_offset),
-                                blob_at(net, l[2].shift_offset), count, net->plan.res, l[0].out_ch, l[2].out_ch, stream);
+        int rc = mbn_stem_fused_ex(net->ctx, dst, src, blob_at(net, l[0].w_offset), blob_at(net, l[0].scale_offset),
+                                   blob_at(net, l[0].shift_offset), blob_at(net, l[1].w_offset), blob_at(net, l[1].scale_offset),
+                                   blob_at(net, l[1].shift_offset), bf ? net->bf16_filt[2] : blob_at(net, l[2].w_offset),
+                                   blob_at(net, l[2].scale_offset), blob_at(net, l[2].shift_offset), count, net->plan.res,
+                                   l[0].out_ch, l[2].out_ch, (net->input_u8 ? MBN_STEM_IN_U8 : 0) | (bf ? MBN_STEM_BF16 : 0), stream);
         if (rc == MBN_OK) {
             if (last_layer != 3) which ^= 1;
             if (first == 0) { net->last_out[0] = net->last_out[1] = NULL; net->last_out[2] = dst; }

@@ -222,6 +222,16 @@ int mbn_stem_fused_u8(mbn_context *ctx, void *out, const void *image_u8, const v
                       const void *wd, const void *s2, const void *b2, const void *wp, const void *s3, const void *b3,
                       int batch, int res, int c1, int c3, void *stream);
 
+/* General form: flags = MBN_STEM_IN_U8 (image is raw uint8 HWC) | MBN_STEM_BF16 (the network's bf16 mode, BASELINE
+ * config 5: `out` is bf16, `wp` is the bf16 copy of the pointwise filter, both on-chip intermediates are rounded to bf16
+ * where the separate launches would store them; everything else — image unless IN_U8, the other filters, scale/shift,
+ * arithmetic — stays fp32). */
+#define MBN_STEM_IN_U8  0x1
+#define MBN_STEM_BF16   0x2
+int mbn_stem_fused_ex(mbn_context *ctx, void *out, const void *image, const void *w1, const void *s1, const void *b1,
+                      const void *wd, const void *s2, const void *b2, const void *wp, const void *s3, const void *b3,
+                      int batch, int res, int c1, int c3, int flags, void *stream);
+
 /* Fused block: a depthwise 3x3 (stride 1 or 2) + pointwise 1x1 pair of the sequence (the pairs L4-5 ...
  * L26-27, MobileNet.c:322-2599; kernel.cl:62-92 + 94-114) in one kernel, each stage followed by its folded-BN
  * scale/shift and ReLU6; the depthwise output never reaches HBM. fp32 NHWC: in [batch][in_rows][in_cols][cin],

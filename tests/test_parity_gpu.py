@@ -934,3 +934,36 @@ def test_f32_dwpw_fused_top_left_padding(pkg, orc, ctx):
                                   n, h, h, 6, 6, cin, cout, 2, 1, 1, None) == 0
     ctx.sync()
     assert_close(d_f.download(want.shape, np.float32), want, TOL_PW, "dwpw top/left padding")
+
+
+def test_bf16_fused_stem_vs_oracle_and_separate_layers(pkg, orc, ctx, tmp_path):
+    """bf16 mode of the fused stem (MBN_STEM_BF16): layer-3 activation vs the oracle's bf16 emulation of layers 1-3 (every
+    layer output rounded to bf16, bf16 pointwise filter) and vs the three separate bf16 launches. Not bit-identical to the
+    separate launches by construction — their pointwise runs on the bf16 MFMA, the stem's on the fp32 MFMA over the same
+    bf16-representable operands, so the fp32 summation order differs — hence the bf16 tolerance on both comparisons."""
+    n, res = 2, 64
+    hw, net = _make_net(pkg, ctx, tmp_path, 1.0, res, 20, n)
+    net.set_dtype(pkg.DT_BF16)
+    imgs = np.random.default_rng(31).uniform(-1, 1, (n, res, res, 3)).astype(np.float32)
+    h = res // 2
+    d_in, d_a, d_b = ctx.to_device(imgs), ctx.alloc(n * h * h * 64 * 2), ctx.alloc(n * h * h * 64 * 2)
+    assert net.fused_layers(3) == 3
+    net.forward(d_in.ptr, d_a.ptr, n, 3)
+    net.set_fuse_stem(False)
+    net.forward(d_in.ptr, d_b.ptr, n, 3)
+    ctx.sync()
+    fused, sep = _bf16_get(pkg, d_a, (n, h, h, 64)), _bf16_get(pkg, d_b, (n, h, h, 64))
+    oplan = orc.plan_build(1.0, res, 20)
+    x = imgs
+    for i in range(3):
+        x = _oracle_layer(orc, oplan, hw.blob, i, x, True)
+    assert_close(fused, x, 2 * TOL_BF16, "bf16 fused stem vs oracle (3 layers of rounding)")
+    assert_close(fused, sep, 2 * TOL_BF16, "bf16 fused stem vs separate bf16 launches")
+    # whole net with the fused stem: logits vs the all-oracle bf16 forward, same bound as the unfused test
+    net.set_fuse_stem(True)
+    d_l = ctx.alloc(n * 20 * 4)
+    net.forward(d_in.ptr, d_l.ptr, n)
+    ctx.sync()
+    full, _ = orc.net_forward(oplan, hw.blob, imgs, bf16=True)
+    assert_close(d_l.download((n, 20), np.float32), np.asarray(full).reshape(n, 20), 6e-2, "bf16 logits, fused stem")
+    net.destroy()
