@@ -17,14 +17,16 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t mbn_make_rsrc(const void *base
 // MODE 0: the MI*32 x NI*32 block lies inside the matrix, no checks. MODE 1: columns inside, rows may run past m — the
 // descriptor (num_records = m*ldc*4 bytes) drops them: the whole offset goes through the VGPR so the hardware range
 // check sees it. MODE 2: explicit row and column checks (ragged column tiles). row0/col0 must be wave-uniform.
-template <int MI, int NI, int MODE>
+// TO = float or __bf16 (the element type of `out`; bf16 is rounded to nearest-even like the plain cast).
+template <int MI, int NI, int MODE, typename TO = float>
 __device__ __forceinline__ void mbn_store_relu6_f32(__amdgpu_buffer_rsrc_t out, unsigned ldc, unsigned row0, int col0,
                                                     int lane, const mbn_f16v (&acc)[MI][NI],
                                                     const float *__restrict__ scale, const float *__restrict__ shift,
                                                     unsigned m, int n)
 {
     const int li = lane & 31, lh = lane >> 5;
-    const unsigned lane_off = ((unsigned)(4 * lh) * ldc + (unsigned)li) * 4u;          // bytes
+    constexpr unsigned ES = sizeof(TO);
+    const unsigned lane_off = ((unsigned)(4 * lh) * ldc + (unsigned)li) * ES;          // bytes
 #pragma unroll
     for (int ni = 0; ni < NI; ni++) {
         const int col = col0 + ni * 32 + li;
@@ -35,11 +37,19 @@ __device__ __forceinline__ void mbn_store_relu6_f32(__amdgpu_buffer_rsrc_t out, 
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const unsigned ro = row0 + mi * 32 + (r & 3) + 8 * (r >> 2);           // + 4*lh per lane
-                const unsigned v = __builtin_bit_cast(unsigned, fminf(fmaxf(fmaf(acc[mi][ni][r], sc, sh), 0.f), 6.f));
-                const unsigned soff = (ro * ldc + (unsigned)(col0 + ni * 32)) * 4u;    // wave-uniform bytes
-                if (MODE == 0) __builtin_amdgcn_raw_buffer_store_b32(v, out, lane_off, soff, 0);
-                else if (MODE == 1) __builtin_amdgcn_raw_buffer_store_b32(v, out, lane_off + soff, 0, 0);
-                else if (cok && ro + 4 * lh < m) __builtin_amdgcn_raw_buffer_store_b32(v, out, lane_off, soff, 0);
+                const float f = fminf(fmaxf(fmaf(acc[mi][ni][r], sc, sh), 0.f), 6.f);
+                const unsigned soff = (ro * ldc + (unsigned)(col0 + ni * 32)) * ES;    // wave-uniform bytes
+                if constexpr (ES == 4) {
+                    const unsigned v = __builtin_bit_cast(unsigned, f);
+                    if (MODE == 0) __builtin_amdgcn_raw_buffer_store_b32(v, out, lane_off, soff, 0);
+                    else if (MODE == 1) __builtin_amdgcn_raw_buffer_store_b32(v, out, lane_off + soff, 0, 0);
+                    else if (cok && ro + 4 * lh < m) __builtin_amdgcn_raw_buffer_store_b32(v, out, lane_off, soff, 0);
+                } else {
+                    const unsigned short v = __builtin_bit_cast(unsigned short, (__bf16)f);
+                    if (MODE == 0) __builtin_amdgcn_raw_buffer_store_b16(v, out, lane_off, soff, 0);
+                    else if (MODE == 1) __builtin_amdgcn_raw_buffer_store_b16(v, out, lane_off + soff, 0, 0);
+                    else if (cok && ro + 4 * lh < m) __builtin_amdgcn_raw_buffer_store_b16(v, out, lane_off, soff, 0);
+                }
             }
     }
 }

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void pw_gemm(PwArgs a)
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int wm_u = (wave_u / WAVES_N) * WM, wn_u = (wave_u % WAVES_N) * WN;      // wave-uniform copies for the epilogue
     const bool g_fast_epilogue = a.fast_epi != 0;
-    const __amdgpu_buffer_rsrc_t orsrc = mbn_make_rsrc(a.out, g_fast_epilogue ? (unsigned)(a.m * a.n * 4) : 0u);
+    const __amdgpu_buffer_rsrc_t orsrc = mbn_make_rsrc(a.out, g_fast_epilogue ? (unsigned)(a.m * a.n * (long)sizeof(T)) : 0u);
     auto stage_glds = [&](int k0, int buf) {
         float *base = lds + buf * (BM + BN) * BKF;
 #pragma unroll
@@ -349,10 +349,10 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void pw_gemm(PwArgs a)
 
         // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
         // One fp32 store instruction writes two 128-B row segments (full cache lines).
-        if (!BF && a.act == MBN_ACT_RELU6 && a.scale && a.shift && cm0 + BM <= a.m && cn0 + BN <= a.n &&
+        if (!(BF && a.out_f32) && a.act == MBN_ACT_RELU6 && a.scale && a.shift && cm0 + BM <= a.m && cn0 + BN <= a.n &&
             g_fast_epilogue) {
             // interior tile of a BN + ReLU6 layer (every pointwise layer of the network): lean stores, mbn_epilogue.h
-            mbn_store_relu6_f32<MI, NI, 0>(orsrc, (unsigned)a.n, (unsigned)cm0 + wm_u, cn0 + wn_u, lane, acc, a.scale,
+            mbn_store_relu6_f32<MI, NI, 0, T>(orsrc, (unsigned)a.n, (unsigned)cm0 + wm_u, cn0 + wn_u, lane, acc, a.scale,
                                               a.shift, (unsigned)a.m, a.n);
         } else
 #pragma unroll
@@ -473,6 +473,8 @@ int mbn_launch_f32_pointwise(const mbn_call &c, void *out, const void *in, const
         switch (tile) {
         case 3: launch_cfg<__bf16, 64, 64, 32, 32>(a, c.stream, cus); break;
         case 5: launch_cfg<__bf16, 128, 128, 32, 64>(a, c.stream, cus); break;
+        case 7: launch_cfg<__bf16, 128, 64, 32, 32>(a, c.stream, cus); break;    // 8 waves of 32x32, 48 KB LDS: 3 WG = 24 waves per CU
+        case 8: launch_cfg<__bf16, 64, 128, 32, 32>(a, c.stream, cus); break;
         default: launch_cfg<__bf16, 128, 64, 64, 32>(a, c.stream, cus); break;
         }
         return MBN_OK;
