@@ -37,7 +37,7 @@ struct StemArgs {
     const uint8_t *in8;         // raw uint8 HWC image instead of `in`: normalised at load, x/127.5 - 1 (MBN_IO_IN_U8)
     int batch, res, h;          // input side, conv1/dw/pw side (res/2)
     int tiles_y, tiles_x;
-    long ntiles;
+    unsigned ntiles;        // < 2^31 (launcher checks): tile indices stay 32-bit, the per-tile index math is scalar and cheap
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return (row << 5) + (((chunk ^ (row >> 1)) & 7) << 2); }
@@ -56,12 +56,12 @@ constexpr int NPF = (PR * PAIRS + 255) / 256;  // float2 prefetch registers per 
 
 // Phase A, first half: this lane's float2 pieces of tile t's input patch (rows 16ty-2 .. 16ty+18, floats 96tx-6 ..
 // 96tx+105 of each row), zero outside the image. Pair boundaries never straddle the image edge (96tx-6 and 3*res even).
-__device__ __forceinline__ void patch_load(const StemArgs &a, long t, int tid, f2 (&pf)[NPF])
+__device__ __forceinline__ void patch_load(const StemArgs &a, unsigned t, int tid, f2 (&pf)[NPF])
 {
-    const int tx = (int)(t % a.tiles_x);
-    const long q0 = t / a.tiles_x;
-    const int ty = (int)(q0 % a.tiles_y);
-    const long n = q0 / a.tiles_y;
+    const int tx = (int)(t % (unsigned)a.tiles_x);
+    const unsigned q0 = t / (unsigned)a.tiles_x;
+    const int ty = (int)(q0 % (unsigned)a.tiles_y);
+    const long n = q0 / (unsigned)a.tiles_y;
     const long img = n * a.res * a.res * 3;
     const int iy0 = 2 * (TH * ty - 1), fx0 = 6 * (TW * tx - 1), rowf = a.res * 3;
 #pragma unroll
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void stem_fused_f32(StemArgs a)   // 2 wave
     for (int ni = 0; ni < 2; ni++) { s3[ni] = a.s3[ni * 32 + li]; b3[ni] = a.b3[ni * 32 + li]; }
 
     f2 pf[NPF];
-    if ((long)blockIdx.x < a.ntiles) {
+    if (blockIdx.x < a.ntiles) {
         patch_load(a, blockIdx.x, tid, pf);
         patch_store(in_s, tid, pf);
     }
@@ -140,12 +140,12 @@ __global__ __launch_bounds__(256, 2) void stem_fused_f32(StemArgs a)   // 2 wave
     // phase C item: tile row cy, pixels cx .. cx+3
     const int cy = tid >> 5, cx = ((tid >> 3) & 3) * 4;
 
-    for (long t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
-        const int tx = (int)(t % a.tiles_x);
-        const long q0 = t / a.tiles_x;
-        const int ty = (int)(q0 % a.tiles_y);
-        const long n = q0 / a.tiles_y;
-        const long tnext = t + gridDim.x;
+    for (unsigned t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
+        const int tx = (int)(t % (unsigned)a.tiles_x);
+        const unsigned q0 = t / (unsigned)a.tiles_x;
+        const int ty = (int)(q0 % (unsigned)a.tiles_y);
+        const long n = q0 / (unsigned)a.tiles_y;
+        const unsigned tnext = t + gridDim.x;
         if (tnext < a.ntiles) patch_load(a, tnext, tid, pf);              // in flight while phase B computes
 
         // ---- B. conv1 (3x3x3, stride 2, pad 0 top/left) + BN + ReLU6 over the 10 x 18 region, 6 pixels x 4 ch per lane
@@ -259,9 +259,10 @@ int mbn_launch_f32_stem(mbn_context *ctx, hipStream_t stream, float *out, const 
     a.out = out; a.in = in; a.w1 = w1; a.s1 = s1; a.b1 = b1; a.wd = wd; a.s2 = s2; a.b2 = b2; a.wp = wp; a.s3 = s3; a.b3 = b3;
     a.batch = batch; a.res = res; a.h = res / 2;
     a.tiles_y = a.h / TH; a.tiles_x = a.h / TW;
-    a.ntiles = (long)batch * a.tiles_y * a.tiles_x;
+    if ((long)batch * a.tiles_y * a.tiles_x >= 0x7fffffffL) return MBN_EUNSUPPORTED;
+    a.ntiles = (unsigned)((long)batch * a.tiles_y * a.tiles_x);
     long grid = (long)ctx->num_cus * 2;                  // 59.7 KB of LDS per workgroup: two per CU
-    if (grid > a.ntiles) grid = a.ntiles;
+    if (grid > (long)a.ntiles) grid = (long)a.ntiles;
     if (bf16) hipLaunchKernelGGL(stem_fused_f32<true>, dim3((unsigned)grid), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(stem_fused_f32<false>, dim3((unsigned)grid), dim3(256), 0, stream, a);
     return MBN_OK;
