@@ -967,3 +967,31 @@ def test_bf16_fused_stem_vs_oracle_and_separate_layers(pkg, orc, ctx, tmp_path):
     full, _ = orc.net_forward(oplan, hw.blob, imgs, bf16=True)
     assert_close(d_l.download((n, 20), np.float32), np.asarray(full).reshape(n, 20), 6e-2, "bf16 logits, fused stem")
     net.destroy()
+
+
+def test_net_full_size_fused_equals_unfused(pkg, ctx, tmp_path):
+    """BASELINE.json's full geometry (1.0x224, 1000 classes), batch 24: the default runner (fused stem + fused blocks
+    4-11) and the one-launch-per-layer runner produce bit-identical logits; so does the uint8 front-end against the
+    separate normalise pass. Size-independent property — no oracle run at this size."""
+    n = 24
+    hw, net = _make_net(pkg, ctx, tmp_path, 1.0, 224, 1000, n)
+    rng = np.random.default_rng(99)
+    u8 = rng.integers(0, 256, (n, 224, 224, 3), dtype=np.uint8)
+    d_u, d_f = ctx.to_device(u8), ctx.alloc(u8.size * 4)
+    assert ctx.lib.mbn_normalize_u8_to_f32(ctx.h, d_f.ptr, d_u.ptr, u8.size, 1 / 127.5, -1.0, None) == 0
+    d_a, d_b, d_c = ctx.alloc(n * 4000), ctx.alloc(n * 4000), ctx.alloc(n * 4000)
+    assert [c for _, c in net.launches(n)][:5] == [3, 2, 2, 2, 2]
+    net.forward(d_f.ptr, d_a.ptr, n)
+    net.set_fuse_stem(False)
+    net.set_fuse_blocks(0)
+    assert len(net.launches(n)) == 29
+    net.forward(d_f.ptr, d_b.ptr, n)
+    net.set_fuse_stem(True)
+    net.set_fuse_blocks(0xFFFFFFFE)                        # every block the kernel accepts (the 7x7 ones fall back)
+    net.set_input_u8(True)
+    net.forward(d_u.ptr, d_c.ptr, n)
+    ctx.sync()
+    a, b, c = (d.download((n, 1000), np.float32) for d in (d_a, d_b, d_c))
+    assert np.isfinite(a).all() and float(np.abs(a).max()) > 0
+    assert np.array_equal(a, b) and np.array_equal(a, c)
+    net.destroy()
