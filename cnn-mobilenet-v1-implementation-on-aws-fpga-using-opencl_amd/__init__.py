@@ -163,6 +163,7 @@ def load():
         lib.mbn_stem_fused_ex.argtypes = [vp] + [vp] * 11 + [ci, ci, ci, ci, ci, vp]
         lib.mbn_net_set_input_u8.argtypes = [vp, ci]
         lib.mbn_dwpw_fused.argtypes = [vp] + [vp] * 8 + [ci] * 10 + [vp]
+        lib.mbn_dwpw_fused_bf16.argtypes = [vp] + [vp] * 8 + [ci] * 10 + [vp]
         lib.mbn_softmax_topk_f32.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, vp]
         lib.mbn_classifier_tail.argtypes = [vp] * 9 + [ci] * 6 + [vp]
         lib.mbn_graph_begin.argtypes = [vp, vp]

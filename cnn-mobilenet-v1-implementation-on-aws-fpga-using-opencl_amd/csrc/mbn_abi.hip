@@ -575,6 +575,22 @@ int mbn_dwpw_fused(mbn_context *ctx, void *out, const void *in, const void *wd, 
                                          in_rows, in_cols, out_rows, out_cols, cin, cout, stride, pad_top, pad_left));
 }
 
+int mbn_dwpw_fused_bf16(mbn_context *ctx, void *out, const void *in, const void *wd, const void *s2, const void *b2,
+                        const void *wp_bf16, const void *s3, const void *b3, int batch, int in_rows, int in_cols, int out_rows,
+                        int out_cols, int cin, int cout, int stride, int pad_top, int pad_left, void *stream)
+{
+    if (!ctx) return MBN_EINVAL;
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    const int rc = mbn_bf16_dwpw_check(out, in, (const float *)wd, (const float *)s2, (const float *)b2, wp_bf16,
+                                       (const float *)s3, (const float *)b3, batch, in_rows, in_cols, out_rows, out_cols, cin,
+                                       cout, stride, pad_top, pad_left);
+    if (rc != MBN_OK) return rc;
+    Scope sc(ctx, s);
+    return sc.finish(mbn_launch_bf16_dwpw(ctx, s, out, in, (const float *)wd, (const float *)s2, (const float *)b2, wp_bf16,
+                                          (const float *)s3, (const float *)b3, batch, in_rows, in_cols, out_rows, out_cols,
+                                          cin, cout, stride, pad_top, pad_left));
+}
+
 int mbn_convert_f32_to_bf16(mbn_context *ctx, void *dst_bf16, const void *src_f32, size_t count, void *stream)
 {
     if (!ctx || !dst_bf16 || !src_f32) return MBN_EINVAL;

@@ -192,14 +192,17 @@ int mbn_net_fused_layers(const mbn_net *net, int last_layer, int *count)
  * nothing kept, enabled in the mask, and inside the kernel's envelope (mbn.h: mbn_dwpw_fused) */
 static int block_fusable(const mbn_net *net, int i, int count, int last_layer)
 {
-    if (net->dtype != MBN_DT_F32 || net->keep || i + 2 > last_layer || i + 1 >= net->plan.n_layers || i + 1 >= 32) return 0;
+    const int bf = net->dtype == MBN_DT_BF16;
+    if ((net->dtype != MBN_DT_F32 && !bf) || net->keep || i + 2 > last_layer || i + 1 >= net->plan.n_layers || i + 1 >= 32) return 0;
+    if (bf && (!net->bf16_filt[i + 1] || (net->plan.layer[i].in_ch % 64) != 0)) return 0;
     if (!((net->fuse_blocks >> (i + 1)) & 1u)) return 0;
     const mbn_layer_desc *d = &net->plan.layer[i], *p = &net->plan.layer[i + 1];
     if (d->kind != MBN_L_DW || p->kind != MBN_L_PW || (d->stride != 1 && d->stride != 2)) return 0;
     if (d->in_ch < 32 || (d->in_ch % 32) != 0 || d->in_ch > 1024 || p->out_ch < 128 || (p->out_ch % 128) != 0) return 0;
     if ((d->out_cols & 1) || p->in_ch != d->out_ch) return 0;
-    if (4.0 * count * d->in_rows * d->in_cols * d->in_ch >= 4026531840.0) return 0;
-    if (4.0 * count * p->out_rows * p->out_cols * p->out_ch >= 4294967296.0) return 0;
+    const double es = bf ? 2.0 : 4.0;
+    if (es * count * d->in_rows * d->in_cols * d->in_ch >= 4026531840.0) return 0;
+    if (es * count * p->out_rows * p->out_cols * p->out_ch >= 4294967296.0) return 0;
     return 1;
 }
 
@@ -368,12 +371,14 @@ static int forward_range(mbn_net *net, const void *images, void *logits, int fir
         if (!layer_ms && block_fusable(net, i, count, last_layer)) {
             /* depthwise + pointwise in one kernel; the depthwise output stays in LDS */
             const mbn_layer_desc *lp = &net->plan.layer[i + 1];
-            const size_t per_img2 = (size_t)lp->out_rows * lp->out_cols * lp->out_ch * sizeof(float);
+            const int bf = net->dtype == MBN_DT_BF16;
+            const size_t per_img2 = (size_t)lp->out_rows * lp->out_cols * lp->out_ch * (bf ? 2 : sizeof(float));
             char *dst2 = (i + 1 == last_layer - 1) ? (char *)logits + (size_t)first * per_img2 : (char *)net->act[which] + slot;
-            int rc = mbn_dwpw_fused(net->ctx, dst2, src, blob_at(net, l->w_offset), blob_at(net, l->scale_offset),
-                                    blob_at(net, l->shift_offset), blob_at(net, lp->w_offset), blob_at(net, lp->scale_offset),
-                                    blob_at(net, lp->shift_offset), count, l->in_rows, l->in_cols, l->out_rows, l->out_cols,
-                                    l->in_ch, lp->out_ch, l->stride, l->pad_top, l->pad_left, stream);
+            int rc = (bf ? mbn_dwpw_fused_bf16 : mbn_dwpw_fused)(
+                net->ctx, dst2, src, blob_at(net, l->w_offset), blob_at(net, l->scale_offset), blob_at(net, l->shift_offset),
+                bf ? net->bf16_filt[i + 1] : blob_at(net, lp->w_offset), blob_at(net, lp->scale_offset),
+                blob_at(net, lp->shift_offset), count, l->in_rows, l->in_cols, l->out_rows, l->out_cols, l->in_ch, lp->out_ch,
+                l->stride, l->pad_top, l->pad_left, stream);
             if (rc == MBN_OK) {
                 if (i + 1 != last_layer - 1) which ^= 1;
                 if (first == 0) { net->last_out[i] = NULL; net->last_out[i + 1] = dst2; }

@@ -248,6 +248,13 @@ int mbn_dwpw_fused(mbn_context *ctx, void *out, const void *in, const void *wd, 
 int mbn_softmax_f32(mbn_context *ctx, void *probs, void *argmax_i32, const void *logits, int batch,
                     int classes, void *stream);
 
+/* The same block in the network's bf16 mode (BASELINE config 5): in/out are bf16 NHWC, wp_bf16 is the bf16 copy of the
+ * pointwise filter [cout][cin]; the depthwise filter and all scale/shift vectors stay fp32, arithmetic is fp32, the
+ * depthwise output is rounded to bf16 where the separate launch would store it. cin must be a multiple of 64. */
+int mbn_dwpw_fused_bf16(mbn_context *ctx, void *out, const void *in, const void *wd, const void *s2, const void *b2,
+                        const void *wp_bf16, const void *s3, const void *b3, int batch, int in_rows, int in_cols, int out_rows,
+                        int out_cols, int cin, int cout, int stride, int pad_top, int pad_left, void *stream);
+
 /* softmax + top-k on device: for every image the k <= 8 most probable classes, most probable first
  * (ties -> lowest index), topk_idx [batch][k] int32 (0-based, -1 when classes < k) and topk_prob [batch][k] fp32;
  * probs (may be NULL) additionally receives the full [batch][classes] distribution. Only 2k values per image have to

@@ -995,3 +995,34 @@ def test_net_full_size_fused_equals_unfused(pkg, ctx, tmp_path):
     assert np.isfinite(a).all() and float(np.abs(a).max()) > 0
     assert np.array_equal(a, b) and np.array_equal(a, c)
     net.destroy()
+
+
+@pytest.mark.parametrize("shape", [(2, 112, 64, 128, 2), (2, 56, 128, 128, 1), (2, 56, 128, 256, 2), (2, 28, 256, 256, 1),
+                                   (1, 28, 256, 512, 2), (3, 14, 64, 128, 1), (1, 6, 192, 384, 1), (2, 14, 512, 512, 1)])
+def test_bf16_dwpw_fused(pkg, orc, ctx, shape):
+    """mbn_dwpw_fused_bf16 vs the oracle's bf16 emulation of the pair (depthwise output rounded to bf16, bf16 pointwise
+    filter, output rounded) and vs the two separate bf16 launches; bf16 tolerance (the pointwise summation order differs)."""
+    n, h, cin, cout, stride = shape
+    rng = np.random.default_rng(h * 13 + cin + cout + stride)
+    x = orc.bf16_round(rng.uniform(0, 4, (n, h, h, cin)).astype(np.float32))
+    wd = rng.normal(0, 0.5, (3, 3, cin)).astype(np.float32)
+    wp = orc.bf16_round(rng.normal(0, (2.0 / cin) ** 0.5, (cout, cin)).astype(np.float32))
+    s2, s3 = rng.uniform(0.5, 1.5, cin).astype(np.float32), rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    b2, b3 = rng.normal(0, 0.1, cin).astype(np.float32), rng.normal(0, 0.1, cout).astype(np.float32)
+    oh = (h + stride - 1) // stride
+    pad = max((oh - 1) * stride + 3 - h, 0) // 2
+    mid = orc.bf16_round(orc.f32_depthwise(x, wd, s2, b2, stride, 2, pad_top=pad, pad_left=pad))
+    want = orc.bf16_round(orc.f32_pointwise(mid.reshape(-1, cin), wp, s3, b3, 2).reshape(n, oh, oh, cout))
+    d_x, d_wp = _bf16_dev(pkg, ctx, x), _bf16_dev(pkg, ctx, wp)
+    d = [ctx.to_device(a) for a in (wd, s2, b2, s3, b3)]
+    d_f, d_m, d_u = ctx.alloc(want.size * 2), ctx.alloc(mid.size * 2), ctx.alloc(want.size * 2)
+    rc = ctx.lib.mbn_dwpw_fused_bf16(ctx.h, d_f.ptr, d_x.ptr, d[0].ptr, d[1].ptr, d[2].ptr, d_wp.ptr, d[3].ptr, d[4].ptr,
+                                     n, h, h, oh, oh, cin, cout, stride, pad, pad, None)
+    assert rc == 0, rc
+    ctx.depthwise(d_m.ptr, d_x.ptr, d[0].ptr, oh, oh, 3, stride, cin,
+                  pkg.make_ext(batch=n, dtype=pkg.DT_BF16, act=2, pad_top=pad, pad_left=pad, in_rows=h, in_cols=h, scale=d[1].ptr, shift=d[2].ptr))
+    ctx.pointwise(d_u.ptr, d_m.ptr, d_wp.ptr, n * oh * oh, 1, cin, cout, pkg.make_ext(batch=1, dtype=pkg.DT_BF16, act=2, scale=d[3].ptr, shift=d[4].ptr))
+    ctx.sync()
+    fused, sep = _bf16_get(pkg, d_f, want.shape), _bf16_get(pkg, d_u, want.shape)
+    assert_close(fused, want, TOL_BF16, "bf16 fused block %s vs oracle" % (shape,))
+    assert_close(fused, sep, TOL_BF16, "bf16 fused block %s vs separate launches" % (shape,))
