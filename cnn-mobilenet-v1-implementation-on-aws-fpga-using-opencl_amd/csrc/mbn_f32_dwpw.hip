@@ -47,6 +47,7 @@ struct DwPwArgs {
     int pad_top, pad_left;
     int mt, nt;
     unsigned in_bytes;
+    unsigned wo_m, wo_s, ho_m, ho_s;   // floor(v / wo) = umulhi(v, wo_m) >> wo_s for v < 2^31 (m == 0: the divisor is 1)
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return (row << 5) + (((chunk ^ (row >> 1)) & 7) << 2); }
@@ -102,17 +103,23 @@ __global__ __launch_bounds__(NT) void dwpw_f32(DwPwArgs a)
             const int n0 = (lid % a.nt) * BN;
             const unsigned m = (unsigned)(lid / a.nt) * BM + 2 * pair;
             const bool mok = m < mtot;
-            const unsigned x = m % (unsigned)a.wo, q = m / (unsigned)a.wo;
-            const unsigned y = q % (unsigned)a.ho, n = q / (unsigned)a.ho;
+            // (n, y, x) of the pixel by multiply-high division (host-computed magic numbers), then every tap offset as
+            // base + dy * row stride + j * column stride: this runs once per tile per lane and used to cost ~400 VALU
+            // instructions (two 32-bit divisions + 12-15 independent offset computations)
+            const unsigned q = a.wo_m ? __umulhi(m, a.wo_m) >> a.wo_s : m;
+            const unsigned x = m - q * (unsigned)a.wo;
+            const unsigned n = a.ho_m ? __umulhi(q, a.ho_m) >> a.ho_s : q;
+            const unsigned y = q - n * (unsigned)a.ho;
+            const int iy0 = (int)y * S - a.pad_top, ix0 = (int)x * S - a.pad_left;
+            const unsigned cs = (unsigned)a.cin * 4u, rs = (unsigned)a.w * cs;                    // column / row stride in bytes
+            const unsigned base = ((n * a.h + iy0) * a.w + ix0) * cs + (unsigned)(c4 * 4) * 4u;         // wraps for taps that are masked out below
 #pragma unroll
             for (int dy = 0; dy < 3; dy++) {
-                const int iy = (int)y * S + dy - a.pad_top;
-                const bool rok = mok && iy >= 0 && iy < a.h;
+                const bool rok = mok && (unsigned)(iy0 + dy) < (unsigned)a.h;
 #pragma unroll
                 for (int j = 0; j < XC; j++) {
-                    const int ix = (int)x * S + j - a.pad_left;
-                    const bool ok = rok && ix >= 0 && ix < a.w;
-                    off[dy][j] = ok ? (((n * a.h + iy) * a.w + ix) * a.cin + c4 * 4) * 4u : OOB;
+                    const bool ok = rok && (unsigned)(ix0 + j) < (unsigned)a.w;
+                    off[dy][j] = ok ? base + dy * rs + j * cs : OOB;
                 }
             }
 #pragma unroll
@@ -289,6 +296,8 @@ int mbn_launch_f32_dwpw(mbn_context *ctx, hipStream_t stream, float *out, const 
     a.m = (long)batch * out_rows * out_cols;
     a.h = in_rows; a.w = in_cols; a.ho = out_rows; a.wo = out_cols;
     a.cin = cin; a.cout = cout; a.pad_top = pad_top; a.pad_left = pad_left;
+    mbn_udiv_magic((unsigned)out_cols, &a.wo_m, &a.wo_s);
+    mbn_udiv_magic((unsigned)out_rows, &a.ho_m, &a.ho_s);
     a.in_bytes = (unsigned)(4.0 * batch * in_rows * in_cols * cin);
     const bool wide = (cout % 256) == 0 && g_mbn_tune.pw_tile != 1;      // pw_tile=1: force the 128-column tile (A/B hook)
     if (stride == 1) {

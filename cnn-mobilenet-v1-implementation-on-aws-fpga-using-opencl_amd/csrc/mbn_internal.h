@@ -89,6 +89,17 @@ int mbn_launch_f32_depthwise(const mbn_call &c, void *out, const void *in, const
 int mbn_launch_f32_pointwise(const mbn_call &c, void *out, const void *in, const void *filt, long m, int cin,
                              int op_size);
 int mbn_launch_f32_pool(const mbn_call &c, void *out, const void *in, int rows, int cols, int fs, int channels);
+// floor(v / d) == umulhi(v, *m) >> *s for every v < 2^31 (d >= 2); d == 1 gives *m = 0 (callers skip the multiply)
+static inline void mbn_udiv_magic(unsigned d, unsigned *m, unsigned *s)
+{
+    if (d <= 1) { *m = 0; *s = 0; return; }
+    unsigned l = 0;
+    while ((1u << l) < d) l++;                           // l = ceil(log2 d) >= 1
+    const unsigned long long p = 1ull << (31 + l);
+    *m = (unsigned)((p + d - 1) / d);                    // ceil(2^(31+l) / d) <= 2^32 - 1 for d >= 2 (== 2^31 for powers of two)
+    *s = l - 1;
+}
+
 int mbn_f32_dwpw_check(const float *out, const float *in, const float *wd, const float *s2, const float *b2,
                        const float *wp, const float *s3, const float *b3, int batch, int in_rows, int in_cols,
                        int out_rows, int out_cols, int cin, int cout, int stride, int pad_top, int pad_left);
