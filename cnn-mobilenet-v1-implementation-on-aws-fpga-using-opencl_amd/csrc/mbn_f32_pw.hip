@@ -129,15 +129,16 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void pw_gemm(PwArgs a)
         for (int p = 0; p < A_LD; p++) {
             long gm = m0 + st_row[p];
             if (gm >= a.m) gm = a.m - 1;             // clamp: rows past M are computed but never stored
-            a_src[p] = gin + gm * a.k + (GLDS ? ((st_ch ^ (st_row[p] >> 1)) & 7) : st_ch) * EPC;
-            a_vo[p] = (unsigned)((gm * a.k + ((st_ch ^ (st_row[p] >> 1)) & 7) * EPC) * (long)sizeof(T));
+            // the pipelined loop addresses by descriptor + 32-bit offset, the other loops by pointer: set up only one of them
+            if (GLDS && a.loop2) a_vo[p] = ((unsigned)gm * (unsigned)a.k + ((st_ch ^ (st_row[p] >> 1)) & 7) * EPC) * (unsigned)sizeof(T);
+            else a_src[p] = gin + gm * a.k + (GLDS ? ((st_ch ^ (st_row[p] >> 1)) & 7) : st_ch) * EPC;
         }
 #pragma unroll
         for (int p = 0; p < B_LD; p++) {
             int gn = n0 + st_row[p];
             if (gn >= a.n) gn = a.n - 1;
-            b_src[p] = gfilt + (long)gn * a.k + (GLDS ? ((st_ch ^ (st_row[p] >> 1)) & 7) : st_ch) * EPC;
-            b_vo[p] = (unsigned)(((long)gn * a.k + ((st_ch ^ (st_row[p] >> 1)) & 7) * EPC) * (long)sizeof(T));
+            if (GLDS && a.loop2) b_vo[p] = ((unsigned)gn * (unsigned)a.k + ((st_ch ^ (st_row[p] >> 1)) & 7) * EPC) * (unsigned)sizeof(T);
+            else b_src[p] = gfilt + (long)gn * a.k + (GLDS ? ((st_ch ^ (st_row[p] >> 1)) & 7) : st_ch) * EPC;
         }
     };
     auto stage_load = [&](int k0) {
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void pw_gemm(PwArgs a)
     int vb = blockIdx.x;
     if (vb >= nwg) return;
     set_tile(vb, m0, n0);
-    if (GLDS) stage_glds(0, 0);
+    if (GLDS) { if (a.loop2) stage_glds2(0, 0); else stage_glds(0, 0); }
     else stage_load(0);
 
     for (;;) {
@@ -343,7 +344,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void pw_gemm(PwArgs a)
         const bool more = nvb < nwg;
         if (more) {
             set_tile(nvb, m0, n0);
-            if (GLDS) stage_glds(0, 0);      // both buffers are free after the K loop's last barrier
+            if (GLDS) { if (a.loop2) stage_glds2(0, 0); else stage_glds(0, 0); }      // both buffers are free after the K loop's last barrier
             else stage_load(0);
         }
 
