@@ -453,3 +453,22 @@ def test_c_host_weight_tooling_cli(pkg, tmp_path):
     assert np.array_equal(back, hw.blob[27 * 4:27 * 4 + 100])
     hw.free()
     assert subprocess.run([exe, "--inspect", "/nonexistent.h5"], capture_output=True).returncode == 1
+
+
+def test_udiv_magic_formula():
+    """The multiply-high division the fused-block kernels use for (n, y, x) of a flattened pixel index
+    (csrc/mbn_internal.h: mbn_udiv_magic): floor(v / d) == ((v * M) >> 32) >> s for every v < 2^31, with
+    l = ceil(log2 d), M = ceil(2^(31+l) / d), s = l - 1. Checked here on the formula itself (pure integers): every divisor
+    up to 4096 against edge values and random values."""
+    import random
+    rnd = random.Random(7)
+    for d in list(range(2, 4097)) + [5000, 65535, 65536, 65537, (1 << 20) + 3]:
+        l = (d - 1).bit_length()
+        m = -(-(1 << (31 + l)) // d)
+        assert m < (1 << 32), d
+        s = l - 1
+        vals = [0, 1, d - 1, d, d + 1, 2 * d - 1, (1 << 31) - 1, (1 << 31) - d, ((1 << 31) - 1) // d * d, ((1 << 31) - 1) // d * d - 1]
+        vals += [rnd.randrange(1 << 31) for _ in range(64)]
+        for v in vals:
+            if 0 <= v < (1 << 31):
+                assert ((v * m) >> 32) >> s == v // d, (v, d)
