@@ -424,7 +424,16 @@ int  mbn_net_layer_output(mbn_net *net, int index, void **dptr, size_t *floats_p
 const char *mbn_version(void);
 
 /* Tuning hooks, process-wide: select among built kernel variants / launch heuristics for A/B measurements
- * (tools/layer_bench.py). 0 always means "the shipped default". Unknown key => MBN_ENOTFOUND. */
+ * (tools/layer_bench.py, tools/block_bench.py). 0 always means "the shipped default". Unknown key => MBN_ENOTFOUND.
+ *   pw_tile      1..8: GEMM tile shape of mbn_pointwise (see mbn_f32_pw.hip); 1 also forces the 128-column tile of
+ *                mbn_dwpw_fused(_bf16)
+ *   misc         workgroups per CU of the persistent GEMM grid (1000 = one tile per workgroup)
+ *   pw_stage     1 = stage GEMM operands through registers instead of direct-to-LDS loads
+ *   conv_variant 1 = generic conv1 kernel; 8 = GEMM without the software-pipelined k-loop; 9 = GEMM with the general epilogue
+ *   dw_variant   depthwise: bits 0-1 = output columns per lane, bit 4 = lanes across all channels, bit 5 = bf16 with
+ *                4-channel lanes
+ *   dw_nseg      depthwise: row segments per image
+ *   net_stagger  layers between the starts of consecutive sub-batch streams (mbn_net_set_streams) */
 int  mbn_tune_set(const char *key, int value);
 int  mbn_tune_get(const char *key, int *value);
 
