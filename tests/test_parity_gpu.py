@@ -969,11 +969,11 @@ def test_bf16_fused_stem_vs_oracle_and_separate_layers(pkg, orc, ctx, tmp_path):
     net.destroy()
 
 
-def test_net_full_size_fused_equals_unfused(pkg, ctx, tmp_path):
-    """BASELINE.json's full geometry (1.0x224, 1000 classes), batch 24: the default runner (fused stem + fused blocks
+@pytest.mark.parametrize("n", [7, 24])
+def test_net_full_size_fused_equals_unfused(pkg, ctx, tmp_path, n):
+    """BASELINE.json's full geometry (1.0x224, 1000 classes), batch 7 (ragged last row tile in every GEMM-shaped kernel) and 24: the default runner (fused stem + fused blocks
     4-11) and the one-launch-per-layer runner produce bit-identical logits; so does the uint8 front-end against the
     separate normalise pass. Size-independent property — no oracle run at this size."""
-    n = 24
     hw, net = _make_net(pkg, ctx, tmp_path, 1.0, 224, 1000, n)
     rng = np.random.default_rng(99)
     u8 = rng.integers(0, 256, (n, 224, 224, 3), dtype=np.uint8)
