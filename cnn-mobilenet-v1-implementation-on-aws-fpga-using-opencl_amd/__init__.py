@@ -138,6 +138,8 @@ def load():
         lib.mbn_profile_begin.argtypes = [vp, ci]
         lib.mbn_profile_end.argtypes = [vp, C.POINTER(C.c_float), ci, C.POINTER(ci)]
         lib.mbn_profile_pause.argtypes = [vp, ci]
+        lib.mbn_mark.argtypes = [vp, vp]
+        lib.mbn_marks_read.argtypes = [vp, C.POINTER(C.c_float), ci, C.POINTER(ci)]
         ext = C.POINTER(LayerExt)
         lib.mbn_convolute.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ext]
         lib.mbn_depthwise.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, ext]
@@ -309,6 +311,15 @@ class Context:
         ms = (C.c_float * capacity)()
         n = C.c_int()
         _chk(self.lib.mbn_profile_end(self.h, ms, capacity, C.byref(n)), self.last_error())
+        return [ms[i] for i in range(n.value)]
+
+    def mark(self, stream=None):
+        _chk(self.lib.mbn_mark(self.h, stream))
+
+    def marks_read(self, capacity: int):
+        ms = (C.c_float * max(capacity, 1))()
+        n = C.c_int()
+        _chk(self.lib.mbn_marks_read(self.h, ms, capacity, C.byref(n)), self.last_error())
         return [ms[i] for i in range(n.value)]
 
     def close(self):

@@ -9,9 +9,51 @@
 
 mbn_tunables g_mbn_tune;
 
+namespace {
+
+// Buffer-size guard. Every buffer handed out by mbn_alloc is recorded with its size; when a pointer given to a layer call
+// lies inside one of them, the bytes the call is about to touch must fit in what is left of that allocation, otherwise
+// the call is a caller error (MBN_EINVAL) instead of a GPU memory fault. Caller-owned memory (hipMalloc, a torch tensor)
+// is not in the map and is not checked. Cause on record (round 1, gpurun_out/fault.log): the C host uploaded a uint8
+// image (3*96*96*3 bytes) and issued the fp32 first-layer kernel on it, which read 4x the buffer.
+struct Span { const void *p; double bytes; const char *what; };
+
+int span_check(mbn_context *ctx, const Span *sp, int n)
+{
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (ctx->allocs.empty()) return MBN_OK;
+    for (int i = 0; i < n; i++) {
+        if (!sp[i].p || sp[i].bytes <= 0) continue;
+        const uintptr_t a = (uintptr_t)sp[i].p;
+        auto it = ctx->allocs.upper_bound(a);
+        if (it == ctx->allocs.begin()) continue;
+        --it;
+        if (a >= it->first + it->second) continue;                 // not inside any of our buffers
+        const double room = (double)(it->first + it->second - a);
+        if (sp[i].bytes > room) {
+            snprintf(ctx->last_error, sizeof(ctx->last_error), "%s: call touches %.0f bytes, %.0f left in its %zu-byte mbn_alloc buffer",
+                     sp[i].what, sp[i].bytes, room, it->second);
+            return MBN_EINVAL;
+        }
+    }
+    return MBN_OK;
+}
+#define MBN_SPANS(ctx, ...)                                                            \
+    do {                                                                               \
+        const Span _sp[] = { __VA_ARGS__ };                                            \
+        const int _rc = span_check((ctx), _sp, (int)(sizeof(_sp) / sizeof(_sp[0])));   \
+        if (_rc != MBN_OK) return _rc;                                                 \
+    } while (0)
+
+// element size of an activation tensor of the call: bf16 mode stores 2 bytes unless the io flag says fp32
+inline double esz_in(const mbn_call &c) { return c.dtype == MBN_DT_BF16 && !(c.io_flags & MBN_IO_IN_F32) ? 2.0 : 4.0; }
+inline double esz_out(const mbn_call &c) { return c.dtype == MBN_DT_BF16 && !(c.io_flags & MBN_IO_OUT_F32) ? 2.0 : 4.0; }
+
+}   // namespace
+
 extern "C" {
 
-static int *tune_slot(const char *key)
+static std::atomic<int> *tune_slot(const char *key)
 {
     if (!key) return nullptr;
     if (!strcmp(key, "dw_variant")) return &g_mbn_tune.dw_variant;
@@ -26,17 +68,17 @@ static int *tune_slot(const char *key)
 
 int mbn_tune_set(const char *key, int value)
 {
-    int *p = tune_slot(key);
+    std::atomic<int> *p = tune_slot(key);
     if (!p) return MBN_ENOTFOUND;
-    *p = value;
+    p->store(value, std::memory_order_relaxed);
     return MBN_OK;
 }
 
 int mbn_tune_get(const char *key, int *value)
 {
-    int *p = tune_slot(key);
+    std::atomic<int> *p = tune_slot(key);
     if (!p || !value) return p ? MBN_EINVAL : MBN_ENOTFOUND;
-    *value = *p;
+    *value = p->load(std::memory_order_relaxed);
     return MBN_OK;
 }
 
@@ -84,9 +126,10 @@ int mbn_shutdown(mbn_context *ctx)
     if (!ctx) return MBN_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (auto &kv : ctx->allocs) (void)hipFree(kv.first);
+    for (auto &kv : ctx->allocs) (void)hipFree((void *)kv.first);
     ctx->allocs.clear();
     for (hipEvent_t e : ctx->pool) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->marks) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->sync_events) (void)hipEventDestroy(e);
     (void)hipEventDestroy(ctx->ev_start);
     (void)hipEventDestroy(ctx->ev_stop);
@@ -205,7 +248,7 @@ int mbn_alloc(mbn_context *ctx, size_t bytes, void **dptr)
     if (e == hipErrorOutOfMemory) return MBN_ENOMEM;
     if (e != hipSuccess) return mbn_record_hip_error(ctx, e, "hipMalloc");
     std::lock_guard<std::mutex> lk(ctx->mu);
-    ctx->allocs[p] = bytes;
+    ctx->allocs[(uintptr_t)p] = bytes;
     *dptr = p;
     return MBN_OK;
 }
@@ -216,7 +259,7 @@ int mbn_free(mbn_context *ctx, void *dptr)
     if (!dptr) return MBN_OK;
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
-        auto it = ctx->allocs.find(dptr);
+        auto it = ctx->allocs.find((uintptr_t)dptr);
         if (it == ctx->allocs.end()) return MBN_EINVAL;   // not ours: caller-owned memory is never freed here
         ctx->allocs.erase(it);
     }
@@ -230,6 +273,7 @@ int mbn_upload(mbn_context *ctx, void *dst, const void *src, size_t bytes)
 {
     if (!ctx || !dst || !src) return MBN_EINVAL;
     if (bytes == 0) return MBN_OK;
+    MBN_SPANS(ctx, { dst, (double)bytes, "upload destination" });
     (void)hipSetDevice(ctx->device);
     MBN_HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
     MBN_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // blocking like CL_TRUE, MobileNet.c:350
@@ -240,6 +284,7 @@ int mbn_download(mbn_context *ctx, void *dst, const void *src, size_t bytes)
 {
     if (!ctx || !dst || !src) return MBN_EINVAL;
     if (bytes == 0) return MBN_OK;
+    MBN_SPANS(ctx, { src, (double)bytes, "download source" });
     (void)hipSetDevice(ctx->device);
     MBN_HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     MBN_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // blocking like CL_TRUE, MobileNet.c:395
@@ -250,6 +295,7 @@ int mbn_memset(mbn_context *ctx, void *dst, int byte, size_t bytes)
 {
     if (!ctx || !dst) return MBN_EINVAL;
     if (bytes == 0) return MBN_OK;
+    MBN_SPANS(ctx, { dst, (double)bytes, "memset destination" });
     (void)hipSetDevice(ctx->device);
     MBN_HIP_TRY(ctx, hipMemsetAsync(dst, byte, bytes, ctx->stream));
     return MBN_OK;
@@ -314,11 +360,43 @@ int mbn_profile_end(mbn_context *ctx, float *ms, int ms_capacity, int *count)
     return MBN_OK;
 }
 
+int mbn_mark(mbn_context *ctx, void *stream)
+{
+    if (!ctx) return MBN_EINVAL;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->marks_used == ctx->marks.size()) {
+        if (ctx->marks.size() >= (1u << 20)) return MBN_ENOMEM;
+        hipEvent_t e;
+        MBN_HIP_TRY(ctx, hipEventCreate(&e));
+        ctx->marks.push_back(e);
+    }
+    MBN_HIP_TRY(ctx, hipEventRecord(ctx->marks[ctx->marks_used], stream ? (hipStream_t)stream : ctx->stream));
+    ctx->marks_used++;
+    return MBN_OK;
+}
+
+int mbn_marks_read(mbn_context *ctx, float *ms_between, int capacity, int *count)
+{
+    if (!ctx || !count || capacity < 0 || (capacity > 0 && !ms_between)) return MBN_EINVAL;
+    (void)hipSetDevice(ctx->device);
+    const size_t used = ctx->marks_used;
+    ctx->marks_used = 0;
+    *count = 0;
+    if (used == 0) return MBN_OK;
+    MBN_HIP_TRY(ctx, hipEventSynchronize(ctx->marks[used - 1]));
+    int n = 0;
+    for (size_t i = 1; i < used && n < capacity; i++, n++)
+        MBN_HIP_TRY(ctx, hipEventElapsedTime(&ms_between[n], ctx->marks[i - 1], ctx->marks[i]));
+    *count = n;
+    return MBN_OK;
+}
+
 }   // extern "C"
 
 // --------------------------------------------------------------------------- call resolution
 
 namespace {
+
 
 struct Scope {   // hipEvent pair around one layer call when profiling is on (MobileNet.c:301-305 analogue)
     mbn_context *ctx;
@@ -410,15 +488,30 @@ int mbn_convolute(mbn_context *ctx, void *output, const void *inp_r, const void 
     if (!output || !inp_r || !filter_k) return MBN_EINVAL;
     if (rows <= 0 || cols <= 0 || op_size <= 0 || stride <= 0 || filtersize <= 0 || !(filtersize & 1))
         return MBN_EINVAL;
-    Scope sc(ctx, c.stream);
+    // every argument check comes before the profiling Scope: an MBN_EINVAL must not consume an event slot
     if (dtype == MBN_DT_U8) {
         if (!inp_g || !inp_b) return MBN_EINVAL;
         if (rows / stride <= 0 || cols / stride <= 0) return MBN_EINVAL;
+        const double plane = (double)rows * cols, oplane = (c.quirks & MBN_Q_LITERAL_INDEX) ? (double)(rows / 2) * (cols / 2)
+                                                                                               : (double)(rows / stride) * (cols / stride);
+        MBN_SPANS(ctx, { inp_r, plane * c.batch, "convolute inp_image_r" }, { inp_g, plane * c.batch, "convolute inp_image_g" },
+                  { inp_b, plane * c.batch, "convolute inp_image_b" }, { output, oplane * op_size * c.batch, "convolute output" },
+                  { filter_k, 4.0 * op_size * 3 * filtersize * filtersize, "convolute filter" });
+        Scope sc(ctx, c.stream);
         return sc.finish(mbn_launch_lit_convolute(c, (uint8_t *)output, (const uint8_t *)inp_r, (const uint8_t *)inp_g,
                                                   (const uint8_t *)inp_b, (const int32_t *)filter_k, rows, cols,
                                                   filtersize, stride, op_size));
     }
     if (c.cin <= 0) c.cin = 3;
+    {
+        const double orow = (rows + stride - 1) / stride, ocol = (cols + stride - 1) / stride;
+        const double in_es = (c.io_flags & MBN_IO_IN_U8) ? 1.0 : esz_in(c);
+        MBN_SPANS(ctx, { inp_r, in_es * c.batch * rows * cols * c.cin, "convolute image" },
+                  { output, esz_out(c) * c.batch * orow * ocol * op_size, "convolute output" },
+                  { filter_k, 4.0 * filtersize * filtersize * c.cin * op_size, "convolute filter" },
+                  { c.scale, 4.0 * op_size, "convolute scale" }, { c.shift, 4.0 * op_size, "convolute shift" });
+    }
+    Scope sc(ctx, c.stream);
     return sc.finish(mbn_launch_f32_conv(c, output, inp_r, (const float *)filter_k, rows, cols, filtersize, stride, op_size));
 }
 
@@ -434,6 +527,13 @@ int mbn_depthwise(mbn_context *ctx, void *output, const void *inp_image, const v
         return MBN_EINVAL;
     if (c.in_rows <= 0) c.in_rows = rows * stride;
     if (c.in_cols <= 0) c.in_cols = cols * stride;
+    {
+        const double es = dtype == MBN_DT_U8 ? 1.0 : esz_in(c), fes = 4.0 * filtersize * filtersize * op_size;
+        MBN_SPANS(ctx, { inp_image, es * c.batch * c.in_rows * c.in_cols * op_size, "depthwise input" },
+                  { output, (dtype == MBN_DT_U8 ? 1.0 : esz_out(c)) * c.batch * rows * cols * op_size, "depthwise output" },
+                  { filter_k, fes, "depthwise filter" }, { c.scale, 4.0 * op_size, "depthwise scale" },
+                  { c.shift, 4.0 * op_size, "depthwise shift" });
+    }
     Scope sc(ctx, c.stream);
     if (dtype == MBN_DT_U8)
         return sc.finish(mbn_launch_lit_depthwise(c, (uint8_t *)output, (const uint8_t *)inp_image,
@@ -451,6 +551,13 @@ int mbn_pointwise(mbn_context *ctx, void *output, const void *inp_image, const v
     if (rc != MBN_OK) return rc;
     if (!output || !inp_image || !filter_k) return MBN_EINVAL;
     if (rows <= 0 || cols <= 0 || op_size <= 0 || filtersize <= 0) return MBN_EINVAL;
+    {
+        const double px = (double)c.batch * rows * cols, lit = dtype == MBN_DT_U8;
+        MBN_SPANS(ctx, { inp_image, (lit ? 1.0 : esz_in(c)) * px * filtersize, "pointwise input" },
+                  { output, (lit ? 1.0 : esz_out(c)) * px * op_size, "pointwise output" },
+                  { filter_k, (dtype == MBN_DT_BF16 ? 2.0 : 4.0) * op_size * filtersize, "pointwise filter" },
+                  { c.scale, 4.0 * op_size, "pointwise scale" }, { c.shift, 4.0 * op_size, "pointwise shift" });
+    }
     Scope sc(ctx, c.stream);
     if (dtype == MBN_DT_U8)
         return sc.finish(mbn_launch_lit_pointwise(c, (uint8_t *)output, (const uint8_t *)inp_image,
@@ -468,9 +575,14 @@ int mbn_pool(mbn_context *ctx, void *output, const void *inp_image, int rows, in
     if (rc != MBN_OK) return rc;
     if (!output || !inp_image) return MBN_EINVAL;
     if (rows <= 0 || cols <= 0 || op_size <= 0 || filtersize <= 0) return MBN_EINVAL;
+    if (dtype == MBN_DT_U8 && (long)filtersize * filtersize > (long)rows * cols) return MBN_EINVAL;   // kernel.cl:126 would run past the plane
+    {
+        const double lit = dtype == MBN_DT_U8;
+        MBN_SPANS(ctx, { inp_image, (lit ? 1.0 : esz_in(c)) * c.batch * rows * cols * op_size, "pool input" },
+                  { output, (lit ? 1.0 : esz_out(c)) * c.batch * op_size, "pool output" });
+    }
     Scope sc(ctx, c.stream);
     if (dtype == MBN_DT_U8) {
-        if ((long)filtersize * filtersize > (long)rows * cols) return MBN_EINVAL;   // kernel.cl:126 would run past the plane
         return sc.finish(mbn_launch_lit_pool(c, (uint8_t *)output, (const uint8_t *)inp_image, rows, cols, filtersize,
                                              op_size));
     }
@@ -482,6 +594,8 @@ int mbn_softmax_f32(mbn_context *ctx, void *probs, void *argmax_i32, const void 
 {
     if (!ctx || !logits || batch <= 0 || classes <= 0 || (!probs && !argmax_i32)) return MBN_EINVAL;
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    MBN_SPANS(ctx, { logits, 4.0 * batch * classes, "softmax logits" }, { probs, 4.0 * batch * classes, "softmax probs" },
+              { argmax_i32, 4.0 * batch, "softmax argmax" });
     Scope sc(ctx, s);
     return sc.finish(mbn_launch_f32_softmax(ctx, s, (float *)probs, (int32_t *)argmax_i32, (const float *)logits, batch,
                                             classes));
@@ -492,6 +606,8 @@ int mbn_softmax_topk_f32(mbn_context *ctx, void *probs, void *topk_idx_i32, void
 {
     if (!ctx || !logits || !topk_idx_i32 || !topk_prob_f32 || batch <= 0 || classes <= 0 || k < 1 || k > 8) return MBN_EINVAL;
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    MBN_SPANS(ctx, { logits, 4.0 * batch * classes, "softmax_topk logits" }, { probs, 4.0 * batch * classes, "softmax_topk probs" },
+              { topk_idx_i32, 4.0 * batch * k, "softmax_topk idx" }, { topk_prob_f32, 4.0 * batch * k, "softmax_topk prob" });
     Scope sc(ctx, s);
     return sc.finish(mbn_launch_f32_softmax_topk(ctx, s, (float *)probs, (int32_t *)topk_idx_i32, (float *)topk_prob_f32,
                                                  (const float *)logits, batch, classes, k));
@@ -529,6 +645,8 @@ static int stem_fused_impl(mbn_context *ctx, void *out, const void *image, const
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     // decide before opening the profiling scope so an unsupported shape does not consume an event slot
     if (c1 != 32 || c3 != 64 || res < 32 || (res % 32) != 0 || batch <= 0) return MBN_EUNSUPPORTED;
+    MBN_SPANS(ctx, { image, (in_u8 ? 1.0 : 4.0) * batch * res * res * 3, "stem image" },
+              { out, (bf16 ? 2.0 : 4.0) * batch * (res / 2) * (res / 2) * c3, "stem output" });
     Scope sc(ctx, s);
     return sc.finish(mbn_launch_f32_stem(ctx, s, (float *)out, (const float *)image, (const float *)w1, (const float *)s1,
                                          (const float *)b1, (const float *)wd, (const float *)s2, (const float *)b2,
@@ -569,6 +687,9 @@ int mbn_dwpw_fused(mbn_context *ctx, void *out, const void *in, const void *wd, 
                                       (const float *)b2, (const float *)wp, (const float *)s3, (const float *)b3, batch,
                                       in_rows, in_cols, out_rows, out_cols, cin, cout, stride, pad_top, pad_left);
     if (rc != MBN_OK) return rc;
+    MBN_SPANS(ctx, { in, 4.0 * batch * in_rows * in_cols * cin, "dwpw input" },
+              { out, 4.0 * batch * out_rows * out_cols * cout, "dwpw output" }, { wd, 36.0 * cin, "dwpw depthwise filter" },
+              { wp, 4.0 * cin * cout, "dwpw pointwise filter" });
     Scope sc(ctx, s);
     return sc.finish(mbn_launch_f32_dwpw(ctx, s, (float *)out, (const float *)in, (const float *)wd, (const float *)s2,
                                          (const float *)b2, (const float *)wp, (const float *)s3, (const float *)b3, batch,
@@ -585,6 +706,9 @@ int mbn_dwpw_fused_bf16(mbn_context *ctx, void *out, const void *in, const void 
                                        (const float *)s3, (const float *)b3, batch, in_rows, in_cols, out_rows, out_cols, cin,
                                        cout, stride, pad_top, pad_left);
     if (rc != MBN_OK) return rc;
+    MBN_SPANS(ctx, { in, 2.0 * batch * in_rows * in_cols * cin, "dwpw input" },
+              { out, 2.0 * batch * out_rows * out_cols * cout, "dwpw output" }, { wd, 36.0 * cin, "dwpw depthwise filter" },
+              { wp_bf16, 2.0 * cin * cout, "dwpw pointwise filter" });
     Scope sc(ctx, s);
     return sc.finish(mbn_launch_bf16_dwpw(ctx, s, out, in, (const float *)wd, (const float *)s2, (const float *)b2, wp_bf16,
                                           (const float *)s3, (const float *)b3, batch, in_rows, in_cols, out_rows, out_cols,
@@ -596,6 +720,7 @@ int mbn_convert_f32_to_bf16(mbn_context *ctx, void *dst_bf16, const void *src_f3
     if (!ctx || !dst_bf16 || !src_f32) return MBN_EINVAL;
     if (count == 0) return MBN_OK;
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    MBN_SPANS(ctx, { src_f32, 4.0 * count, "convert source" }, { dst_bf16, 2.0 * count, "convert destination" });
     Scope sc(ctx, s);
     return sc.finish(mbn_launch_convert(ctx, s, dst_bf16, src_f32, count, 1));
 }
@@ -605,6 +730,7 @@ int mbn_convert_bf16_to_f32(mbn_context *ctx, void *dst_f32, const void *src_bf1
     if (!ctx || !dst_f32 || !src_bf16) return MBN_EINVAL;
     if (count == 0) return MBN_OK;
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    MBN_SPANS(ctx, { src_bf16, 2.0 * count, "convert source" }, { dst_f32, 4.0 * count, "convert destination" });
     Scope sc(ctx, s);
     return sc.finish(mbn_launch_convert(ctx, s, dst_f32, src_bf16, count, 0));
 }
@@ -615,6 +741,7 @@ int mbn_normalize_u8_to_f32(mbn_context *ctx, void *out_f32, const void *in_u8, 
     if (!ctx || !out_f32 || !in_u8) return MBN_EINVAL;
     if (count == 0) return MBN_OK;
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    MBN_SPANS(ctx, { in_u8, 1.0 * count, "normalize input" }, { out_f32, 4.0 * count, "normalize output" });
     Scope sc(ctx, s);
     return sc.finish(mbn_launch_normalize(ctx, s, (float *)out_f32, (const uint8_t *)in_u8, count, scale, bias));
 }

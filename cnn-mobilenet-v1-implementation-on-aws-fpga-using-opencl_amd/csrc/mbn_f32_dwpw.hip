@@ -253,7 +253,8 @@ void launch(DwPwArgs &a, hipStream_t s, int num_cus)
     a.mt = (int)((a.m + BM - 1) / BM);
     a.nt = a.cout / BN;
     const long nwg = (long)a.mt * a.nt;
-    long grid = (long)num_cus * (g_mbn_tune.misc > 0 ? g_mbn_tune.misc : 1);
+    const int per_cu = g_mbn_tune.misc;
+    long grid = (long)num_cus * (per_cu > 0 ? per_cu : 1);
     if (grid > nwg) grid = nwg;
     hipLaunchKernelGGL((dwpw_f32<S, BN>), dim3((unsigned)grid), dim3(NT), 0, s, a);
 }

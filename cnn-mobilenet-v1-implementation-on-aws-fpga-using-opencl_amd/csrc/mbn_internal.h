@@ -6,8 +6,9 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
+#include <map>
 #include <mutex>
-#include <unordered_map>
 #include <vector>
 
 #include "mbn.h"
@@ -27,8 +28,11 @@ struct mbn_context {
     std::vector<hipEvent_t> pool;                // mbn_profile_begin/end: 2 events per recorded call
     int pool_cap = 0, pool_used = 0;
     bool pool_on = false;
+    std::vector<hipEvent_t> marks;               // mbn_mark / mbn_marks_read: step markers (reused across reads)
+    size_t marks_used = 0;
     std::mutex mu;
-    std::unordered_map<void *, size_t> allocs;   // buffers handed out by mbn_alloc
+    std::map<uintptr_t, size_t> allocs;          // buffers handed out by mbn_alloc: base address -> bytes (ordered: mbn_span_check
+                                                 // finds the allocation that CONTAINS an interior pointer)
 };
 
 static inline int mbn_record_hip_error(mbn_context *ctx, hipError_t e, const char *what)
@@ -44,14 +48,16 @@ static inline int mbn_record_hip_error(mbn_context *ctx, hipError_t e, const cha
     } while (0)
 
 // Process-wide tuning knobs (mbn_tune_set). 0 = shipped default everywhere.
+// Relaxed atomics: the knobs are read on every launch by whichever host thread drives a context (one thread per GPU is
+// the documented model, mbn.h) while another thread may call mbn_tune_set — no torn or racy reads, no ordering implied.
 struct mbn_tunables {
-    int dw_variant = 0;   // depthwise kernel variant
-    int dw_nseg = 0;      // force row segments per image (0 = heuristic)
-    int pw_tile = 0;      // pointwise tile config override
-    int pw_stage = 0;     // 1 = register staging instead of direct-to-LDS loads
-    int conv_variant = 0; // conv1 kernel variant
-    int misc = 0;
-    int net_stagger = 2;  // layers by which consecutive sub-batch streams are staggered (mbn_net_set_streams)
+    std::atomic<int> dw_variant{0};   // depthwise kernel variant
+    std::atomic<int> dw_nseg{0};      // force row segments per image (0 = heuristic)
+    std::atomic<int> pw_tile{0};      // pointwise tile config override
+    std::atomic<int> pw_stage{0};     // 1 = register staging instead of direct-to-LDS loads
+    std::atomic<int> conv_variant{0}; // conv1 kernel variant
+    std::atomic<int> misc{0};
+    std::atomic<int> net_stagger{2};  // layers by which consecutive sub-batch streams are staggered (mbn_net_set_streams)
 };
 extern mbn_tunables g_mbn_tune;
 

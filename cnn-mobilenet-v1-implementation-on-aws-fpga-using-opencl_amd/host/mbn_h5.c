@@ -54,7 +54,7 @@ static uint64_t rd_le(const uint8_t *p, int n)
 
 static const uint8_t *at(const mbn_h5 *h, uint64_t addr, uint64_t len)
 {
-    if (addr == H5_UNDEF) return NULL;
+    if (addr == H5_UNDEF || addr > UINT64_MAX - h->base) return NULL;    /* the sum below must not wrap */
     uint64_t a = addr + h->base;
     if (a > h->size || len > h->size - a) return NULL;
     return h->map + a;
@@ -136,6 +136,9 @@ static int iter_messages(const mbn_h5 *h, uint64_t ohdr, msg_cb cb, void *user)
         if (!q) return MBN_EFORMAT;
         uint64_t chunk0 = rd_le(q + pos, csz);
         pos += csz;
+        /* an 8-byte size field comes straight from the file: chunk0 + 4 wraps for chunk0 >= 2^64 - 4 and would pass at()
+         * with a tiny length while iter_v2_block walks chunk0 bytes */
+        if (chunk0 > h->size) return MBN_EFORMAT;
         const uint8_t *blk = at(h, ohdr + pos, chunk0 + 4);
         if (!blk) return MBN_EFORMAT;
         int rc = iter_v2_block(h, blk, chunk0, (flags & 0x04) != 0, cb, user, 0);
@@ -463,7 +466,13 @@ static int dataset_view(const mbn_h5 *h, uint64_t ohdr, int *ndim, int64_t shape
     }
     const uint8_t *p = NULL;
     if (o.layout_class == 1) {
-        if (o.data_addr == H5_UNDEF) return count == 0 ? MBN_OK : MBN_EFORMAT;   /* never written */
+        if (o.data_addr == H5_UNDEF) {                                   /* never written: legal only for an empty dataset */
+            if (count != 0) return MBN_EFORMAT;
+            if (ndim) *ndim = o.ndim;
+            if (shape) for (int i = 0; i < o.ndim; i++) shape[i] = o.shape[i];
+            if (data) *data = NULL;
+            return MBN_OK;
+        }
         p = at(h, o.data_addr, count * 4);
         if (!p) return MBN_EFORMAT;
     } else if (o.layout_class == 0) {

@@ -146,21 +146,25 @@ int mbn_split_rgb(const unsigned char *hwc, int pixels, unsigned char *r, unsign
     return MBN_OK;
 }
 
-/* MobileNet.c:2771-2792. */
+/* MobileNet.c:2771-2792: exp() in double over the uint8 logits, normalise, arg-max (first maximum wins, 1-based).
+ * A logit is one of 256 values, so exp is taken once per distinct value instead of twice per class as the reference
+ * does; the sum still runs over the classes in index order, which keeps the reference's rounding. */
 int mbn_softmax_argmax_u8(const unsigned char *logits, int n, double *probs, int *location, double *maximum)
 {
     if (!logits || !probs || n <= 0) return MBN_EINVAL;
+    double e[256];
+    unsigned char seen[256] = { 0 };
     double sum = 0.0;
+    int best = 0;
     for (int k = 0; k < n; k++) {
-        probs[k] = exp((double)logits[k]);
-        sum += exp((double)logits[k]);
+        const unsigned v = logits[k];
+        if (!seen[v]) { e[v] = exp((double)v); seen[v] = 1; }
+        sum += e[v];
+        if (v > logits[best]) best = k;                  /* exp is monotone: the arg-max of the logits is the arg-max of the probabilities */
     }
-    for (int k = 0; k < n; k++) probs[k] = probs[k] / sum;
-    double mx = probs[0];
-    int loc = 1;
-    for (int k = 1; k < n; k++)
-        if (probs[k] > mx) { mx = probs[k]; loc = k + 1; }
-    if (location) *location = loc;
-    if (maximum) *maximum = mx;
+    const double inv_free_sum = sum;                     /* divide (not multiply by a reciprocal): same quotient as the reference */
+    for (int k = 0; k < n; k++) probs[k] = e[logits[k]] / inv_free_sum;
+    if (location) *location = best + 1;
+    if (maximum) *maximum = probs[best];
     return MBN_OK;
 }

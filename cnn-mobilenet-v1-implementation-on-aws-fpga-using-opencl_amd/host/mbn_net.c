@@ -9,6 +9,7 @@
  *
  * Plain C: this file uses nothing but the functions declared in mbn.h.
  */
+#include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -32,6 +33,9 @@ struct mbn_net {
     void *g_logits;
     int g_batch, g_last, g_dtype, g_keep;
     int free_running;          /* no fork dependency on the context's stream (mbn_net_set_free_running) */
+    const void *fr_images;     /* free-running: the (images, logits, batch, last_layer) of the previous forward; a call that */
+    void *fr_logits;           /* differs re-inserts the fork wait, because sub-batch slices of act[] move with the batch */
+    int fr_batch, fr_last;
     int nstreams;              /* sub-batch pipelining (mbn_net_set_streams); 1 = everything on the context's stream */
     void *streams[8];
     void *bf16_filt[MBN_MAX_LAYERS];   /* bf16 copies of the pointwise / FC filters (bf16 mode) */
@@ -162,6 +166,9 @@ int mbn_net_set_streams(mbn_net *net, int n)
 static int stem_fusable(const mbn_net *net, int last_layer)
 {
     const mbn_layer_desc *l = net->plan.layer;
+    /* the fused kernels load with 16-byte accesses: a caller-provided device blob must be aligned (the plan's segments are
+     * 256-byte aligned inside it); mbn_net_launches and the forward both decide here, so they cannot disagree */
+    if (((uintptr_t)net->dev_blob % 16) != 0) return 0;
     return net->fuse_stem && !net->keep && last_layer >= 3 && net->plan.n_layers >= 3 &&
            (net->dtype == MBN_DT_F32 || (net->dtype == MBN_DT_BF16 && net->bf16_filt[2])) &&
            l[0].kind == MBN_L_CONV && l[1].kind == MBN_L_DW && l[2].kind == MBN_L_PW && l[0].in_ch == 3 &&
@@ -196,6 +203,7 @@ static int block_fusable(const mbn_net *net, int i, int count, int last_layer)
     if ((net->dtype != MBN_DT_F32 && !bf) || net->keep || i + 2 > last_layer || i + 1 >= net->plan.n_layers || i + 1 >= 32) return 0;
     if (bf && (!net->bf16_filt[i + 1] || (net->plan.layer[i].in_ch % 64) != 0)) return 0;
     if (!((net->fuse_blocks >> (i + 1)) & 1u)) return 0;
+    if (((uintptr_t)net->dev_blob % 16) != 0) return 0;            /* see stem_fusable */
     const mbn_layer_desc *d = &net->plan.layer[i], *p = &net->plan.layer[i + 1];
     if (d->kind != MBN_L_DW || p->kind != MBN_L_PW || (d->stride != 1 && d->stride != 2)) return 0;
     if (d->in_ch < 32 || (d->in_ch % 32) != 0 || d->in_ch > 1024 || p->out_ch < 128 || (p->out_ch % 128) != 0) return 0;
@@ -470,9 +478,20 @@ static int forward_impl(mbn_net *net, const void *images, void *logits, int batc
      * stream's depthwise (HBM-bound) meets another's pointwise (MFMA-bound); join: the context's stream waits for all. */
     const int q = batch / ns, r = batch % ns;
     int first = 0;
+    /* free-running skips the fork only between IDENTICAL consecutive calls: with another batch the sub-batch slices of the
+     * ping-pong buffers move, with other images/logits the caller may have queued their producer/consumer on the context's
+     * stream — both need the ordering back */
+    const int fork = !net->free_running || net->fr_images != images || net->fr_logits != logits || net->fr_batch != batch ||
+                     net->fr_last != last_layer;
+    net->fr_images = images; net->fr_logits = logits; net->fr_batch = batch; net->fr_last = last_layer;
+    if (fork && net->free_running)
+        for (int j = 0; j < ns; j++) {                       /* the previous free-running forward's tails, on every sub-stream */
+            int rc = mbn_stream_wait(net->ctx, NULL, net->streams[j]);
+            if (rc != MBN_OK) return rc;
+        }
     for (int j = 0; j < ns; j++) {
         const int count = q + (j < r ? 1 : 0);
-        int rc = net->free_running ? MBN_OK : mbn_stream_wait(net->ctx, net->streams[j], NULL);
+        int rc = fork ? mbn_stream_wait(net->ctx, net->streams[j], NULL) : MBN_OK;
         if (rc == MBN_OK)
             rc = forward_range(net, images, logits, first, count, last_layer, net->streams[j], NULL, 0,
                                j + 1 < ns ? net->streams[j + 1] : NULL, stagger);

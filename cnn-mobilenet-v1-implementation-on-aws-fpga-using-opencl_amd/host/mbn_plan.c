@@ -36,6 +36,10 @@ int mbn_plan_build(float alpha, int res, int classes, mbn_plan *plan)
 
     if (!plan) return MBN_EINVAL;
     if (!(alpha > 0.f) || alpha > 4.f || res < 32 || res > 4096 || classes <= 0) return MBN_EINVAL;
+    /* Odd feature maps are where TF-"SAME" (out = ceil(h/2), pad_top = total/2: what this table computes) and Keras
+     * MobileNet (ZeroPadding2D(((0,1),(0,1))) + 'valid': pad_top = 0, out = floor((h-2)/2)+1) disagree — 25 -> 13 vs 12.
+     * With res a multiple of 32 every stride-2 layer sees an even map and the two coincide, so that is the supported set. */
+    if (res % 32) return MBN_EUNSUPPORTED;
     memset(plan, 0, sizeof(*plan));
     plan->alpha = alpha;
     plan->res = res;

@@ -15,6 +15,7 @@
  * line (MobileNet.c:2792).
  */
 #include <stdio.h>
+#include <unistd.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -177,7 +178,9 @@ int main(int argc, char **argv)
     char tmp[] = "/tmp/mbn_synth_XXXXXX.h5";
     if (!h5) {
         if (!have_seed) { fprintf(stderr, "need --h5, --synthetic or --literal\n"); return 2; }
-        snprintf(tmp, sizeof(tmp), "/tmp/mbn_synth_%llu.h5", seed % 1000000ULL);
+        int tfd = mkstemps(tmp, 3);                 /* O_EXCL-created, unpredictable name: no symlink following, no clash between runs */
+        if (tfd < 0) { fprintf(stderr, "cannot create a temporary file in /tmp\n"); return 2; }
+        close(tfd);
         CHECK(mbn_weights_synthetic_h5(tmp, alpha > 0.f ? alpha : 1.0f, 1000, seed));
         h5 = tmp;
     }

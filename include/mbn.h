@@ -152,6 +152,12 @@ int  mbn_graph_launch(mbn_context *ctx, void *graph_exec, void *stream);
 int  mbn_graph_destroy(mbn_context *ctx, void *graph_exec);
 
 /* ---------------------------------------------------- buffers (clCreateBuffer &c.) */
+/* Every buffer handed out by mbn_alloc is remembered with its size. When a pointer passed to a layer call, a fused call,
+ * the classifier calls or mbn_upload/download/memset lies inside one of them (interior pointers included), the bytes the
+ * call will touch — computed from its shape arguments, ext->batch and dtype — must fit in the rest of that buffer;
+ * otherwise the call returns MBN_EINVAL and launches nothing (mbn_last_device_error names the operand). A uint8 image
+ * handed to the fp32 first layer, a logits buffer sized for a smaller batch, a filter shorter than op_size x filtersize
+ * are caller errors here, not GPU memory faults. Memory the caller allocated itself is not tracked and not checked. */
 int  mbn_alloc(mbn_context *ctx, size_t bytes, void **dptr);                 /* MobileNet.c:340-342 */
 int  mbn_free(mbn_context *ctx, void *dptr);
 int  mbn_upload(mbn_context *ctx, void *dst_dev, const void *src_host, size_t bytes);   /* blocking, :350 */
@@ -169,6 +175,12 @@ int  mbn_set_profiling(mbn_context *ctx, int enabled);   /* default 0: no events
 int  mbn_profile_begin(mbn_context *ctx, int capacity);
 int  mbn_profile_end(mbn_context *ctx, float *ms, int ms_capacity, int *count);
 int  mbn_profile_pause(mbn_context *ctx, int paused);   /* 1: stop recording (slots keep their order), 0: resume */
+/* Step markers: mbn_mark queues one timing event on `stream` (NULL = the context's stream) without synchronising;
+ * mbn_marks_read waits for the last one and returns the milliseconds between consecutive marks, in order
+ * (count = marks - 1), then forgets them. bench.py brackets every timed step with one mark to report the median and
+ * the p10/p90 of the per-step time next to the wall-clock figure. */
+int  mbn_mark(mbn_context *ctx, void *stream);
+int  mbn_marks_read(mbn_context *ctx, float *ms_between, int capacity, int *count);
 
 /* --------------------------------------------------------------- layer calls
  * Positional parameters are kernel.cl's, in kernel.cl's order and meaning:

@@ -112,6 +112,9 @@ def test_plan_rejects_bad_arguments(pkg):
     for a, r, c in ((0.0, 224, 1000), (-1.0, 224, 1000), (1.0, 8, 1000), (1.0, 224, 0), (0.01, 224, 10)):
         assert lib.mbn_plan_build(a, r, c, C.byref(p)) == pkg.EINVAL
     assert lib.mbn_plan_build(1.0, 224, 1000, None) == pkg.EINVAL
+    # odd feature maps are where TF-SAME and Keras' ZeroPadding2D + 'valid' disagree: only res % 32 == 0 is offered
+    for r in (100, 150, 225, 33):
+        assert lib.mbn_plan_build(1.0, r, 1000, C.byref(p)) == pkg.EUNSUPPORTED
 
 
 # ----------------------------------------------------------------------------- loaders kept from the reference
@@ -182,8 +185,16 @@ def test_host_softmax_argmax_u8(pkg, orc):
     probs = np.zeros(1000)
     loc, mx = C.c_int(), C.c_double()
     assert lib.mbn_softmax_argmax_u8(logits.ctypes.data, 1000, probs.ctypes.data, C.byref(loc), C.byref(mx)) == 0
+    # three independent formulations: numpy (float64 exp / sum), the oracle's restatement of MobileNet.c:2771-2792, and the
+    # host's per-distinct-value form; same quotients up to the summation order numpy chooses
+    e = np.exp(logits.astype(np.float64))
+    want = e / e.sum()
+    assert np.allclose(probs, want, rtol=1e-12, atol=0) and loc.value == int(np.argmax(want)) + 1 == 418
     op, oloc, omx = orc.softmax_argmax_u8(logits)
-    assert loc.value == oloc == 418 and mx.value == omx and np.array_equal(probs, op)   # 1-based like MobileNet.c:2788
+    assert loc.value == oloc and mx.value == omx and np.array_equal(probs, op)   # 1-based like MobileNet.c:2788
+    ties = np.zeros(10, np.uint8); ties[[3, 7]] = 5                               # first maximum wins (strict > at :2786)
+    tp, tl = np.zeros(10), C.c_int()
+    assert lib.mbn_softmax_argmax_u8(ties.ctypes.data, 10, tp.ctypes.data, C.byref(tl), C.byref(mx)) == 0 and tl.value == 4
     assert abs(probs.sum() - 1) < 1e-12
     logits[:] = 0
     logits[0] = 9
@@ -290,6 +301,66 @@ def test_h5_fuzz_never_crashes(pkg, tmp_path):
             fn = CB(lambda *a: 0)
             lib.mbn_h5_visit(h, C.cast(fn, C.c_void_p), None)
             lib.mbn_h5_close(h)
+
+
+def _crafted_v2_file(chunk_size_field, body=b""):
+    """4 KB file: superblock v2 (8-byte offsets/lengths) whose root object header is a v2 OHDR with an 8-byte
+    chunk-size field (flags & 3 == 3) holding `chunk_size_field`."""
+    f = bytearray(4096)
+    f[0:8] = b"\x89HDF\r\n\x1a\n"
+    f[8], f[9], f[10], f[11] = 2, 8, 8, 0
+    f[12:20] = (0).to_bytes(8, "little")                   # base address
+    f[20:28] = (2 ** 64 - 1).to_bytes(8, "little")         # superblock extension: undefined
+    f[28:36] = (4096).to_bytes(8, "little")                # EOF
+    f[36:44] = (512).to_bytes(8, "little")                 # root group object header
+    f[512:516] = b"OHDR"
+    f[516], f[517] = 2, 0x03                               # version 2, flags: 8-byte chunk-0 size
+    f[518:526] = int(chunk_size_field).to_bytes(8, "little")
+    f[526:526 + len(body)] = body
+    return bytes(f)
+
+
+@pytest.mark.parametrize("chunk0", [2 ** 64 - 4, 2 ** 64 - 1, 2 ** 63, 4096, 3571])
+def test_h5_crafted_chunk0_size_is_rejected(pkg, tmp_path, chunk0):
+    """an 8-byte chunk-0 size taken straight from the file made `chunk0 + 4` wrap, so the bounds
+    check passed with a tiny length and the message walk ran past the mapping. Every oversize value must come back
+    as an error code from both entry points (run under ASan by tools/run_asan_cpu.sh)."""
+    lib = pkg.host_lib()
+    t = tmp_path / "crafted.h5"
+    t.write_bytes(_crafted_v2_file(chunk0))
+    assert h5_get(lib, str(t), "/x")[0] == pkg.EFORMAT
+    w = pkg.Weights()
+    assert lib.mbn_weights_from_h5(str(t).encode(), C.c_float(0.0), 224, C.byref(w)) != 0
+    # a chunk that does fit (all NIL messages) is a valid empty group: the name is simply not there
+    t.write_bytes(_crafted_v2_file(64))
+    assert h5_get(lib, str(t), "/x")[0] == pkg.ENOTFOUND
+
+
+def test_h5_never_written_empty_dataset_has_defined_shape(pkg, tmp_path):
+    """a contiguous dataset that was never written (address undefined) with zero elements returned MBN_OK
+    without setting ndim/shape/data. Crafted v2 header: dataspace (2, 0), float32 datatype, contiguous layout at
+    H5_UNDEF."""
+    lib = pkg.host_lib()
+    space = bytes([1, 2, 0, 0]) + (2).to_bytes(4, "little")[:0] + bytes(4) + (2).to_bytes(8, "little") + (0).to_bytes(8, "little")
+    # v1 dataspace message: version 1, rank 2, flags 0, reserved 5 bytes, then the dims
+    space = bytes([1, 2, 0, 0, 0, 0, 0, 0]) + (2).to_bytes(8, "little") + (0).to_bytes(8, "little")
+    dtype = bytes([0x11, 0x20, 0x1F, 0x00]) + (4).to_bytes(4, "little") + bytes([0, 0, 32, 0, 23, 8, 0, 23]) + (127).to_bytes(4, "little")
+    layout = bytes([3, 1]) + (2 ** 64 - 1).to_bytes(8, "little") + (0).to_bytes(8, "little")
+
+    def msg(t, body):
+        return bytes([t]) + len(body).to_bytes(2, "little") + bytes([0]) + body
+    body = msg(0x01, space) + msg(0x03, dtype) + msg(0x08, layout)
+    t = tmp_path / "empty.h5"
+    t.write_bytes(_crafted_v2_file(len(body), body))
+    h = C.c_void_p()
+    assert lib.mbn_h5_open(str(t).encode(), C.byref(h)) == 0
+    ndim, shape, data = C.c_int(-7), (C.c_int64 * 8)(*([-7] * 8)), C.POINTER(C.c_float)()
+    rc = lib.mbn_h5_get(h, b"/", C.byref(ndim), shape, C.byref(data))
+    lib.mbn_h5_close(h)
+    if rc == 0:                     # accepted as an empty dataset: everything must be defined
+        assert ndim.value == 2 and list(shape)[:2] == [2, 0] and not data
+    else:                           # or refused — but never MBN_OK with garbage outputs
+        assert rc in (pkg.EFORMAT, pkg.EUNSUPPORTED, pkg.ENOTFOUND)
 
 
 def _write(lib, path, items):
