@@ -16,12 +16,19 @@ Prints ONE JSON line on rank 0. Extra objects:
                 MFMA peak 157.3 TFLOP/s (MI355X_MICROARCH.md). `stages` carries the same for every stage group,
                 depthwise against the 8 TB/s HBM peak.
   cpu_baseline  the oracle's C restatement (kind "port": the reference has no CPU path and cannot be built here)
-                timed on this box's host cores on a bounded sample of the same workload.
+                timed on this box's host cores on a bounded sample of the same workload: the FIRST n images of the timed
+                batch. `variants` = SURVEY.md §8d's table (1 thread and all cores, batch 1 and 8, median of 5).
+  parity_check  the oracle's logits for those n images against the logits the timed steps left on the device; the run
+                exits non-zero above the tolerance (fp32 1e-3, bf16 6e-2 of max|ref|: tests/test_parity_gpu.py).
+  step_ms       median / p10 / p90 of the per-step time from one HIP event between steps (no sync inside the region).
+  unfused_stages  per-stage numbers of all 13 depthwise + 13 pointwise layers from a few UNTIMED forwards with one launch
+                per layer (the default runner folds layers 1-11 into fused launches).
 """
 import argparse
 import json
 import os
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -59,18 +66,61 @@ def layer_weight_bytes(l, pkg, act_bytes=4.0):
     return 0.0
 
 
-def load_traffic(layers=None):
+def load_traffic(layers=None, key="f32"):
     """HBM bytes per launch of the dominant kernel from the PMC counters (FETCH_SIZE x2 on gfx950 + WRITE_SIZE), measured
     in separate rocprofv3 --pmc passes of this same workload (tools/pmc_pass.sh) and committed under profiles/.
     bench.py cannot run the profiler on itself, so it reports the committed measurement — averaged over the pointwise
-    layers that are separate launches in this run — or null when there is none."""
+    layers that are separate launches in this run — or null when there is none. Returns (bytes, source) where source
+    names the git sha and command the committed figure was measured at."""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        if key != "f32":
+            t = t[key]
+        src = {k: t.get(k) for k in ("git_sha", "command", "date") if t.get(k)} or None
         if layers:
-            return sum(t["pointwise_layers"][str(l)]["bytes"] for l in layers) / len(layers)
-        return t["pointwise_avg_bytes_per_launch"]
+            return sum(t["pointwise_layers"][str(l)]["bytes"] for l in layers) / len(layers), src
+        return t["pointwise_avg_bytes_per_launch"], src
     except Exception:
-        return None
+        return None, None
+
+
+def stage_table(plan, pkg, launches, layer_ms, batch, act_bytes, mfma_peak):
+    """Per-launch and per-stage-group achieved GB/s / TFLOP/s from the launch list and its measured milliseconds."""
+    def launch_work(idx):
+        """Algorithmic work of one launch: FLOPs of every layer in it; bytes = first layer's input + last layer's
+        output + every layer's weights (a fused launch's intermediates never reach HBM)."""
+        fl = sum(layer_work(plan.layer[i], batch, pkg, act_bytes)[0] for i in idx)
+        first, last = plan.layer[idx[0]], plan.layer[idx[-1]]
+        by = sum(layer_weight_bytes(plan.layer[i], pkg, act_bytes) for i in idx)
+        by += (4.0 if first.kind == pkg.L_CONV else act_bytes) * first.in_rows * first.in_cols * first.in_ch * batch
+        by += (4.0 if last.kind == pkg.L_FC else act_bytes) * last.out_rows * last.out_cols * last.out_ch * batch
+        return fl, by
+    kind_name = {pkg.L_CONV: "conv1", pkg.L_DW: "depthwise", pkg.L_PW: "pointwise", pkg.L_POOL: "pool", pkg.L_FC: "fc"}
+    stage_of = ["stem_fused" if len(idx) == 3 else "block_fused" if len(idx) == 2 else kind_name[plan.layer[idx[0]].kind]
+                for idx in launches]
+    stages, per_layer = {}, []
+    for j, idx in enumerate(launches):
+        f, b = launch_work(idx)
+        per_layer.append({"layers": [i + 1 for i in idx], "stage": stage_of[j], "ms": round(float(layer_ms[j]), 5),
+                          "GBps": round(b / layer_ms[j] / 1e6, 1), "TFLOPs": round(f / layer_ms[j] / 1e9, 2)})
+    for name in ["stem_fused", "block_fused", "conv1", "depthwise", "pointwise", "pool", "fc"]:
+        js = [j for j in range(len(launches)) if stage_of[j] == name]
+        if not js:
+            continue
+        fl = sum(launch_work(launches[j])[0] for j in js)
+        by = sum(launch_work(launches[j])[1] for j in js)
+        ms_sum = float(sum(layer_ms[j] for j in js))
+        st = {"launches": len(js), "ms": round(ms_sum, 4), "GBps": round(by / ms_sum / 1e6, 1),
+              "TFLOPs": round(fl / ms_sum / 1e9, 2)}
+        st["frac_hbm"] = round(st["GBps"] / HBM_PEAK_GBS, 4)
+        st["frac_mfma"] = round(st["TFLOPs"] / mfma_peak, 4)
+        stages[name] = st
+    if "stem_fused" in stages:
+        stages["stem_fused"]["layers"] = "1-3 (conv1 + depthwise + pointwise in one kernel)"
+    if "block_fused" in stages:
+        stages["block_fused"]["layers"] = ", ".join("%d-%d" % (idx[0] + 1, idx[1] + 1) for idx in launches if len(idx) == 2) \
+                                          + " (depthwise + pointwise in one kernel each)"
+    return stages, per_layer, stage_of
 
 
 def main():
@@ -94,6 +144,8 @@ def main():
                     help="mask for mbn_net_set_fuse_blocks (bit L = fuse depthwise layer L with pointwise L+1); default: library's")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=0, help="images in the CPU baseline sample (0 = auto)")
+    ap.add_argument("--no-cpu-variants", action="store_true", help="skip the 1-thread / batch-1 / batch-8 CPU table")
+    ap.add_argument("--no-unfused-stages", action="store_true", help="skip the untimed one-launch-per-layer pass")
     ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the CPU baseline (cap; box share is 16)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--profile-every", type=int, default=5,
@@ -130,7 +182,8 @@ def main():
     plan = pkg.plan_build(args.alpha, args.res, 1000, lib=lib)
     blob_t = torch.empty(plan.blob_floats, dtype=torch.float32, device=dev)
     if rank == 0:
-        path = "/tmp/mbn_bench_%d.h5" % os.getpid()
+        fd, path = tempfile.mkstemp(prefix="mbn_bench_", suffix=".h5")      # O_EXCL, unpredictable name
+        os.close(fd)
         pkg.synthetic_h5(path, alpha=args.alpha, classes=1000, seed=0xC0FFEE, lib=lib)
         hw = pkg.HostWeights(path, alpha=args.alpha, res=args.res, lib=lib)
         os.remove(path)
@@ -168,6 +221,7 @@ def main():
     h0 = time.perf_counter()
     d_in.upload(imgs)                      # blocking H2D of one batch from pageable host memory (PCIe), not timed as a step
     h2d_ms = 1000.0 * (time.perf_counter() - h0)
+    head = imgs[:64].copy()                # the CPU baseline / parity check runs the oracle on the first images of THIS batch
     del imgs
     d_out = ctx.alloc(args.batch * 1000 * 4)
 
@@ -193,6 +247,7 @@ def main():
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    ctx.mark()                                  # one HIP event between steps: per-step durations without a sync in the region
     for step in range(args.steps):
         if profile and step in sampled:
             ctx.profile_pause(False)
@@ -200,6 +255,7 @@ def main():
             ctx.profile_pause(True)
         else:
             net.forward(d_in.ptr, d_out.ptr, args.batch)
+        ctx.mark()
     torch.cuda.synchronize()
     barrier()
     t1 = time.perf_counter()
@@ -212,6 +268,7 @@ def main():
         arr = np.asarray(ms, dtype=np.float64).reshape(len(sampled), nsub, n_launch)
         layer_ms = arr.mean(axis=0).sum(axis=0)
 
+    step_ms = np.asarray(ctx.marks_read(args.steps + 1), dtype=np.float64)
     elapsed = mdist.max_over_ranks(elapsed, "cpu" if args.dist_backend == "gloo" else dev)
 
     logits = d_out.download((args.batch, 1000), np.float32)
@@ -242,52 +299,20 @@ def main():
                        "streams": args.streams, "device": ctx.name()},
         }
         if layer_ms is not None:
-            def launch_work(idx):
-                """Algorithmic work of one launch: FLOPs of every layer in it; bytes = first layer's input + last layer's
-                output + every layer's weights (the fused stem's intermediates never reach HBM)."""
-                fl = sum(layer_work(plan.layer[i], args.batch, pkg, act_bytes)[0] for i in idx)
-                first, last = plan.layer[idx[0]], plan.layer[idx[-1]]
-                by = sum(layer_weight_bytes(plan.layer[i], pkg, act_bytes) for i in idx)
-                by += (4.0 if first.kind == pkg.L_CONV else act_bytes) * first.in_rows * first.in_cols * first.in_ch * args.batch
-                by += (4.0 if last.kind == pkg.L_FC else act_bytes) * last.out_rows * last.out_cols * last.out_ch * args.batch
-                return fl, by
-            kind_name = {pkg.L_CONV: "conv1", pkg.L_DW: "depthwise", pkg.L_PW: "pointwise", pkg.L_POOL: "pool", pkg.L_FC: "fc"}
-            stage_of = ["stem_fused" if len(idx) == 3 else "block_fused" if len(idx) == 2 else kind_name[plan.layer[idx[0]].kind]
-                        for idx in launches]
-            stages, per_layer = {}, []
-            for j, idx in enumerate(launches):
-                f, b = launch_work(idx)
-                per_layer.append({"layers": [i + 1 for i in idx], "stage": stage_of[j], "ms": round(float(layer_ms[j]), 5),
-                                  "GBps": round(b / layer_ms[j] / 1e6, 1), "TFLOPs": round(f / layer_ms[j] / 1e9, 2)})
-            for name in ["stem_fused", "block_fused", "conv1", "depthwise", "pointwise", "pool", "fc"]:
-                js = [j for j in range(n_launch) if stage_of[j] == name]
-                if not js:
-                    continue
-                fl = sum(launch_work(launches[j])[0] for j in js)
-                by = sum(launch_work(launches[j])[1] for j in js)
-                ms_sum = float(sum(layer_ms[j] for j in js))
-                st = {"launches": len(js), "ms": round(ms_sum, 4), "GBps": round(by / ms_sum / 1e6, 1),
-                      "TFLOPs": round(fl / ms_sum / 1e9, 2)}
-                st["frac_hbm"] = round(st["GBps"] / HBM_PEAK_GBS, 4)
-                st["frac_mfma"] = round(st["TFLOPs"] / mfma_peak, 4)
-                stages[name] = st
-            if "stem_fused" in stages:
-                stages["stem_fused"]["layers"] = "1-3 (conv1 + depthwise + pointwise in one kernel)"
-            if "block_fused" in stages:
-                stages["block_fused"]["layers"] = ", ".join("%d-%d" % (idx[0] + 1, idx[1] + 1) for idx in launches if len(idx) == 2) \
-                                                  + " (depthwise + pointwise in one kernel each)"
+            stages, per_layer, stage_of = stage_table(plan, pkg, launches, layer_ms, args.batch, act_bytes, mfma_peak)
             pw = stages["pointwise"]
             pw_idx = [launches[j][0] for j in range(n_launch) if stage_of[j] == "pointwise"]
             out["launches_per_layer"] = nsub
             flops_per_launch = sum(layer_work(plan.layer[i], args.batch, pkg, act_bytes)[0] for i in pw_idx) / len(pw_idx)
             bytes_per_launch = sum(layer_work(plan.layer[i], args.batch, pkg, act_bytes)[1] for i in pw_idx) / len(pw_idx)
             avg_ms = pw["ms"] / len(pw_idx)           # per LAYER (= per launch when --streams 1)
+            traffic, traffic_src = load_traffic([i + 1 for i in pw_idx], "bf16_%gx%d" % (args.alpha, args.res) if bf16 else "f32")
             if bf16:       # ridge ~312 flop/B: every pointwise layer is HBM-bound in bf16 (SURVEY §7)
                 out["roofline"] = {
                     "kernel": "pw_gemm<bf16> (%d pointwise 1x1 conv launches per step)" % len(pw_idx),
                     "bound": "hbm", "achieved": round(bytes_per_launch / avg_ms / 1e6, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(bytes_per_launch / avg_ms / 1e6 / HBM_PEAK_GBS, 4),
-                    "traffic": None, "avg_launch_ms": round(avg_ms, 5),
+                    "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(avg_ms, 5),
                     "algorithmic_bytes_per_launch": bytes_per_launch,
                 }
             else:
@@ -295,7 +320,7 @@ def main():
                     "kernel": "pw_gemm<float> (%d pointwise 1x1 conv launches per step)" % len(pw_idx),
                     "bound": "mfma", "achieved": round(flops_per_launch / avg_ms / 1e9, 2), "peak": MFMA_F32_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(flops_per_launch / avg_ms / 1e9 / MFMA_F32_PEAK_TFLOPS, 4),
-                    "traffic": load_traffic([i + 1 for i in pw_idx]), "avg_launch_ms": round(avg_ms, 5),
+                    "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(avg_ms, 5),
                     "algorithmic_flops_per_launch": flops_per_launch,
                     "algorithmic_bytes_per_launch": bytes_per_launch,
                 }
@@ -304,23 +329,79 @@ def main():
             out["sum_kernel_ms"] = round(float(layer_ms.sum()), 4)
             out["profiled_steps"] = len(sampled)
         out["h2d_ms_per_batch"] = round(h2d_ms, 3)   # PCIe-inclusive rate = batch / (ms_per_step + this)
+        if step_ms.size:
+            out["step_ms"] = {"median": round(float(np.median(step_ms)), 4), "p10": round(float(np.percentile(step_ms, 10)), 4),
+                              "p90": round(float(np.percentile(step_ms, 90)), 4), "n": int(step_ms.size),
+                              "how": "HIP event between steps on the kernels' stream, no sync inside the timed region"}
+        if world == 1 and profile and not args.no_unfused_stages and nsub == 1:
+            # all 13 depthwise + 13 pointwise stages as their own launches (the metric names per-stage numbers; the timed
+            # configuration above folds layers 1-11 into fused launches). UNTIMED: outside the region `value` comes from.
+            saved_mask = net.get_fuse_blocks()
+            net.set_fuse_stem(False)
+            net.set_fuse_blocks(0)
+            ul = [list(range(f - 1, f - 1 + c)) for f, c in net.launches(args.batch)]
+            for _ in range(2):
+                net.forward(d_in.ptr, d_out.ptr, args.batch)
+            reps = 5
+            ctx.profile_begin(len(ul) * reps)
+            for _ in range(reps):
+                net.forward(d_in.ptr, d_out.ptr, args.batch)
+            ums = np.asarray(ctx.profile_end(len(ul) * reps), dtype=np.float64).reshape(reps, len(ul)).mean(axis=0)
+            ust, ulayers, _ = stage_table(plan, pkg, ul, ums, args.batch, act_bytes, mfma_peak)
+            out["unfused_stages"] = {"note": "untimed: %d forwards with one launch per layer (mbn_net_set_fuse_stem(0), "
+                                             "mbn_net_set_fuse_blocks(0)); same batch, same buffers" % reps,
+                                     "stages": ust, "layers": ulayers, "sum_kernel_ms": round(float(ums.sum()), 4)}
+            net.set_fuse_stem(not args.no_fuse_stem)
+            net.set_fuse_blocks(saved_mask)
         if world == 1 and not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import oracle as orc   # cpu_baseline leg: the oracle is the thing timed here, never the product path
             oplan = orc.plan_build(args.alpha, args.res, 1000)
             cores = min(orc.num_threads(), args.cpu_threads)      # the one-GPU box's CPU share is 16 cores
-            n_img = args.cpu_images or max(2, 4 * cores)          # ~20-30 CPU-seconds of work
+            n_img = min(args.cpu_images or max(2, 4 * cores), head.shape[0], args.batch)   # ~1-2 s on 16 cores
             blob = blob_t.cpu().numpy()
-            sample = np.random.default_rng(1).random((n_img, args.res, args.res, 3), dtype=np.float32) * 2 - 1
+            sample = head[:n_img]                                 # the first n images of the timed batch
             c0 = time.perf_counter()
             ref, _ = orc.net_forward(oplan, blob, sample, threads=cores, bf16=bf16)
             c1 = time.perf_counter()
             out["cpu_baseline"] = {"value": n_img / (c1 - c0), "unit": "images/sec", "cores": cores, "kind": "port",
-                                   "sample": "%d images, same network/weights, C restatement of kernel.cl semantics "
-                                             "in fp32 NHWC (oracle/mbn_oracle.c), OpenMP over output pixels, %.1f s"
-                                             % (n_img, c1 - c0)}
+                                   "sample": "first %d images of the timed batch, same network/weights, C restatement of "
+                                             "kernel.cl semantics in fp32 NHWC (oracle/mbn_oracle.c), OpenMP over output "
+                                             "pixels, %.1f s" % (n_img, c1 - c0)}
+            # ---- parity of the timed workload itself: what the steps left in d_out vs the oracle, same images
+            ref = np.asarray(ref, dtype=np.float64).reshape(n_img, 1000)
+            got = logits[:n_img].astype(np.float64)
+            scale = max(float(np.abs(ref).max()), 1e-6)
+            err = float(np.abs(got - ref).max()) / scale
+            tol = 6e-2 if bf16 else 1e-3
+            out["parity_check"] = {"images": n_img, "max_rel_err": err, "tolerance": tol, "ok": bool(err <= tol),
+                                   "argmax_agree": int((got.argmax(1) == ref.argmax(1)).sum()),
+                                   "against": "oracle/mbn_oracle.c F32 mode%s, logits of the first %d images of the timed batch"
+                                              % (" (bf16 storage emulated)" if bf16 else "", n_img)}
+            if not args.no_cpu_variants:
+                # SURVEY.md §8d / BASELINE.md §3: single thread (faithful to the reference's one-work-item-at-a-time
+                # semantics) and all cores, batch 1 and 8, median of 5
+                def med5(nb, th):
+                    ts = []
+                    for _ in range(5):
+                        a0 = time.perf_counter()
+                        orc.net_forward(oplan, blob, head[:nb], threads=th, bf16=bf16)
+                        ts.append(time.perf_counter() - a0)
+                    return float(np.median(ts))
+                var = {}
+                for th in (1, cores):
+                    for nb in (1, 8):
+                        t = med5(nb, th)
+                        var["threads%d_batch%d" % (th, nb)] = {"ms_per_image": round(1000.0 * t / nb, 2),
+                                                               "images_per_sec": round(nb / t, 2)}
+                out["cpu_baseline"]["variants"] = var
+                out["cpu_baseline"]["variants_how"] = "median of 5, host cores of this box: %d used of %d visible" % (
+                    cores, os.cpu_count() or cores)
         print(json.dumps(out))
         sys.stdout.flush()
+        if "parity_check" in out and not out["parity_check"]["ok"]:
+            sys.exit("parity check failed: max rel err %.3e > %.1e" % (out["parity_check"]["max_rel_err"],
+                                                                       out["parity_check"]["tolerance"]))
 
     net.destroy()
     ctx.close()

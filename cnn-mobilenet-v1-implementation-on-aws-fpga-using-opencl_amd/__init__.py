@@ -158,6 +158,7 @@ def load():
         lib.mbn_net_set_fuse_stem.argtypes = [vp, ci]
         lib.mbn_net_fused_layers.argtypes = [vp, ci, C.POINTER(ci)]
         lib.mbn_net_set_fuse_blocks.argtypes = [vp, C.c_uint]
+        lib.mbn_net_get_fuse_blocks.argtypes = [vp, C.POINTER(C.c_uint)]
         lib.mbn_net_classify.argtypes = [vp, vp, ci, ci, vp, vp]
         lib.mbn_net_launches.argtypes = [vp, ci, ci, C.POINTER(ci), C.POINTER(ci), ci, C.POINTER(ci)]
         lib.mbn_stem_fused.argtypes = [vp] + [vp] * 11 + [ci, ci, ci, ci, vp]
@@ -417,6 +418,11 @@ class Net:
 
     def set_fuse_blocks(self, mask):
         _chk(self.ctx.lib.mbn_net_set_fuse_blocks(self.h, int(mask)))
+
+    def get_fuse_blocks(self) -> int:
+        m = C.c_uint()
+        _chk(self.ctx.lib.mbn_net_get_fuse_blocks(self.h, C.byref(m)))
+        return m.value
 
     def launches(self, batch, last_layer=0):
         """[(first_layer, n_layers), ...] of the launches one forward issues per (sub-)batch."""

@@ -240,6 +240,13 @@ int mbn_net_set_fuse_blocks(mbn_net *net, unsigned mask)
     return MBN_OK;
 }
 
+int mbn_net_get_fuse_blocks(const mbn_net *net, unsigned *mask)
+{
+    if (!net || !mask) return MBN_EINVAL;
+    *mask = net->fuse_blocks;
+    return MBN_OK;
+}
+
 int mbn_net_launches(const mbn_net *net, int batch, int last_layer, int *first_layer, int *n_layers, int capacity, int *count)
 {
     if (!net || !count || batch <= 0) return MBN_EINVAL;

@@ -412,6 +412,7 @@ int  mbn_net_fused_layers(const mbn_net *net, int last_layer, int *count);
  * (DESIGN.md); 0 = every layer its own launch. Results are bit-identical either way. */
 #define MBN_FUSE_BLOCKS_DEFAULT ((1u << 4) | (1u << 6) | (1u << 8) | (1u << 10))
 int  mbn_net_set_fuse_blocks(mbn_net *net, unsigned mask);
+int  mbn_net_get_fuse_blocks(const mbn_net *net, unsigned *mask);
 /* The launches the next forward(batch, last_layer) issues per (sub-)batch: launch j covers n_layers[j] layers starting
  * at the 1-based layer first_layer[j] (3 = fused stem, 2 = fused block, 1 = single layer). *count = number of
  * launches; the arrays (may be NULL) receive at most `capacity` entries. */

@@ -1026,3 +1026,139 @@ def test_bf16_dwpw_fused(pkg, orc, ctx, shape):
     fused, sep = _bf16_get(pkg, d_f, want.shape), _bf16_get(pkg, d_u, want.shape)
     assert_close(fused, want, TOL_BF16, "bf16 fused block %s vs oracle" % (shape,))
     assert_close(fused, sep, TOL_BF16, "bf16 fused block %s vs separate launches" % (shape,))
+
+
+# =========================================================================== headline workloads
+
+def _headline_images(n, res, seed):
+    """Seeded U[-1,1) batch generated in slices (a 512 x 224 x 224 x 3 float64 temporary is avoided)."""
+    rng = np.random.default_rng(seed)
+    out = np.empty((n, res, res, 3), np.float32)
+    for i in range(0, n, 64):
+        out[i:i + 64] = rng.random((min(64, n - i), res, res, 3), dtype=np.float32) * 2.0 - 1.0
+    return out
+
+
+def test_headline_fp32_batch256_vs_oracle(pkg, orc, ctx, tmp_path):
+    """BASELINE.json configs[2] itself — MobileNet-V1 1.0x224 fp32, batch 256, the runner's DEFAULT configuration (fused
+    stem, fused blocks, persistent GEMM tiles walking many tiles per workgroup) — checked for correctness, not just
+    finiteness: logits of the first, two middle and the last image against the oracle run on those images alone
+    (TOL_NET), and forward(256)[:24] == forward(24) bit for bit (tile and segment heuristics depend on the batch, the
+    per-row arithmetic must not). Reference behaviour matched: the 29-layer sequence MobileNet.c:240-2763."""
+    n = 256
+    hw, net = _make_net(pkg, ctx, tmp_path, 1.0, 224, 1000, n)
+    imgs = _headline_images(n, 224, 20261004)
+    d_in, d_out = ctx.to_device(imgs), ctx.alloc(n * 1000 * 4)
+    spans = [c for _, c in net.launches(n)]
+    assert spans[0] == 3 and spans.count(2) >= 4, spans          # the fused kernels are on the path being checked
+    net.forward(d_in.ptr, d_out.ptr, n)
+    ctx.sync()
+    got = d_out.download((n, 1000), np.float32)
+    assert np.isfinite(got).all()
+    pick = [0, 85, 170, 255]
+    oplan = orc.plan_build(1.0, 224, 1000)
+    want, _ = orc.net_forward(oplan, hw.blob, imgs[pick], threads=orc.num_threads())
+    assert_close(got[pick], np.asarray(want).reshape(len(pick), 1000), TOL_NET, "batch-256 logits of images %s" % pick)
+    assert (got[pick].argmax(1) == np.asarray(want).reshape(len(pick), 1000).argmax(1)).all()
+    d_small = ctx.alloc(24 * 1000 * 4)
+    net.forward(d_in.ptr, d_small.ptr, 24)
+    ctx.sync()
+    assert np.array_equal(d_small.download((24, 1000), np.float32), got[:24])
+    net.destroy()
+
+
+@pytest.mark.parametrize("cfg", [(1.0, 224), (0.5, 160)])
+def test_headline_bf16_batch512_vs_oracle(pkg, orc, ctx, tmp_path, cfg):
+    """BASELINE.json configs[4]: bf16 storage, batch 512, at 1.0x224 and 0.5x160, default runner. Logits of four images
+    spread over the batch against the oracle's bf16-emulating forward of those images alone (6e-2 of max|ref|: rounding
+    flips accumulate over 28 layers, same bound as the small bf16 net tests), and batch-slot independence at full size:
+    forward(512)[:16] == forward(16)."""
+    alpha, res = cfg
+    n = 512
+    hw, net = _make_net(pkg, ctx, tmp_path, alpha, res, 1000, n)
+    net.set_dtype(pkg.DT_BF16)
+    imgs = _headline_images(n, res, 512 + res)
+    d_in, d_out = ctx.to_device(imgs), ctx.alloc(n * 1000 * 4)
+    net.forward(d_in.ptr, d_out.ptr, n)
+    ctx.sync()
+    got = d_out.download((n, 1000), np.float32)
+    assert np.isfinite(got).all()
+    pick = [0, 170, 341, 511]
+    oplan = orc.plan_build(alpha, res, 1000)
+    want, _ = orc.net_forward(oplan, hw.blob, imgs[pick], threads=orc.num_threads(), bf16=True)
+    assert_close(got[pick], np.asarray(want).reshape(len(pick), 1000), 6e-2, "bf16 batch-512 logits %s" % (cfg,))
+    d_small = ctx.alloc(16 * 1000 * 4)
+    net.forward(d_in.ptr, d_small.ptr, 16)
+    ctx.sync()
+    assert np.array_equal(d_small.download((16, 1000), np.float32), got[:16])
+    net.destroy()
+
+
+def test_undersized_buffers_are_einval_not_faults(pkg, ctx):
+    """The fault class on record from round 1 (gpurun_out/fault.log: the C host handed a 3*96*96*3-BYTE uint8 image to the
+    fp32 first-layer kernel, which read 4x the buffer) is a caller error the ABI can see: every mbn_alloc buffer's size
+    is known. An undersized input, output, filter or scale must come back as MBN_EINVAL with nothing launched."""
+    n, res = 3, 96
+    u8 = np.zeros((n, res, res, 3), np.uint8)
+    d_img = ctx.to_device(u8)                                        # n*res*res*3 BYTES
+    d_out = ctx.alloc(n * 48 * 48 * 8 * 4)
+    d_w = ctx.to_device(np.zeros((3, 3, 3, 8), np.float32))
+    ext = pkg.make_ext(batch=n, cin=3)
+    rc = ctx.lib.mbn_convolute(ctx.h, d_out.ptr, d_img.ptr, None, None, d_w.ptr, res, res, 3, 2, 8, C.byref(ext))
+    assert rc == pkg.EINVAL and b"convolute image" in ctx.lib.mbn_last_device_error(ctx.h)
+    ext_u8 = pkg.make_ext(batch=n, cin=3, io_flags=pkg.IO_IN_U8)     # the same buffer IS right for the uint8 front-end
+    assert ctx.lib.mbn_convolute(ctx.h, d_out.ptr, d_img.ptr, None, None, d_w.ptr, res, res, 3, 2, 8, C.byref(ext_u8)) == 0
+    # output one image short; interior pointer whose remainder is too small; short filter; short scale
+    x = ctx.to_device(np.zeros((2, 14, 14, 64), np.float32))
+    w = ctx.to_device(np.zeros((128, 64), np.float32))
+    o = ctx.alloc(1 * 14 * 14 * 128 * 4)
+    e2 = pkg.make_ext(batch=2)
+    assert ctx.lib.mbn_pointwise(ctx.h, o.ptr, x.ptr, w.ptr, 14, 14, 64, 128, C.byref(e2)) == pkg.EINVAL
+    o2 = ctx.alloc(2 * 14 * 14 * 128 * 4)
+    assert ctx.lib.mbn_pointwise(ctx.h, o2.ptr, x.ptr, w.ptr, 14, 14, 64, 128, C.byref(e2)) == 0
+    assert ctx.lib.mbn_pointwise(ctx.h, o2.ptr + 4096, x.ptr, w.ptr, 14, 14, 64, 128, C.byref(e2)) == pkg.EINVAL
+    assert ctx.lib.mbn_pointwise(ctx.h, o2.ptr, x.ptr, w.ptr, 14, 14, 64, 256, C.byref(e2)) == pkg.EINVAL   # filter 128x64, call says 256
+    sc = ctx.to_device(np.ones(64, np.float32))
+    e3 = pkg.make_ext(batch=2, scale=sc.ptr, shift=sc.ptr)
+    assert ctx.lib.mbn_pointwise(ctx.h, o2.ptr, x.ptr, w.ptr, 14, 14, 64, 128, C.byref(e3)) == pkg.EINVAL   # 64 scales for 128 channels
+    dwf = ctx.to_device(np.zeros((3, 3, 64), np.float32))
+    assert ctx.lib.mbn_depthwise(ctx.h, o2.ptr, x.ptr, dwf.ptr, 14, 14, 3, 1, 64, C.byref(pkg.make_ext(batch=3))) == pkg.EINVAL
+    assert ctx.lib.mbn_pool(ctx.h, o2.ptr, x.ptr, 14, 14, 14, 64, C.byref(pkg.make_ext(batch=4, act=0))) == pkg.EINVAL
+    assert ctx.lib.mbn_upload(ctx.h, sc.ptr, u8.ctypes.data, 64 * 4 + 1) == pkg.EINVAL
+    ctx.sync()                                                        # nothing faulted; the context is still usable
+    # the whole-network runner inherits the guard through the layer calls: a logits buffer sized for half the batch
+    plan = pkg.plan_build(0.25, 64, 10)
+    blob = np.zeros(plan.blob_floats, np.float32)
+    net = pkg.Net(ctx, plan, blob, 4)
+    imgs = ctx.to_device(np.zeros((4, 64, 64, 3), np.float32))
+    small = ctx.alloc(2 * 10 * 4)
+    assert ctx.lib.mbn_net_forward(net.h, imgs.ptr, small.ptr, 4, 0) == pkg.EINVAL
+    ok = ctx.alloc(4 * 10 * 4)
+    assert ctx.lib.mbn_net_forward(net.h, imgs.ptr, ok.ptr, 4, 0) == 0
+    ctx.sync()
+    net.destroy()
+
+
+def test_profile_scope_not_consumed_by_rejected_calls(pkg, ctx):
+    """VERDICT r1 weak #13 / ADVICE: a call that returns MBN_EINVAL after validation must not take an event slot —
+    mbn_profile_end then read a start event whose stop was never recorded."""
+    x = ctx.to_device(np.zeros((1, 8, 8, 3), np.float32))
+    w = ctx.to_device(np.zeros((3, 3, 3, 8), np.float32))
+    o = ctx.alloc(4 * 4 * 8 * 4)
+    ctx.profile_begin(4)
+    lit = pkg.make_ext(dtype=pkg.DT_U8, quirks=0)
+    assert ctx.lib.mbn_convolute(ctx.h, o.ptr, x.ptr, None, None, w.ptr, 8, 8, 3, 2, 8, C.byref(lit)) == pkg.EINVAL   # LITERAL needs g/b planes
+    assert ctx.lib.mbn_convolute(ctx.h, o.ptr, x.ptr, None, None, w.ptr, 8, 8, 3, 2, 8, C.byref(pkg.make_ext(cin=3))) == 0
+    ms = ctx.profile_end(4)
+    assert len(ms) == 1 and ms[0] > 0
+
+
+def test_step_markers(pkg, ctx):
+    x = ctx.alloc(1 << 20)
+    for _ in range(4):
+        ctx.mark()
+        assert ctx.lib.mbn_memset(ctx.h, x.ptr, 0, 1 << 20) == 0
+    ctx.mark()
+    ms = ctx.marks_read(16)
+    assert len(ms) == 4 and all(m >= 0 for m in ms)
+    assert ctx.marks_read(16) == []
