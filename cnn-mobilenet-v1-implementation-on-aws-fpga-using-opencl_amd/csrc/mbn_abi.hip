@@ -63,6 +63,7 @@ static std::atomic<int> *tune_slot(const char *key)
     if (!strcmp(key, "conv_variant")) return &g_mbn_tune.conv_variant;
     if (!strcmp(key, "misc")) return &g_mbn_tune.misc;
     if (!strcmp(key, "net_stagger")) return &g_mbn_tune.net_stagger;
+    if (!strcmp(key, "dwpw_variant")) return &g_mbn_tune.dwpw_variant;
     return nullptr;
 }
 
@@ -691,6 +692,14 @@ int mbn_dwpw_fused(mbn_context *ctx, void *out, const void *in, const void *wd, 
               { out, 4.0 * batch * out_rows * out_cols * cout, "dwpw output" }, { wd, 36.0 * cin, "dwpw depthwise filter" },
               { wp, 4.0 * cin * cout, "dwpw pointwise filter" });
     Scope sc(ctx, s);
+    // unified-wave kernel (mbn_f32_dwpw2.hip) for the 128-column tile, where it measures 9-12 % faster than the round-1
+    // producer/consumer kernel; the 256-column tile stays on the round-1 kernel (within +-3 % of each other there).
+    // dwpw_variant: 1 = always round-1, 2 = always unified (A/B hooks, tools/block_bench.py)
+    const int dv = g_mbn_tune.dwpw_variant;
+    if (dv != 1 && (dv >= 2 || (cout % 256) != 0))
+        return sc.finish(mbn_launch_f32_dwpw2(ctx, s, (float *)out, (const float *)in, (const float *)wd, (const float *)s2,
+                                              (const float *)b2, (const float *)wp, (const float *)s3, (const float *)b3, batch,
+                                              in_rows, in_cols, out_rows, out_cols, cin, cout, stride, pad_top, pad_left));
     return sc.finish(mbn_launch_f32_dwpw(ctx, s, (float *)out, (const float *)in, (const float *)wd, (const float *)s2,
                                          (const float *)b2, (const float *)wp, (const float *)s3, (const float *)b3, batch,
                                          in_rows, in_cols, out_rows, out_cols, cin, cout, stride, pad_top, pad_left));

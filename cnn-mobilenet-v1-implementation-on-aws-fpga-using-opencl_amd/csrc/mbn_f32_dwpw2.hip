@@ -1,0 +1,339 @@
+// mbn_f32_dwpw2.hip — fused depthwise 3x3 -> pointwise 1x1 block for gfx950, fp32, UNIFIED-WAVE form (round 2).
+// Same contract as mbn_f32_dwpw.hip (one launch replaces a `depthwise` + `pointwise` pair of the reference's sequence,
+// kernel.cl:62-92 + 94-114, pairs L4-5 ... of MobileNet.c:322-2599; bit-identical to the two separate launches):
+//
+//   out[m][n] = relu6( s3[n] * sum_c relu6( s2[c] * sum_{dy,dx} in[pix(m)+(dy,dx)][c] * wd[dy][dx][c] + b2[c] ) * wp[n][c] + b3[n] )
+//
+// Why a second form. On a gfx950 SIMD fp32 MFMA time and VALU time ADD (tools/micro/: v_mfma_f32_32x32x2_f32 runs at the
+// fp32 vector rate and a VALU wave gets no issue slot beside an MFMA-streaming wave), so the best a fused block can do
+// is (MFMA cycles) + (VALU instructions x ~5 cycles). The round-1 kernel split the workgroup into 8 producer (VALU) and
+// 8 consumer (MFMA) waves: the producers were starved while the consumers streamed, so their whole dependent chain —
+// LDS-DMA wait, eleven LDS weight reads, 52 FMAs, two LDS writes — ran after the consumers' MFMAs with every latency
+// exposed: ~3000 cycles per 32-channel chunk on top of 4096-8192 MFMA cycles (0.36 HBM / 0.50 MFMA, BENCH_r01).
+// Here every wave does BOTH jobs in one in-order instruction stream: its 1/8 of the depthwise chunk (2 pixels x 4
+// channels per lane) and its 32x64 / 64x64 MFMA tile, so nothing is starved, there is one barrier per chunk and no
+// cross-wave hand-over besides it, and each operand of the VALU part is in registers before the part starts:
+//   * x window of chunk g+1: buffer_load_dwordx4 issued one chunk ahead (taps outside the image carry an out-of-range
+//     offset, the buffer unit returns 0: zero padding costs no VALU and no branches);
+//   * depthwise taps + scale/shift of chunk g+1: read from LDS before the previous barrier (44 VGPRs; 8 waves per
+//     workgroup = 2 per SIMD = 256 VGPRs per wave make room for them next to the 64 accumulators);
+//   * pointwise filter chunk [BN][32]: buffer_load ... lds (descriptor + fixed per-lane offset + scalar K offset),
+//     issued first thing after the barrier; its wait sits in front of the NEXT barrier behind a whole chunk of MFMAs.
+// Per chunk and wave: D(g+1) = 36 v_pk_fma + 8 fma + 8 med3 + 2 ds_write_b128; L(g+2) = 12-15 buffer loads;
+// M(g) = 32 / 64 MFMAs with the fragment reads of group i+1 ahead of the MFMAs of group i (as in mbn_f32_pw.hip).
+// Measured and rejected here (profiles/r02/b_block_kernel_variants.txt): the transposed product (operands swapped so a
+// lane holds 4 consecutive output channels and the epilogue is 8 buffer_store_dwordx4 instead of 32 dword stores per
+// 32x64 wave tile): 4-8 % SLOWER on every block — 64 scattered 16-byte segments per store instruction cost more in the
+// memory pipeline than two full 128-byte lines. Ablation of one step (block 6-7, same file): without the epilogue
+// stores -13 %, without the x-window loads -13 %, without the depthwise math -7 %, without the filter DMA -4 %.
+// The loop is unrolled by two so the LDS buffer index is a literal in every address (the waitcnt pass then keeps the
+// LDS-DMA of buffer p^1 apart from the fragment reads of buffer p instead of draining vmcnt before each ds_read).
+#include "mbn_internal.h"
+#include "mbn_epilogue.h"
+
+namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef mbn_f16v f16v;
+
+constexpr int BM = 128, BKF = 32;
+constexpr int NW = 8, NT = 64 * NW;            // 8 waves: 2 per SIMD, 256 VGPRs each
+constexpr int CMAX = 1024;                     // largest Cin (depthwise constants resident in LDS: 44 KB)
+constexpr unsigned OOB = 0xF0000000u;          // byte offset beyond any supported tensor: the load returns zeros
+
+struct DwPw2Args {
+    float *out;
+    const float *in, *wd, *s2, *b2, *wp, *s3, *b3;
+    long m;                 // output pixels = batch * ho * wo
+    int h, w, ho, wo;       // input / output map sides
+    int cin, cout;
+    int pad_top, pad_left;
+    int mt, nt;
+    unsigned in_bytes, wp_bytes;
+    int dbg;                // experiments (tune misc): 1 = no x loads after the first, 2 = no depthwise math, 4 = no output stores, 8 = no filter DMA, 16 = no MFMA
+    unsigned wo_m, wo_s, ho_m, ho_s;   // floor(v / wo) = umulhi(v, wo_m) >> wo_s for v < 2^31 (m == 0: the divisor is 1)
+};
+
+__device__ __forceinline__ int swz(int row, int chunk) { return (row << 5) + (((chunk ^ (row >> 1)) & 7) << 2); }
+__device__ __forceinline__ float relu6(float v) { return fminf(fmaxf(v, 0.f), 6.f); }
+__device__ __forceinline__ f4 bn_relu6(f4 a, f4 s, f4 b)
+{
+    return f4{ relu6(fmaf(a.x, s.x, b.x)), relu6(fmaf(a.y, s.y, b.y)), relu6(fmaf(a.z, s.z, b.z)), relu6(fmaf(a.w, s.w, b.w)) };
+}
+__device__ __forceinline__ int xcd_remap(int vb, int nwg)
+{
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = vb & 7;
+    return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (vb >> 3);
+}
+
+// Workgroup barrier with the waits spelled out. __syncthreads() is a workgroup-scope fence over every address space: with
+// global loads in flight for the NEXT chunk the waitcnt pass drains them (s_waitcnt vmcnt(0)) in front of every barrier
+// (also with the "local"-only fence form), which serialises the prefetch with the hand-over. Here: wait until all but
+// the VM_LEFT youngest vector-memory operations are done (= the LDS-DMA of the filter chunk has landed, the x-window
+// loads issued after it may still fly), until this wave's own LDS writes are done (lgkmcnt(0)), then s_barrier. The asm
+// is volatile with a memory clobber, so the compiler moves no LDS or global access across it.
+template <int VM_LEFT>
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(VM_LEFT) : "memory");
+}
+
+// pointwise filter chunk -> LDS, buffer form (a __device__ function: see mbn_f32_pw.hip lds_dma_rows)
+template <int B_LD>
+__device__ __forceinline__ void dma_filter(__amdgpu_buffer_rsrc_t rsrc, float *lds_b, const unsigned *voff, int soff, int wave_u)
+{
+#pragma unroll
+    for (int p = 0; p < B_LD; p++)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(lds_b + (p * (NT / 8) + wave_u * 8) * BKF),
+                                                 16, voff[p], soff, 0, 0);
+}
+
+template <int S, int BN, bool PRE>
+__global__ __launch_bounds__(NT) void dwpw2_f32(DwPw2Args a)
+{
+    constexpr int WN = 64, WM = BN == 256 ? 64 : 32;   // wave tile: 8 waves as 2 x 4 (BN 256) or 4 x 2 (BN 128)
+    constexpr int WAVES_N = BN / WN;
+    static_assert((BM / WM) * WAVES_N == NW, "8 waves");
+    constexpr int MI = WM / 32, NI = WN / 32;
+    constexpr int B_LD = BN * 8 / NT;                  // 16-B filter pieces per lane per chunk (2 / 4)
+    constexpr int XC = S + 3;                          // input columns feeding 2 adjacent output pixels
+    constexpr int NX = 3 * XC;                         // buffer loads per lane per chunk
+    constexpr int ABUF = BM * BKF, BBUF = BN * BKF;
+    __shared__ __attribute__((aligned(16))) float lds[2 * ABUF + 2 * BBUF + 11 * CMAX];
+    float *const a_s0 = lds, *const b_s0 = lds + 2 * ABUF, *const wd_s = b_s0 + 2 * BBUF, *const sb_s = wd_s + 9 * CMAX;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nk = a.cin / 32, nwg = a.mt * a.nt;
+    const unsigned mtot = (unsigned)a.m;
+
+    for (int i = tid * 4; i < 9 * a.cin; i += NT * 4) *reinterpret_cast<f4 *>(wd_s + i) = *reinterpret_cast<const f4 *>(a.wd + i);
+    for (int i = tid * 4; i < a.cin; i += NT * 4) {
+        *reinterpret_cast<f4 *>(sb_s + i) = *reinterpret_cast<const f4 *>(a.s2 + i);
+        *reinterpret_cast<f4 *>(sb_s + a.cin + i) = *reinterpret_cast<const f4 *>(a.b2 + i);
+    }
+    __syncthreads();
+    if ((int)blockIdx.x >= nwg) return;
+
+    // ---- roles of this lane
+    const int c4 = tid & 7, pair = tid >> 3;                        // depthwise: tile rows 2*pair, 2*pair+1, channels 4*c4..+3 of the chunk
+    const int wm = (wave_u / WAVES_N) * WM, wn = (wave_u % WAVES_N) * WN;      // MFMA tile origin inside the workgroup tile
+    const int li = lane & 31, lh = lane >> 5;
+    const __amdgpu_buffer_rsrc_t irsrc = mbn_make_rsrc(a.in, a.in_bytes);
+    const __amdgpu_buffer_rsrc_t wrsrc = mbn_make_rsrc(a.wp, a.wp_bytes);
+    const __amdgpu_buffer_rsrc_t orsrc = mbn_make_rsrc(a.out, (unsigned)(a.m * a.cout * 4));
+    const int aw0 = swz(2 * pair, c4), aw1 = swz(2 * pair + 1, c4);           // A-tile slots this lane writes
+    int fr_a[4], fr_b[4];                                                       // fragment slots this lane reads
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        fr_a[g] = swz(wm + li, 2 * g + lh);
+        fr_b[g] = swz(wn + li, 2 * g + lh);
+    }
+    unsigned b_vo[B_LD];                                                        // filter piece offsets: fixed for the kernel, the tile's
+#pragma unroll                                                                  // column origin and the chunk go into the scalar offset
+    for (int p = 0; p < B_LD; p++) {
+        const int row = (p * NT + tid) >> 3;
+        b_vo[p] = ((unsigned)row * (unsigned)a.cin + (unsigned)(((c4 ^ (row >> 1)) & 7) * 4)) * 4u;
+    }
+    const float *wk = wd_s + c4 * 4;                                           // depthwise taps of this lane's 4 channels (+ kc*32 + tap*cin)
+    const float *sk = sb_s + c4 * 4;
+
+    unsigned off[3][XC];
+    auto set_offsets = [&](unsigned m0) __attribute__((always_inline)) {
+        const unsigned m = m0 + 2 * pair;
+        const bool mok = m < mtot;
+        const unsigned q = a.wo_m ? __umulhi(m, a.wo_m) >> a.wo_s : m;
+        const unsigned x = m - q * (unsigned)a.wo;
+        const unsigned n = a.ho_m ? __umulhi(q, a.ho_m) >> a.ho_s : q;
+        const unsigned y = q - n * (unsigned)a.ho;
+        const int iy0 = (int)y * S - a.pad_top, ix0 = (int)x * S - a.pad_left;
+        const unsigned cs = (unsigned)a.cin * 4u, rs = (unsigned)a.w * cs;                    // column / row stride in bytes
+        const unsigned base = ((n * a.h + iy0) * a.w + ix0) * cs + (unsigned)(c4 * 4) * 4u;         // wraps for taps that are masked out below
+#pragma unroll
+        for (int dy = 0; dy < 3; dy++) {
+            const bool rok = mok && (unsigned)(iy0 + dy) < (unsigned)a.h;
+#pragma unroll
+            for (int j = 0; j < XC; j++) {
+                const bool ok = rok && (unsigned)(ix0 + j) < (unsigned)a.w;
+                off[dy][j] = ok ? base + dy * rs + j * cs : OOB;
+            }
+        }
+    };
+    f4 xr[3][XC];
+    auto ldx = [&](int kc) __attribute__((always_inline)) {
+#pragma unroll
+        for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+            for (int j = 0; j < XC; j++)
+                xr[dy][j] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(irsrc, off[dy][j], kc * 128, 0));
+    };
+    f4 wreg[11];                                                               // 9 taps, scale, shift of the chunk D works on
+    auto ldw = [&](int kc) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < 9; t++) wreg[t] = *reinterpret_cast<const f4 *>(wk + kc * 32 + t * a.cin);
+        wreg[9] = *reinterpret_cast<const f4 *>(sk + kc * 32);
+        wreg[10] = *reinterpret_cast<const f4 *>(sk + a.cin + kc * 32);
+    };
+    // depthwise + BN + ReLU6 of the chunk in xr/wreg into A buffer `buf` (same fma order as mbn_f32_dw.hip: bit-identical)
+    auto dw = [&](int kc, const int buf) __attribute__((always_inline)) {
+        if (!PRE) ldw(kc);
+        f4 acc0 = f4{ 0.f, 0.f, 0.f, 0.f }, acc1 = acc0;
+#pragma unroll
+        for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+            for (int dx = 0; dx < 3; dx++) {
+                acc0 = __builtin_elementwise_fma(xr[dy][dx], wreg[dy * 3 + dx], acc0);
+                acc1 = __builtin_elementwise_fma(xr[dy][dx + S], wreg[dy * 3 + dx], acc1);
+            }
+        *reinterpret_cast<f4 *>(a_s0 + buf * ABUF + aw0) = bn_relu6(acc0, wreg[9], wreg[10]);
+        *reinterpret_cast<f4 *>(a_s0 + buf * ABUF + aw1) = bn_relu6(acc1, wreg[9], wreg[10]);
+    };
+
+    f16v acc[MI][NI];
+    f4 fa[2][MI], fb[2][NI];
+    auto ldfrag = [&](const int buf, int g, int slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int mi = 0; mi < MI; mi++) fa[slot][mi] = *reinterpret_cast<const f4 *>(a_s0 + buf * ABUF + fr_a[g] + mi * 32 * BKF);
+#pragma unroll
+        for (int ni = 0; ni < NI; ni++) fb[slot][ni] = *reinterpret_cast<const f4 *>(b_s0 + buf * BBUF + fr_b[g] + ni * 32 * BKF);
+    };
+    auto mfma_group = [&](int slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+#pragma unroll
+            for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+                for (int ni = 0; ni < NI; ni++)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][mi][s], fb[slot][ni][s], acc[mi][ni], 0, 0, 0);
+    };
+    auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+            for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[mi][ni][r] = 0.f;
+    };
+
+    // ---- three cursors over the flattened (tile, chunk) sequence of this workgroup: L (x loads) one chunk ahead of
+    //      D (depthwise + filter DMA) one chunk ahead of M (MFMA). A cursor = (virtual block id, chunk, tile origin).
+    int vbM, kM, n0M; unsigned m0M;
+    int vbD, kD, n0D; unsigned m0D;
+    bool validD;
+    auto origin = [&](int vb, unsigned &m0, int &n0) __attribute__((always_inline)) {
+        const int lid = xcd_remap(vb, nwg);
+        n0 = (lid % a.nt) * BN;
+        m0 = (unsigned)(lid / a.nt) * BM;
+    };
+
+    // prologue: L(0), D(0) into buffer 0, L(1)
+    vbM = blockIdx.x; kM = 0;
+    origin(vbM, m0M, n0M);
+    set_offsets(m0M);
+    ldx(0);
+    if (PRE) ldw(0);
+    dma_filter<B_LD>(wrsrc, b_s0, b_vo, (n0M * a.cin + 0) * 4, wave_u);
+    dw(0, 0);
+    // D cursor = successor of M
+    vbD = vbM; kD = 1; m0D = m0M; n0D = n0M; validD = true;
+    if (kD >= nk) {
+        kD = 0; vbD += gridDim.x; validD = vbD < nwg;
+        if (validD) { origin(vbD, m0D, n0D); set_offsets(m0D); }
+    }
+    if (validD) {
+        ldx(kD);
+        if (PRE) ldw(kD);
+    }
+    zero_acc();
+    if (validD) lds_barrier<NX>();        // filter chunk 0 landed; the NX newer loads may fly
+    else lds_barrier<0>();
+
+    // One chunk step with the MFMA chunk in buffer P (a literal at both call sites).
+    // Returns false when the sequence is finished.
+#define MBN_DWPW2_STEP(P)                                                                                               \
+    {                                                                                                                   \
+        ldfrag(P, 0, 0);                                                                                                \
+        bool validL = false;                                                                                            \
+        int vbL = vbD, kL = kD + 1, n0L = n0D;                                                                          \
+        unsigned m0L = m0D;                                                                                             \
+        if (validD) {                                                                                                   \
+            if (!(a.dbg & 8)) dma_filter<B_LD>(wrsrc, b_s0 + (P ^ 1) * BBUF, b_vo, (n0D * a.cin + kD * 32) * 4, wave_u); \
+            if (!(a.dbg & 2)) dw(kD, P ^ 1);                                                                            \
+            validL = true;                                                                                              \
+            if (kL >= nk) {                                                                                             \
+                kL = 0; vbL += gridDim.x; validL = vbL < nwg;                                                           \
+                if (validL) { origin(vbL, m0L, n0L); set_offsets(m0L); }                                                \
+            }                                                                                                           \
+            if (validL && !(a.dbg & 1)) ldx(kL);                                                                        \
+        }                                                                                                               \
+        if (!(a.dbg & 16)) {                                                                                            \
+        _Pragma("unroll") for (int g = 0; g < 3; g++) {                                                                 \
+            ldfrag(P, g + 1, (g + 1) & 1);                                                                              \
+            __builtin_amdgcn_sched_barrier(0);                                                                          \
+            mfma_group(g & 1);                                                                                          \
+            __builtin_amdgcn_sched_barrier(0);                                                                          \
+        }                                                                                                               \
+        mfma_group(1);                                                                                                  \
+        }                                                                                                               \
+        if (PRE && validL) ldw(kL);                                                                                     \
+        if (validL) lds_barrier<NX>();                                                                                  \
+        else lds_barrier<0>();                                                                                          \
+        if (kM == nk - 1 && !(a.dbg & 4)) {                                                                             \
+            if (m0M + BM <= mtot) mbn_store_relu6_f32<MI, NI, 0>(orsrc, (unsigned)a.cout, m0M + wm, n0M + wn, lane, acc, a.s3, a.b3, mtot, a.cout); \
+            else mbn_store_relu6_f32<MI, NI, 1>(orsrc, (unsigned)a.cout, m0M + wm, n0M + wn, lane, acc, a.s3, a.b3, mtot, a.cout);               \
+            zero_acc();                                                                                                 \
+        }                                                                                                               \
+        if (!validD) break;                                                                                             \
+        vbM = vbD; kM = kD; m0M = m0D; n0M = n0D;                                                                       \
+        vbD = vbL; kD = kL; m0D = m0L; n0D = n0L; validD = validL;                                                      \
+    }
+
+    for (;;) {
+        MBN_DWPW2_STEP(0)
+        MBN_DWPW2_STEP(1)
+    }
+#undef MBN_DWPW2_STEP
+}
+
+template <int S, int BN>
+void launch2(DwPw2Args &a, hipStream_t s, int num_cus, bool pre)
+{
+    a.mt = (int)((a.m + BM - 1) / BM);
+    a.nt = a.cout / BN;
+    const long nwg = (long)a.mt * a.nt;
+    long grid = num_cus;
+    if (grid > nwg) grid = nwg;
+    if (pre) hipLaunchKernelGGL((dwpw2_f32<S, BN, true>), dim3((unsigned)grid), dim3(NT), 0, s, a);
+    else hipLaunchKernelGGL((dwpw2_f32<S, BN, false>), dim3((unsigned)grid), dim3(NT), 0, s, a);
+}
+
+}   // namespace
+
+// Unified-wave form of mbn_launch_f32_dwpw (same envelope: mbn_f32_dwpw_check has been passed by the caller).
+int mbn_launch_f32_dwpw2(mbn_context *ctx, hipStream_t stream, float *out, const float *in, const float *wd,
+                         const float *s2, const float *b2, const float *wp, const float *s3, const float *b3, int batch,
+                         int in_rows, int in_cols, int out_rows, int out_cols, int cin, int cout, int stride, int pad_top,
+                         int pad_left)
+{
+    DwPw2Args a;
+    a.out = out; a.in = in; a.wd = wd; a.s2 = s2; a.b2 = b2; a.wp = wp; a.s3 = s3; a.b3 = b3;
+    a.m = (long)batch * out_rows * out_cols;
+    a.h = in_rows; a.w = in_cols; a.ho = out_rows; a.wo = out_cols;
+    a.cin = cin; a.cout = cout; a.pad_top = pad_top; a.pad_left = pad_left;
+    mbn_udiv_magic((unsigned)out_cols, &a.wo_m, &a.wo_s);
+    mbn_udiv_magic((unsigned)out_rows, &a.ho_m, &a.ho_s);
+    const int variant = g_mbn_tune.dwpw_variant;
+    a.in_bytes = (unsigned)(4.0 * batch * in_rows * in_cols * cin);
+    a.wp_bytes = (unsigned)(4.0 * cin * cout);
+    a.dbg = variant >= 100 ? variant - 100 : 0;
+    const bool pre = variant != 3;                                       // 3: taps read from LDS inside the step (A/B hook)
+    const bool wide = (cout % 256) == 0 && g_mbn_tune.pw_tile != 1;      // pw_tile=1: force the 128-column tile (A/B hook)
+    if (stride == 1) {
+        if (wide) launch2<1, 256>(a, stream, ctx->num_cus, pre);
+        else launch2<1, 128>(a, stream, ctx->num_cus, pre);
+    } else {
+        if (wide) launch2<2, 256>(a, stream, ctx->num_cus, pre);
+        else launch2<2, 128>(a, stream, ctx->num_cus, pre);
+    }
+    return MBN_OK;
+}

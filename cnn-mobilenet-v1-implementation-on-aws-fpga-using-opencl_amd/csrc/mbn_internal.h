@@ -57,6 +57,8 @@ struct mbn_tunables {
     std::atomic<int> pw_stage{0};     // 1 = register staging instead of direct-to-LDS loads
     std::atomic<int> conv_variant{0}; // conv1 kernel variant
     std::atomic<int> misc{0};
+    std::atomic<int> dwpw_variant{0}; // fused block kernel: 0 = shipped choice per shape, 1 = round-1 producer/consumer kernel, 2 = unified-wave kernel,
+                                      // 3 = unified with the taps read inside the step, 100 + bits = unified with parts switched off (ablation)
     std::atomic<int> net_stagger{2};  // layers by which consecutive sub-batch streams are staggered (mbn_net_set_streams)
 };
 extern mbn_tunables g_mbn_tune;
@@ -113,6 +115,10 @@ int mbn_launch_f32_dwpw(mbn_context *ctx, hipStream_t stream, float *out, const 
                         const float *s2, const float *b2, const float *wp, const float *s3, const float *b3, int batch,
                         int in_rows, int in_cols, int out_rows, int out_cols, int cin, int cout, int stride, int pad_top,
                         int pad_left);
+int mbn_launch_f32_dwpw2(mbn_context *ctx, hipStream_t stream, float *out, const float *in, const float *wd,
+                         const float *s2, const float *b2, const float *wp, const float *s3, const float *b3, int batch,
+                         int in_rows, int in_cols, int out_rows, int out_cols, int cin, int cout, int stride, int pad_top,
+                         int pad_left);
 int mbn_bf16_dwpw_check(const void *out, const void *in, const float *wd, const float *s2, const float *b2, const void *wp,
                         const float *s3, const float *b3, int batch, int in_rows, int in_cols, int out_rows, int out_cols,
                         int cin, int cout, int stride, int pad_top, int pad_left);
