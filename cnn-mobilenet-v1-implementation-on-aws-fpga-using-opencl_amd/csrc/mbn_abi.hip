@@ -719,6 +719,10 @@ int mbn_dwpw_fused_bf16(mbn_context *ctx, void *out, const void *in, const void 
               { out, 2.0 * batch * out_rows * out_cols * cout, "dwpw output" }, { wd, 36.0 * cin, "dwpw depthwise filter" },
               { wp_bf16, 2.0 * cin * cout, "dwpw pointwise filter" });
     Scope sc(ctx, s);
+    if (g_mbn_tune.dwpw_variant != 1)      // unified-wave kernel (mbn_bf16_dwpw2.hip); 1 = the round-1 producer/consumer kernel (A/B hook)
+        return sc.finish(mbn_launch_bf16_dwpw2(ctx, s, out, in, (const float *)wd, (const float *)s2, (const float *)b2, wp_bf16,
+                                               (const float *)s3, (const float *)b3, batch, in_rows, in_cols, out_rows, out_cols,
+                                               cin, cout, stride, pad_top, pad_left));
     return sc.finish(mbn_launch_bf16_dwpw(ctx, s, out, in, (const float *)wd, (const float *)s2, (const float *)b2, wp_bf16,
                                           (const float *)s3, (const float *)b3, batch, in_rows, in_cols, out_rows, out_cols,
                                           cin, cout, stride, pad_top, pad_left));

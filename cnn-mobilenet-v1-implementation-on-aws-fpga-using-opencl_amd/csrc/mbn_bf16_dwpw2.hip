@@ -1,0 +1,342 @@
+// mbn_bf16_dwpw2.hip — fused depthwise 3x3 -> pointwise 1x1 block in the network's bf16 mode (BASELINE config 5),
+// UNIFIED-WAVE form (round 2): the bf16 counterpart of mbn_f32_dwpw2.hip and the replacement of the producer/consumer
+// kernel of mbn_bf16_dwpw.hip. Activations and the pointwise filter are bf16, all arithmetic is fp32, every layer output
+// is rounded to bf16 (RNE) — including the depthwise output, which only ever exists in LDS. Replaces a `depthwise` +
+// `pointwise` launch pair of the reference's sequence (kernel.cl:62-92 + 94-114; pairs L4-5 ... L26-27, MobileNet.c:322-2599).
+//
+// In bf16 the matrix work is a sixteenth of the fp32 kernel's (v_mfma_f32_32x32x16_bf16), so a block is bound by HBM and
+// by the depthwise VALU work (widening 12-15 packed vectors, 72 packed FMAs, BN + ReLU6, rounding: ~230 instructions per
+// lane per 64-channel chunk). What the round-1 kernel lost is latency: its producers drained vmcnt(0) in front of every
+// barrier, i.e. the x-window prefetch for the next chunk never overlapped anything (0.15 ms for block 14-15 against
+// 0.12 ms for the two separate launches and a 0.034 ms HBM floor). Here, as in the fp32 unified kernel: 8 waves, every
+// wave produces its 1/8 of the chunk (2 pixels x 8 channels per lane) AND multiplies its 64x64 / 32x64 tile; x-window
+// loads are issued one chunk ahead and stay in flight across the barrier (counted s_waitcnt vmcnt(NX): only the filter
+// chunk's LDS-DMA has to have landed); one barrier per chunk. A K chunk is 64 channels, so LDS rows are 128 bytes and the
+// LDS image, swizzle and fragment reads are byte-for-byte those of pw_gemm<__bf16>.
+// Result vs the two separate bf16 launches: the same bf16 x bf16 products accumulated in fp32 in a different order, i.e.
+// within the bf16 tolerance of the parity tests, not bit-identical.
+#include "mbn_internal.h"
+#include "mbn_epilogue.h"
+
+namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f8 __attribute__((ext_vector_type(8)));
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef mbn_f16v f16v;
+
+constexpr int BM = 128, BKF = 32;              // LDS rows are 128 bytes = 32 words = 64 bf16
+constexpr int NW = 8, NT = 64 * NW;            // 8 waves: 2 per SIMD, 256 VGPRs each
+constexpr int CMAX = 1024;                     // largest Cin (depthwise constants resident in LDS: 44 KB)
+constexpr unsigned OOB = 0xF0000000u;          // byte offset beyond any supported tensor: the load returns zeros
+
+struct DwPw2Args {
+    __bf16 *out;
+    const __bf16 *in, *wp;
+    const float *wd, *s2, *b2, *s3, *b3;
+    long m;                 // output pixels = batch * ho * wo
+    int h, w, ho, wo;       // input / output map sides
+    int cin, cout;
+    int pad_top, pad_left;
+    int mt, nt;
+    unsigned in_bytes, wp_bytes;
+    int dbg;                // experiments (tune misc): 1 = no x loads after the first, 2 = no depthwise math, 4 = no output stores, 8 = no filter DMA, 16 = no MFMA
+    unsigned wo_m, wo_s, ho_m, ho_s;   // floor(v / wo) = umulhi(v, wo_m) >> wo_s for v < 2^31 (m == 0: the divisor is 1)
+};
+
+__device__ __forceinline__ int swz(int row, int chunk) { return (row << 5) + (((chunk ^ (row >> 1)) & 7) << 2); }
+__device__ __forceinline__ f8 widen8(u4v p)
+{
+    f8 r;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        r[2 * i] = __builtin_bit_cast(float, p[i] << 16);
+        r[2 * i + 1] = __builtin_bit_cast(float, p[i] & 0xffff0000u);
+    }
+    return r;
+}
+__device__ __forceinline__ f8 ld8(const float *p)
+{
+    const f4 a = *reinterpret_cast<const f4 *>(p), b = *reinterpret_cast<const f4 *>(p + 4);
+    return f8{ a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w };
+}
+__device__ __forceinline__ int xcd_remap(int vb, int nwg)
+{
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = vb & 7;
+    return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (vb >> 3);
+}
+
+// Workgroup barrier with the waits spelled out. __syncthreads() is a workgroup-scope fence over every address space: with
+// global loads in flight for the NEXT chunk the waitcnt pass drains them (s_waitcnt vmcnt(0)) in front of every barrier
+// (also with the "local"-only fence form), which serialises the prefetch with the hand-over. Here: wait until all but
+// the VM_LEFT youngest vector-memory operations are done (= the LDS-DMA of the filter chunk has landed, the x-window
+// loads issued after it may still fly), until this wave's own LDS writes are done (lgkmcnt(0)), then s_barrier. The asm
+// is volatile with a memory clobber, so the compiler moves no LDS or global access across it.
+template <int VM_LEFT>
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(VM_LEFT) : "memory");
+}
+
+// pointwise filter chunk -> LDS, buffer form (a __device__ function: see mbn_f32_pw.hip lds_dma_rows)
+template <int B_LD>
+__device__ __forceinline__ void dma_filter(__amdgpu_buffer_rsrc_t rsrc, float *lds_b, const unsigned *voff, int soff, int wave_u)
+{
+#pragma unroll
+    for (int p = 0; p < B_LD; p++)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(lds_b + (p * (NT / 8) + wave_u * 8) * BKF),
+                                                 16, voff[p], soff, 0, 0);
+}
+
+template <int S, int BN>
+__global__ __launch_bounds__(NT) void dwpw2_bf16(DwPw2Args a)
+{
+    constexpr int WN = 64, WM = BN == 256 ? 64 : 32;   // wave tile: 8 waves as 2 x 4 (BN 256) or 4 x 2 (BN 128)
+    constexpr int WAVES_N = BN / WN;
+    static_assert((BM / WM) * WAVES_N == NW, "8 waves");
+    constexpr int MI = WM / 32, NI = WN / 32;
+    constexpr int B_LD = BN * 8 / NT;                  // 16-B filter pieces per lane per chunk (2 / 4)
+    constexpr int XC = S + 3;                          // input columns feeding 2 adjacent output pixels
+    constexpr int NX = 3 * XC;                         // buffer loads per lane per chunk
+    constexpr int ABUF = BM * BKF, BBUF = BN * BKF;
+    __shared__ __attribute__((aligned(16))) float lds[2 * ABUF + 2 * BBUF + 11 * CMAX];
+    float *const a_s0 = lds, *const b_s0 = lds + 2 * ABUF, *const wd_s = b_s0 + 2 * BBUF, *const sb_s = wd_s + 9 * CMAX;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nk = a.cin / 64, nwg = a.mt * a.nt;
+    const unsigned mtot = (unsigned)a.m;
+
+    for (int i = tid * 4; i < 9 * a.cin; i += NT * 4) *reinterpret_cast<f4 *>(wd_s + i) = *reinterpret_cast<const f4 *>(a.wd + i);
+    for (int i = tid * 4; i < a.cin; i += NT * 4) {
+        *reinterpret_cast<f4 *>(sb_s + i) = *reinterpret_cast<const f4 *>(a.s2 + i);
+        *reinterpret_cast<f4 *>(sb_s + a.cin + i) = *reinterpret_cast<const f4 *>(a.b2 + i);
+    }
+    __syncthreads();
+    if ((int)blockIdx.x >= nwg) return;
+
+    // ---- roles of this lane
+    const int c4 = tid & 7, pair = tid >> 3;                        // depthwise: tile rows 2*pair, 2*pair+1, channels 8*c4..+7 of the chunk
+    const int wm = (wave_u / WAVES_N) * WM, wn = (wave_u % WAVES_N) * WN;      // MFMA tile origin inside the workgroup tile
+    const int li = lane & 31, lh = lane >> 5;
+    const __amdgpu_buffer_rsrc_t irsrc = mbn_make_rsrc(a.in, a.in_bytes);
+    const __amdgpu_buffer_rsrc_t wrsrc = mbn_make_rsrc(a.wp, a.wp_bytes);
+    const __amdgpu_buffer_rsrc_t orsrc = mbn_make_rsrc(a.out, (unsigned)(a.m * a.cout * 2));
+    const int aw0 = swz(2 * pair, c4), aw1 = swz(2 * pair + 1, c4);           // A-tile slots this lane writes
+    int fr_a[4], fr_b[4];                                                       // fragment slots this lane reads
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        fr_a[g] = swz(wm + li, 2 * g + lh);
+        fr_b[g] = swz(wn + li, 2 * g + lh);
+    }
+    unsigned b_vo[B_LD];                                                        // filter piece offsets: fixed for the kernel, the tile's
+#pragma unroll                                                                  // column origin and the chunk go into the scalar offset
+    for (int p = 0; p < B_LD; p++) {
+        const int row = (p * NT + tid) >> 3;
+        // channel-paired column blocks (mbn_epilogue.h): LDS filter row `row` holds output channel mbn_pair_channel(row)
+        b_vo[p] = ((unsigned)mbn_pair_channel(row) * (unsigned)a.cin + (unsigned)(((c4 ^ (row >> 1)) & 7) * 8)) * 2u;
+    }
+    const float *wk = wd_s + c4 * 8;                                           // depthwise taps of this lane's 8 channels (+ kc*64 + tap*cin)
+    const float *sk = sb_s + c4 * 8;
+
+    unsigned off[3][XC];
+    auto set_offsets = [&](unsigned m0) __attribute__((always_inline)) {
+        const unsigned m = m0 + 2 * pair;
+        const bool mok = m < mtot;
+        const unsigned q = a.wo_m ? __umulhi(m, a.wo_m) >> a.wo_s : m;
+        const unsigned x = m - q * (unsigned)a.wo;
+        const unsigned n = a.ho_m ? __umulhi(q, a.ho_m) >> a.ho_s : q;
+        const unsigned y = q - n * (unsigned)a.ho;
+        const int iy0 = (int)y * S - a.pad_top, ix0 = (int)x * S - a.pad_left;
+        const unsigned cs = (unsigned)a.cin * 2u, rs = (unsigned)a.w * cs;                    // column / row stride in bytes
+        const unsigned base = ((n * a.h + iy0) * a.w + ix0) * cs + (unsigned)(c4 * 8) * 2u;         // wraps for taps that are masked out below
+#pragma unroll
+        for (int dy = 0; dy < 3; dy++) {
+            const bool rok = mok && (unsigned)(iy0 + dy) < (unsigned)a.h;
+#pragma unroll
+            for (int j = 0; j < XC; j++) {
+                const bool ok = rok && (unsigned)(ix0 + j) < (unsigned)a.w;
+                off[dy][j] = ok ? base + dy * rs + j * cs : OOB;
+            }
+        }
+    };
+    u4v xr[3][XC];                                                            // the window stays packed (4 VGPRs per vector)
+    auto ldx = [&](int kc) __attribute__((always_inline)) {
+#pragma unroll
+        for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+            for (int j = 0; j < XC; j++)
+                xr[dy][j] = __builtin_amdgcn_raw_buffer_load_b128(irsrc, off[dy][j], kc * 128, 0);
+    };
+    // depthwise + BN + ReLU6 of the chunk in xr into A buffer `buf`, rounded to bf16 (the layer output); the window is
+    // widened one row at a time, each vector once; taps and scale/shift come from LDS (fp32)
+    auto dw = [&](int kc, const int buf) __attribute__((always_inline)) {
+        f8 acc0, acc1;
+#pragma unroll
+        for (int i = 0; i < 8; i++) acc0[i] = acc1[i] = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < 3; dy++) {
+            f8 row[XC];
+#pragma unroll
+            for (int j = 0; j < XC; j++) row[j] = widen8(xr[dy][j]);
+#pragma unroll
+            for (int dx = 0; dx < 3; dx++) {
+                const f8 w = ld8(wk + kc * 64 + (dy * 3 + dx) * a.cin);
+                acc0 = __builtin_elementwise_fma(row[dx], w, acc0);
+                acc1 = __builtin_elementwise_fma(row[dx + S], w, acc1);
+            }
+        }
+        const f8 sc = ld8(sk + kc * 64), sh = ld8(sk + a.cin + kc * 64);
+        bf8 o0, o1;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            o0[i] = (__bf16)fminf(fmaxf(fmaf(acc0[i], sc[i], sh[i]), 0.f), 6.f);
+            o1[i] = (__bf16)fminf(fmaxf(fmaf(acc1[i], sc[i], sh[i]), 0.f), 6.f);
+        }
+        *reinterpret_cast<bf8 *>(a_s0 + buf * ABUF + aw0) = o0;
+        *reinterpret_cast<bf8 *>(a_s0 + buf * ABUF + aw1) = o1;
+    };
+
+    f16v acc[MI][NI];
+    f4 fa[2][MI], fb[2][NI];
+    auto ldfrag = [&](const int buf, int g, int slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int mi = 0; mi < MI; mi++) fa[slot][mi] = *reinterpret_cast<const f4 *>(a_s0 + buf * ABUF + fr_a[g] + mi * 32 * BKF);
+#pragma unroll
+        for (int ni = 0; ni < NI; ni++) fb[slot][ni] = *reinterpret_cast<const f4 *>(b_s0 + buf * BBUF + fr_b[g] + ni * 32 * BKF);
+    };
+    auto mfma_group = [&](int slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+            for (int ni = 0; ni < NI; ni++)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, fa[slot][mi]), __builtin_bit_cast(bf8, fb[slot][ni]),
+                                                                      acc[mi][ni], 0, 0, 0);
+    };
+    auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+            for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[mi][ni][r] = 0.f;
+    };
+
+    // ---- three cursors over the flattened (tile, chunk) sequence of this workgroup: L (x loads) one chunk ahead of
+    //      D (depthwise + filter DMA) one chunk ahead of M (MFMA). A cursor = (virtual block id, chunk, tile origin).
+    int vbM, kM, n0M; unsigned m0M;
+    int vbD, kD, n0D; unsigned m0D;
+    bool validD;
+    auto origin = [&](int vb, unsigned &m0, int &n0) __attribute__((always_inline)) {
+        const int lid = xcd_remap(vb, nwg);
+        n0 = (lid % a.nt) * BN;
+        m0 = (unsigned)(lid / a.nt) * BM;
+    };
+
+    // prologue: L(0), D(0) into buffer 0, L(1)
+    vbM = blockIdx.x; kM = 0;
+    origin(vbM, m0M, n0M);
+    set_offsets(m0M);
+    ldx(0);
+    dma_filter<B_LD>(wrsrc, b_s0, b_vo, (n0M * a.cin + 0) * 2, wave_u);
+    dw(0, 0);
+    // D cursor = successor of M
+    vbD = vbM; kD = 1; m0D = m0M; n0D = n0M; validD = true;
+    if (kD >= nk) {
+        kD = 0; vbD += gridDim.x; validD = vbD < nwg;
+        if (validD) { origin(vbD, m0D, n0D); set_offsets(m0D); }
+    }
+    if (validD) {
+        ldx(kD);
+    }
+    zero_acc();
+    if (validD) lds_barrier<NX>();        // filter chunk 0 landed; the NX newer loads may fly
+    else lds_barrier<0>();
+
+    // One chunk step with the MFMA chunk in buffer P (a literal at both call sites).
+    // Returns false when the sequence is finished.
+#define MBN_DWPW2_STEP(P)                                                                                               \
+    {                                                                                                                   \
+        ldfrag(P, 0, 0);                                                                                                \
+        bool validL = false;                                                                                            \
+        int vbL = vbD, kL = kD + 1, n0L = n0D;                                                                          \
+        unsigned m0L = m0D;                                                                                             \
+        if (validD) {                                                                                                   \
+            if (!(a.dbg & 8)) dma_filter<B_LD>(wrsrc, b_s0 + (P ^ 1) * BBUF, b_vo, (n0D * a.cin + kD * 64) * 2, wave_u); \
+            if (!(a.dbg & 2)) dw(kD, P ^ 1);                                                                            \
+            validL = true;                                                                                              \
+            if (kL >= nk) {                                                                                             \
+                kL = 0; vbL += gridDim.x; validL = vbL < nwg;                                                           \
+                if (validL) { origin(vbL, m0L, n0L); set_offsets(m0L); }                                                \
+            }                                                                                                           \
+            if (validL && !(a.dbg & 1)) ldx(kL);                                                                        \
+        }                                                                                                               \
+        if (!(a.dbg & 16)) {                                                                                            \
+        _Pragma("unroll") for (int g = 0; g < 3; g++) {                                                                 \
+            ldfrag(P, g + 1, (g + 1) & 1);                                                                              \
+            __builtin_amdgcn_sched_barrier(0);                                                                          \
+            mfma_group(g & 1);                                                                                          \
+            __builtin_amdgcn_sched_barrier(0);                                                                          \
+        }                                                                                                               \
+        mfma_group(1);                                                                                                  \
+        }                                                                                                               \
+        if (validL) lds_barrier<NX>();                                                                                  \
+        else lds_barrier<0>();                                                                                          \
+        if (kM == nk - 1 && !(a.dbg & 4)) {                                                                             \
+            if (m0M + BM <= mtot) mbn_store_relu6_bf16_pair<MI, NI, 0>(orsrc, (unsigned)a.cout, m0M + wm, n0M + wn, lane, acc, a.s3, a.b3); \
+            else mbn_store_relu6_bf16_pair<MI, NI, 1>(orsrc, (unsigned)a.cout, m0M + wm, n0M + wn, lane, acc, a.s3, a.b3);               \
+            zero_acc();                                                                                                 \
+        }                                                                                                               \
+        if (!validD) break;                                                                                             \
+        vbM = vbD; kM = kD; m0M = m0D; n0M = n0D;                                                                       \
+        vbD = vbL; kD = kL; m0D = m0L; n0D = n0L; validD = validL;                                                      \
+    }
+
+    for (;;) {
+        MBN_DWPW2_STEP(0)
+        MBN_DWPW2_STEP(1)
+    }
+#undef MBN_DWPW2_STEP
+}
+
+template <int S, int BN>
+void launch2(DwPw2Args &a, hipStream_t s, int num_cus)
+{
+    a.mt = (int)((a.m + BM - 1) / BM);
+    a.nt = a.cout / BN;
+    const long nwg = (long)a.mt * a.nt;
+    long grid = num_cus;
+    if (grid > nwg) grid = nwg;
+    hipLaunchKernelGGL((dwpw2_bf16<S, BN>), dim3((unsigned)grid), dim3(NT), 0, s, a);
+}
+
+}   // namespace
+
+// Unified-wave form of mbn_launch_bf16_dwpw (same envelope: mbn_bf16_dwpw_check has been passed by the caller).
+int mbn_launch_bf16_dwpw2(mbn_context *ctx, hipStream_t stream, void *out, const void *in, const float *wd, const float *s2,
+                          const float *b2, const void *wp, const float *s3, const float *b3, int batch, int in_rows,
+                          int in_cols, int out_rows, int out_cols, int cin, int cout, int stride, int pad_top, int pad_left)
+{
+    DwPw2Args a;
+    a.out = (__bf16 *)out; a.in = (const __bf16 *)in; a.wp = (const __bf16 *)wp;
+    a.wd = wd; a.s2 = s2; a.b2 = b2; a.s3 = s3; a.b3 = b3;
+    a.m = (long)batch * out_rows * out_cols;
+    a.h = in_rows; a.w = in_cols; a.ho = out_rows; a.wo = out_cols;
+    a.cin = cin; a.cout = cout; a.pad_top = pad_top; a.pad_left = pad_left;
+    mbn_udiv_magic((unsigned)out_cols, &a.wo_m, &a.wo_s);
+    mbn_udiv_magic((unsigned)out_rows, &a.ho_m, &a.ho_s);
+    const int variant = g_mbn_tune.dwpw_variant;
+    a.in_bytes = (unsigned)(2.0 * batch * in_rows * in_cols * cin);
+    a.wp_bytes = (unsigned)(2.0 * cin * cout);
+    a.dbg = variant >= 100 ? variant - 100 : 0;
+    const bool wide = (cout % 256) == 0 && g_mbn_tune.pw_tile != 1;      // pw_tile=1: force the 128-column tile (A/B hook)
+    if (stride == 1) {
+        if (wide) launch2<1, 256>(a, stream, ctx->num_cus);
+        else launch2<1, 128>(a, stream, ctx->num_cus);
+    } else {
+        if (wide) launch2<2, 256>(a, stream, ctx->num_cus);
+        else launch2<2, 128>(a, stream, ctx->num_cus);
+    }
+    return MBN_OK;
+}

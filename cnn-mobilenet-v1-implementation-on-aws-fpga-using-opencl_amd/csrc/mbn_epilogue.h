@@ -53,3 +53,43 @@ __device__ __forceinline__ void mbn_store_relu6_f32(__amdgpu_buffer_rsrc_t out, 
             }
     }
 }
+
+// bf16 output with CHANNEL-PAIRED column blocks. A bf16 kernel stages its filter rows into LDS in the order
+//   LDS row rho of a 64-column group  <-  output channel 2*(rho & 31) + (rho >> 5)   (mbn_pair_channel below),
+// so lane l's accumulators of the two 32x32 blocks of a group (ni = 2t, 2t+1) are the ADJACENT channels 2*(l&31) and
+// 2*(l&31)+1 of the same pixel rows: they round and pack into one dword and a store instruction writes 128 contiguous
+// bytes per pixel row (32 lanes x 4 B), two rows per instruction — 8*MI*NI buffer_store_dword per wave instead of
+// 16*MI*NI buffer_store_short with 64-byte rows. Measured alternatives (profiles/r02): the transposed product with one
+// 16-byte store per lane (every lane a different pixel row) is 20 % SLOWER than the 2-byte stores on the 512->512 GEMM and
+// 2.5x slower on the 16->32 layer — the memory pipeline wants contiguity ACROSS lanes, not width per lane.
+// NI must be even. MODE 0: block inside the matrix; MODE 1: rows may run past m (descriptor range check).
+__device__ __forceinline__ int mbn_pair_channel(int rho) { return (rho & ~63) | (2 * (rho & 31) + ((rho >> 5) & 1)); }
+
+template <int MI, int NI, int MODE>
+__device__ __forceinline__ void mbn_store_relu6_bf16_pair(__amdgpu_buffer_rsrc_t out, unsigned ldc, unsigned row0, int col0, int lane,
+                                                          const mbn_f16v (&acc)[MI][NI], const float *__restrict__ scale,
+                                                          const float *__restrict__ shift)
+{
+    static_assert((NI & 1) == 0, "channel-paired epilogue needs an even number of 32-column blocks");
+    typedef float f2e __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf2e __attribute__((ext_vector_type(2)));
+    const int li = lane & 31, lh = lane >> 5;
+    const unsigned lane_off = ((unsigned)(4 * lh) * ldc + (unsigned)(2 * li)) * 2u;        // bytes
+#pragma unroll
+    for (int t = 0; t < NI / 2; t++) {
+        const f2e sc = *reinterpret_cast<const f2e *>(scale + col0 + 64 * t + 2 * li);
+        const f2e sh = *reinterpret_cast<const f2e *>(shift + col0 + 64 * t + 2 * li);
+#pragma unroll
+        for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const unsigned ro = row0 + mi * 32 + (r & 3) + 8 * (r >> 2);               // + 4*lh per lane
+                const float v0 = fminf(fmaxf(fmaf(acc[mi][2 * t][r], sc.x, sh.x), 0.f), 6.f);
+                const float v1 = fminf(fmaxf(fmaf(acc[mi][2 * t + 1][r], sc.y, sh.y), 0.f), 6.f);
+                const unsigned v = __builtin_bit_cast(unsigned, bf2e{ (__bf16)v0, (__bf16)v1 });   // RNE (v_cvt_pk_bf16_f32)
+                const unsigned soff = (ro * ldc + (unsigned)(col0 + 64 * t)) * 2u;         // wave-uniform bytes
+                if (MODE == 0) __builtin_amdgcn_raw_buffer_store_b32(v, out, lane_off, soff, 0);
+                else __builtin_amdgcn_raw_buffer_store_b32(v, out, lane_off + soff, 0, 0);
+            }
+    }
+}

@@ -87,6 +87,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void pw_gemm(PwArgs a)
     constexpr int WAVES_N = BN / WN;
     constexpr int NT = 64 * (BM / WM) * WAVES_N;              // threads per workgroup
     constexpr int MI = WM / 32, NI = WN / 32;
+    constexpr bool PAIRN = BF && (NI % 2) == 0;               // bf16: channel-paired column blocks (mbn_epilogue.h): LDS filter row rho <- channel mbn_pair_channel(rho)
     constexpr int A_LD = BM * 8 / NT, B_LD = BN * 8 / NT;     // 16-B loads per thread per k-tile
     constexpr int ST = A_LD > B_LD ? A_LD : B_LD;
     static_assert(A_LD >= 1 && B_LD >= 1 && A_LD * NT == BM * 8 && B_LD * NT == BN * 8, "tile/threads mismatch");
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void pw_gemm(PwArgs a)
         }
 #pragma unroll
         for (int p = 0; p < B_LD; p++) {
-            int gn = n0 + st_row[p];
+            int gn = n0 + (PAIRN ? mbn_pair_channel(st_row[p]) : st_row[p]);
             if (gn >= a.n) gn = a.n - 1;
             if (GLDS && a.loop2) b_vo[p] = ((unsigned)gn * (unsigned)a.k + ((st_ch ^ (st_row[p] >> 1)) & 7) * EPC) * (unsigned)sizeof(T);
             else b_src[p] = gfilt + (long)gn * a.k + (GLDS ? ((st_ch ^ (st_row[p] >> 1)) & 7) : st_ch) * EPC;
@@ -349,12 +350,40 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void pw_gemm(PwArgs a)
         }
 
         // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-        // One fp32 store instruction writes two 128-B row segments (full cache lines).
+        // fp32: one store instruction writes two 128-B row segments (full cache lines). bf16 with an even number of column
+        // blocks per wave (PAIRN): the filter rows were staged channel-paired, so blocks 2t and 2t+1 hold adjacent channels
+        // and mbn_store_relu6_bf16_pair writes the same two 128-B segments per instruction with packed pairs.
         if (!(BF && a.out_f32) && a.act == MBN_ACT_RELU6 && a.scale && a.shift && cm0 + BM <= a.m && cn0 + BN <= a.n &&
-            g_fast_epilogue) {
+            g_fast_epilogue && (!PAIRN || (a.n & 1) == 0)) {
             // interior tile of a BN + ReLU6 layer (every pointwise layer of the network): lean stores, mbn_epilogue.h
-            mbn_store_relu6_f32<MI, NI, 0, T>(orsrc, (unsigned)a.n, (unsigned)cm0 + wm_u, cn0 + wn_u, lane, acc, a.scale,
-                                              a.shift, (unsigned)a.m, a.n);
+            if constexpr (PAIRN)
+                mbn_store_relu6_bf16_pair<MI, NI, 0>(orsrc, (unsigned)a.n, (unsigned)cm0 + wm_u, cn0 + wn_u, lane, acc, a.scale, a.shift);
+            else
+                mbn_store_relu6_f32<MI, NI, 0, T>(orsrc, (unsigned)a.n, (unsigned)cm0 + wm_u, cn0 + wn_u, lane, acc, a.scale,
+                                                  a.shift, (unsigned)a.m, a.n);
+        } else if constexpr (PAIRN) {
+            // element-wise path on the channel-paired layout (ragged tiles, the FC layer's fp32 logits, no BN): rare and small
+#pragma unroll
+            for (int ni = 0; ni < NI; ni++) {
+                const int col = cn0 + wn + (ni >> 1) * 64 + 2 * li + (ni & 1);
+                const bool cok = col < a.n;
+                const int cc = cok ? col : a.n - 1;
+                const float sc = a.scale ? a.scale[cc] : 1.f;
+                const float sh = a.shift ? a.shift[cc] : 0.f;
+#pragma unroll
+                for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const long row = cm0 + wm + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        float v = fmaf(acc[mi][ni][r], sc, sh);
+                        if (a.act == MBN_ACT_RELU6) v = fminf(fmaxf(v, 0.f), 6.f);
+                        else if (a.act == MBN_ACT_RELU) v = fmaxf(v, 0.f);
+                        if (cok && row < a.m) {
+                            if (a.out_f32) reinterpret_cast<float *>(a.out)[row * a.n + col] = v;
+                            else reinterpret_cast<__bf16 *>(a.out)[row * a.n + col] = (__bf16)v;
+                        }
+                    }
+            }
         } else
 #pragma unroll
         for (int ni = 0; ni < NI; ni++) {
@@ -472,7 +501,10 @@ int mbn_launch_f32_pointwise(const mbn_call &c, void *out, const void *in, const
     const int cus = c.ctx->num_cus;
     if (bf) {                                                              // bf16: the three shipped shapes only
         switch (tile) {
-        case 3: launch_cfg<__bf16, 64, 64, 32, 32>(a, c.stream, cus); break;
+        case 3:                                                                  // small problems
+            if (op_size >= 128) launch_cfg<__bf16, 64, 128, 32, 64>(a, c.stream, cus);   // 4 waves of 32x64: even NI, channel-paired 4-byte stores
+            else launch_cfg<__bf16, 64, 64, 32, 32>(a, c.stream, cus);                  // narrow outputs (alpha < 1 early layers): a 128-column tile would idle
+            break;
         case 5: launch_cfg<__bf16, 128, 128, 32, 64>(a, c.stream, cus); break;
         case 7: launch_cfg<__bf16, 128, 64, 32, 32>(a, c.stream, cus); break;    // 8 waves of 32x32, 48 KB LDS: 3 WG = 24 waves per CU
         case 8: launch_cfg<__bf16, 64, 128, 32, 32>(a, c.stream, cus); break;

@@ -125,6 +125,9 @@ int mbn_bf16_dwpw_check(const void *out, const void *in, const float *wd, const 
 int mbn_launch_bf16_dwpw(mbn_context *ctx, hipStream_t stream, void *out, const void *in, const float *wd, const float *s2,
                          const float *b2, const void *wp, const float *s3, const float *b3, int batch, int in_rows,
                          int in_cols, int out_rows, int out_cols, int cin, int cout, int stride, int pad_top, int pad_left);
+int mbn_launch_bf16_dwpw2(mbn_context *ctx, hipStream_t stream, void *out, const void *in, const float *wd, const float *s2,
+                          const float *b2, const void *wp, const float *s3, const float *b3, int batch, int in_rows,
+                          int in_cols, int out_rows, int out_cols, int cin, int cout, int stride, int pad_top, int pad_left);
 int mbn_launch_f32_stem(mbn_context *ctx, hipStream_t stream, float *out, const float *in, const float *w1,
                         const float *s1, const float *b1, const float *wd, const float *s2, const float *b2,
                         const float *wp, const float *s3, const float *b3, int batch, int res, int c1, int c3, int in_u8, int bf16);

@@ -27,6 +27,7 @@ struct mbn_net {
     int fuse_stem;             /* mbn_net_set_fuse_stem (default 1) */
     int input_u8;              /* mbn_net_set_input_u8: images are raw uint8 HWC */
     unsigned fuse_blocks;      /* mbn_net_set_fuse_blocks: bit L = run the depthwise layer L and the pointwise layer L+1 as one launch */
+    int fuse_blocks_set;       /* the caller chose a mask; otherwise the default of the current dtype applies */
     int use_graph;             /* mbn_net_set_graph */
     void *graph;               /* instantiated hipGraph of one forward, valid for the key below */
     const void *g_images;
@@ -195,6 +196,13 @@ int mbn_net_fused_layers(const mbn_net *net, int last_layer, int *count)
     return MBN_OK;
 }
 
+/* the mask in force: the caller's, or the measured default of the current dtype (mbn.h) */
+static unsigned fuse_mask(const mbn_net *net)
+{
+    if (net->fuse_blocks_set) return net->fuse_blocks;
+    return net->dtype == MBN_DT_BF16 ? MBN_FUSE_BLOCKS_DEFAULT_BF16 : MBN_FUSE_BLOCKS_DEFAULT;
+}
+
 /* layers i+1 (depthwise) and i+2 (pointwise), 0-based index i, can go through mbn_dwpw_fused for `count` images: fp32,
  * nothing kept, enabled in the mask, and inside the kernel's envelope (mbn.h: mbn_dwpw_fused) */
 static int block_fusable(const mbn_net *net, int i, int count, int last_layer)
@@ -202,7 +210,10 @@ static int block_fusable(const mbn_net *net, int i, int count, int last_layer)
     const int bf = net->dtype == MBN_DT_BF16;
     if ((net->dtype != MBN_DT_F32 && !bf) || net->keep || i + 2 > last_layer || i + 1 >= net->plan.n_layers || i + 1 >= 32) return 0;
     if (bf && (!net->bf16_filt[i + 1] || (net->plan.layer[i].in_ch % 64) != 0)) return 0;
-    if (!((net->fuse_blocks >> (i + 1)) & 1u)) return 0;
+    if (!((fuse_mask(net) >> (i + 1)) & 1u)) return 0;
+    /* bf16 default: the block kernel recomputes the depthwise chunk once per 256-column tile and is bound by that VALU work,
+     * so a block wider than one tile measures slower fused than as two launches; an explicit mask overrides */
+    if (bf && !net->fuse_blocks_set && net->plan.layer[i + 1].out_ch > 256) return 0;
     if (((uintptr_t)net->dev_blob % 16) != 0) return 0;            /* see stem_fusable */
     const mbn_layer_desc *d = &net->plan.layer[i], *p = &net->plan.layer[i + 1];
     if (d->kind != MBN_L_DW || p->kind != MBN_L_PW || (d->stride != 1 && d->stride != 2)) return 0;
@@ -235,15 +246,16 @@ int mbn_net_set_input_u8(mbn_net *net, int enabled)
 int mbn_net_set_fuse_blocks(mbn_net *net, unsigned mask)
 {
     if (!net) return MBN_EINVAL;
-    if (net->fuse_blocks != mask) drop_graph(net);
+    if (fuse_mask(net) != mask) drop_graph(net);
     net->fuse_blocks = mask;
+    net->fuse_blocks_set = 1;
     return MBN_OK;
 }
 
 int mbn_net_get_fuse_blocks(const mbn_net *net, unsigned *mask)
 {
     if (!net || !mask) return MBN_EINVAL;
-    *mask = net->fuse_blocks;
+    *mask = fuse_mask(net);
     return MBN_OK;
 }
 

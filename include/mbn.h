@@ -408,9 +408,15 @@ int  mbn_net_set_input_u8(mbn_net *net, int enabled);
 int  mbn_net_fused_layers(const mbn_net *net, int last_layer, int *count);
 /* Fused depthwise->pointwise blocks (mbn_dwpw_fused): bit L of `mask` (L = 1-based number of a depthwise layer) lets
  * layers L and L+1 run as one launch when the plan is fp32, activations are not kept and the shapes are inside the
- * kernel's envelope. Default MBN_FUSE_BLOCKS_DEFAULT = the blocks measured faster fused at batch 256 on MI355X
- * (DESIGN.md); 0 = every layer its own launch. Results are bit-identical either way. */
+ * kernel's envelope. Default (until this is called) = MBN_FUSE_BLOCKS_DEFAULT in fp32, MBN_FUSE_BLOCKS_DEFAULT_BF16 in bf16
+ * mode: the blocks measured faster fused at batch 256 / 512 on MI355X; 0 = every layer its own launch. fp32
+ * results are bit-identical either way. */
 #define MBN_FUSE_BLOCKS_DEFAULT ((1u << 4) | (1u << 6) | (1u << 8) | (1u << 10))
+/* bf16 mode: the matrix work is a sixteenth of fp32's and a block is bound by HBM and the depthwise VALU work: one launch
+ * that never writes the depthwise output wins on every block inside the kernel's envelope whose pointwise layer is at
+ * most 256 channels wide (one column tile: no depthwise recompute); wider blocks stay two launches under this default
+ * and can be forced with an explicit mask. */
+#define MBN_FUSE_BLOCKS_DEFAULT_BF16 0x0FFFFFFEu
 int  mbn_net_set_fuse_blocks(mbn_net *net, unsigned mask);
 int  mbn_net_get_fuse_blocks(const mbn_net *net, unsigned *mask);
 /* The launches the next forward(batch, last_layer) issues per (sub-)batch: launch j covers n_layers[j] layers starting
