@@ -50,6 +50,7 @@ struct PwArgs {
     int out_f32;    // bf16 mode: write fp32 (FC logits)
     int fast_epi;   // 0 = always the general epilogue (A/B hook: tune conv_variant=9)
     int loop2;      // 1 = software-pipelined k-loop (default); 0 = plain loop (A/B hook: tune conv_variant=8)
+    int xn;         // XCD groups along n (1, 2 or 4): > 1 when the filter does not fit an XCD's L2 next to the streamed A panels
 };
 
 constexpr int BKB = 128;            // k-tile in BYTES per row (32 fp32 / 64 bf16)
@@ -122,10 +123,28 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void pw_gemm(PwArgs a)
     f4 a_reg[A_LD], b_reg[B_LD];
     const f4 zero4 = f4{ 0.f, 0.f, 0.f, 0.f };
 
+    // Tile order. xn == 1: same-XCD workgroups (vb % 8) walk a contiguous range of tiles with the n-tile index fastest, so an
+    // A row-panel is fetched once per XCD while the WHOLE filter is swept per panel — fine while the filter (N x K) fits the
+    // XCD's 4 MB L2 beside the panels. xn > 1 (2 MB filters and up: the 7x7 layers): the 8 XCDs form (8 / xn) x xn groups; a
+    // group owns an m-range AND an n-range, i.e. a filter slice of N/xn rows that stays L2-resident for the group's whole
+    // share, at the price of each A panel being fetched by xn XCDs. Round 1 measured 4.5x the algorithmic bytes on layer 27
+    // (reads 7.8x) with the single ordering: the 4 MB filter was re-fetched per sweep. Which XCD a block lands on is a
+    // speed assumption only (round-robin dispatch); the mapping is a bijection for any placement.
+    const int xm = 8 / a.xn;
     auto set_tile = [&](int vb, long &m0, int &n0) {
-        const int lid = xcd_remap(vb, nwg);
-        n0 = (lid % a.nt) * BN;
-        m0 = (long)(lid / a.nt) * BM;
+        int mtile, ntile;
+        if (a.xn > 1) {
+            const int x = vb & 7, j = vb >> 3, gm = x / a.xn, gn = x % a.xn;
+            const int mlo = (int)((long)a.mt * gm / xm), nlo = a.nt * gn / a.xn, nn = a.nt * (gn + 1) / a.xn - nlo;
+            mtile = mlo + j / nn;
+            ntile = nlo + j % nn;
+        } else {
+            const int lid = xcd_remap(vb, nwg);
+            mtile = lid / a.nt;
+            ntile = lid % a.nt;
+        }
+        n0 = ntile * BN;
+        m0 = (long)mtile * BM;
 #pragma unroll
         for (int p = 0; p < A_LD; p++) {
             long gm = m0 + st_row[p];
@@ -194,7 +213,14 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void pw_gemm(PwArgs a)
     long m0;
     int n0;
     int vb = blockIdx.x;
-    if (vb >= nwg) return;
+    // xn > 1: this block's XCD group has (its m-tiles) x (its n-tiles) tiles, walked by j = vb >> 3 (gridDim is a multiple of 8)
+    int vb_end = nwg;
+    if (a.xn > 1) {
+        const int x = vb & 7, gm = x / a.xn, gn = x % a.xn;
+        const int cnt = (int)((long)a.mt * (gm + 1) / xm - (long)a.mt * gm / xm) * (a.nt * (gn + 1) / a.xn - a.nt * gn / a.xn);
+        vb_end = (cnt << 3) + x;                 // vb = 8 j + x < 8 cnt + x  <=>  j < cnt
+    }
+    if (vb >= vb_end) return;
     set_tile(vb, m0, n0);
     if (GLDS) { if (a.loop2) stage_glds2(0, 0); else stage_glds(0, 0); }
     else stage_load(0);
@@ -342,7 +368,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void pw_gemm(PwArgs a)
         const long cm0 = m0;
         const int cn0 = n0;
         const int nvb = vb + gridDim.x;
-        const bool more = nvb < nwg;
+        const bool more = nvb < vb_end;
         if (more) {
             set_tile(nvb, m0, n0);
             if (GLDS) { if (a.loop2) stage_glds2(0, 0); else stage_glds(0, 0); }      // both buffers are free after the K loop's last barrier
@@ -449,6 +475,17 @@ void launch_cfg(PwArgs &a, hipStream_t s, int num_cus)
     long grid_l = (long)num_cus * per_cu;
     // a single-k-tile problem (layer 3 in fp32) is a pure streaming kernel: one tile per workgroup measured faster
     if (grid_l > nwg || g_mbn_tune.misc >= 1000 || nbuf == 1) grid_l = nwg;
+    // n-split across XCD groups (see set_tile): only with a persistent grid that is a multiple of 8 and enough tiles per group
+    a.xn = 1;
+    {
+        const double filt_bytes = (double)a.n * a.k * sizeof(T);
+        // measured (profiles/r02/c_gemm_xcd_groups.txt): layer 27 fp32 (4 MB filter) FETCH_SIZE 207 -> 105 MiB raw with 2 groups,
+        // same time (MFMA-bound); layer 25 fp32 and both layers in bf16 (filters of 2 MB and less) fetch MORE with 2 groups
+        // (25 -> 29, 52 -> 63 MiB) and bf16 runs 3 % slower: the n-split starts where the filter alone fills the L2
+        int xn = filt_bytes >= 16.0 * 1048576 ? 4 : filt_bytes >= 4.0 * 1048576 ? 2 : 1;
+        if (g_mbn_tune.pw_xn > 0) xn = g_mbn_tune.pw_xn;                  // A/B hook: 1, 2, 4 (1 = the single ordering)
+        if ((xn == 2 || xn == 4) && grid_l < nwg && (grid_l % 8) == 0 && a.nt >= xn && a.mt >= 8 / xn) a.xn = xn;
+    }
     const dim3 grid((unsigned)grid_l), block(NT);
     const bool kfull = (a.k % BKE) == 0;
     const bool glds = kfull && nbuf == 2 && g_mbn_tune.pw_stage != 1;   // pw_stage=1: register staging (A/B hook)

@@ -24,6 +24,9 @@ namespace {
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f16v __attribute__((ext_vector_type(16)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
 
 constexpr int TH = 8, TW = 16;                 // output tile (pixels of the 112x112 map)
 constexpr int CR = TH + 2, CC = TW + 2;        // conv1 region incl. the depthwise halo: 10 x 18
@@ -41,6 +44,9 @@ struct StemArgs {
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return (row << 5) + (((chunk ^ (row >> 1)) & 7) << 2); }
+// bf16 mode: A and B tiles hold bf16, 32 channels = 64-byte rows = four 16-byte slots; slot XOR (row>>2)&3 makes the
+// ds_read_b128 of 16 consecutive rows hit 16 distinct bank quads ((row&3)*4 + slot'). Returns the 4-byte-word offset.
+__device__ __forceinline__ int swzb(int row, int slot) { return (row << 4) + (((slot ^ (row >> 2)) & 3) << 2); }
 __device__ __forceinline__ float relu6(float v) { return fminf(fmaxf(v, 0.f), 6.f); }
 __device__ __forceinline__ f4 bn_relu6(f4 a, f4 s, f4 b)
 {
@@ -109,13 +115,18 @@ __global__ __launch_bounds__(256, 2) void stem_fused_f32(StemArgs a)   // 2 wave
 
     // ---- per-workgroup constants
     for (int i = tid * 4; i < 27 * C1; i += 1024) *reinterpret_cast<f4 *>(w1_s + i) = *reinterpret_cast<const f4 *>(a.w1 + i);
+    if (BF) {
+        // bf16 B tile [64][32] bf16, 64-byte rows; LDS row rho holds output channel 2*(rho&31) + (rho>>5) (channel-paired
+        // column blocks: lane l's two accumulators are the adjacent channels 2l, 2l+1 -> packed 4-byte stores, 128 B per pixel)
+        if (tid < C3 * 4) {
+            const int row = tid >> 2, slot = tid & 3, ch = 2 * (row & 31) + (row >> 5);
+            *reinterpret_cast<f4 *>(b_s + swzb(row, slot)) =
+                *reinterpret_cast<const f4 *>(reinterpret_cast<const __bf16 *>(a.wp) + ch * 32 + slot * 8);
+        }
+    } else
     for (int i = tid; i < C3 * 8; i += 256) {                             // pointwise filter [64][32] -> swizzled B tile
         const int row = i >> 3, ch = i & 7;
-        if (BF) {
-            typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
-            const bf4 w = *reinterpret_cast<const bf4 *>(reinterpret_cast<const __bf16 *>(a.wp) + row * 32 + ch * 4);
-            *reinterpret_cast<f4 *>(b_s + swz(row, ch)) = f4{ (float)w.x, (float)w.y, (float)w.z, (float)w.w };
-        } else *reinterpret_cast<f4 *>(b_s + swz(row, ch)) = *reinterpret_cast<const f4 *>(a.wp + row * 32 + ch * 4);
+        *reinterpret_cast<f4 *>(b_s + swz(row, ch)) = *reinterpret_cast<const f4 *>(a.wp + row * 32 + ch * 4);
     }
     if (tid < 4 * C1) {
         const float *src = tid < C1 ? a.s1 : tid < 2 * C1 ? a.b1 : tid < 3 * C1 ? a.s2 : a.b2;
@@ -126,7 +137,10 @@ __global__ __launch_bounds__(256, 2) void stem_fused_f32(StemArgs a)   // 2 wave
     for (int k = 0; k < 9; k++) wd[k] = *reinterpret_cast<const f4 *>(a.wd + k * C1 + c4 * 4);
     float s3[2], b3[2];
 #pragma unroll
-    for (int ni = 0; ni < 2; ni++) { s3[ni] = a.s3[ni * 32 + li]; b3[ni] = a.b3[ni * 32 + li]; }
+    for (int ni = 0; ni < 2; ni++) {                                      // bf16: accumulator ni of lane li is channel 2*li + ni
+        const int ch = BF ? 2 * li + ni : ni * 32 + li;
+        s3[ni] = a.s3[ch]; b3[ni] = a.b3[ch];
+    }
 
     f2 pf[NPF];
     if (blockIdx.x < a.ntiles) {
@@ -200,9 +214,11 @@ __global__ __launch_bounds__(256, 2) void stem_fused_f32(StemArgs a)   // 2 wave
             const f4 s2 = *reinterpret_cast<const f4 *>(sb_s + 2 * C1 + c4 * 4), b2 = *reinterpret_cast<const f4 *>(sb_s + 3 * C1 + c4 * 4);
 #pragma unroll
             for (int p = 0; p < 4; p++) {
-                f4 v = bn_relu6(acc[p], s2, b2);
-                if (BF) v = rbf4(v);
-                *reinterpret_cast<f4 *>(a_s + swz(cy * TW + cx + p, c4)) = v;
+                const f4 v = bn_relu6(acc[p], s2, b2);
+                if (BF) {                                                 // the layer output, rounded to bf16 (RNE): 8 bytes per lane
+                    const int row = cy * TW + cx + p;
+                    *reinterpret_cast<bf4 *>(a_s + swzb(row, c4 >> 1) + 2 * (c4 & 1)) = bf4{ (__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w };
+                } else *reinterpret_cast<f4 *>(a_s + swz(cy * TW + cx + p, c4)) = v;
             }
         }
         __syncthreads();
@@ -213,6 +229,30 @@ __global__ __launch_bounds__(256, 2) void stem_fused_f32(StemArgs a)   // 2 wave
         for (int ni = 0; ni < 2; ni++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[ni][r] = 0.f;
+        if constexpr (BF) {
+            // bf16 mode: both operands ARE bf16 (the depthwise output was rounded above, the filter is the bf16 copy), so the
+            // 32-deep product is 2 v_mfma_f32_32x32x16_bf16 per column block instead of 16 fp32 MFMAs: 4 x 32 cycles per wave and
+            // tile instead of 32 x 64 — the fp32 form made the bf16 stem SLOWER per image than the fp32 stem
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                const f4 av = *reinterpret_cast<const f4 *>(a_s + swzb(wave * 32 + li, 2 * ks + lh));
+#pragma unroll
+                for (int ni = 0; ni < 2; ni++) {
+                    const f4 bv = *reinterpret_cast<const f4 *>(b_s + swzb(ni * 32 + li, 2 * ks + lh));
+                    acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, av), __builtin_bit_cast(bf8, bv), acc[ni], 0, 0, 0);
+                }
+            }
+            // channel-paired store: lane li holds channels 2li (acc[0]) and 2li+1 (acc[1]) of pixel row q: one dword per row,
+            // 32 lanes = the pixel's whole 128-byte line
+            unsigned *obase = reinterpret_cast<unsigned *>(reinterpret_cast<__bf16 *>(a.out) + ((n * a.h + TH * ty) * a.h + TW * tx) * C3) + li;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int q = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int y = q >> 4, x = q & 15;
+                const float v0 = relu6(fmaf(acc[0][r], s3[0], b3[0])), v1 = relu6(fmaf(acc[1][r], s3[1], b3[1]));
+                obase[((long)y * a.h + x) * (C3 / 2)] = __builtin_bit_cast(unsigned, bf2{ (__bf16)v0, (__bf16)v1 });
+            }
+        } else {
 #pragma unroll
         for (int g = 0; g < 4; g++) {
             const int chunk = 2 * g + lh;
@@ -232,10 +272,9 @@ __global__ __launch_bounds__(256, 2) void stem_fused_f32(StemArgs a)   // 2 wave
             for (int r = 0; r < 16; r++) {
                 const int q = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 const int y = q >> 4, x = q & 15;
-                const float v = relu6(fmaf(acc[ni][r], s3[ni], b3[ni]));
-                if (BF) reinterpret_cast<__bf16 *>(a.out)[(((n * a.h + TH * ty) * a.h + TW * tx) + (long)y * a.h + x) * C3 + ni * 32 + li] = (__bf16)v;
-                else obase[((long)y * a.h + x) * C3 + ni * 32 + li] = v;
+                obase[((long)y * a.h + x) * C3 + ni * 32 + li] = relu6(fmaf(acc[ni][r], s3[ni], b3[ni]));
             }
+        }
         // No barrier here: the next tile's B writes c1_s (last read in C, one barrier ago) and its C writes a_s only after
         // the barrier that follows B, which every wave reaches after finishing the a_s reads above.
     }

@@ -57,6 +57,7 @@ struct mbn_tunables {
     std::atomic<int> pw_stage{0};     // 1 = register staging instead of direct-to-LDS loads
     std::atomic<int> conv_variant{0}; // conv1 kernel variant
     std::atomic<int> misc{0};
+    std::atomic<int> pw_xn{0};        // pointwise GEMM: XCD groups along n (0 = by filter size, 1 = off, 2, 4)
     std::atomic<int> dwpw_variant{0}; // fused block kernel: 0 = shipped choice per shape, 1 = round-1 producer/consumer kernel, 2 = unified-wave kernel,
                                       // 3 = unified with the taps read inside the step, 100 + bits = unified with parts switched off (ablation)
     std::atomic<int> net_stagger{2};  // layers by which consecutive sub-batch streams are staggered (mbn_net_set_streams)

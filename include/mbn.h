@@ -452,7 +452,10 @@ const char *mbn_version(void);
  *   dw_variant   depthwise: bits 0-1 = output columns per lane, bit 4 = lanes across all channels, bit 5 = bf16 with
  *                4-channel lanes
  *   dw_nseg      depthwise: row segments per image
- *   net_stagger  layers between the starts of consecutive sub-batch streams (mbn_net_set_streams) */
+ *   net_stagger  layers between the starts of consecutive sub-batch streams (mbn_net_set_streams)
+ *   pw_xn        pointwise GEMM tile order: XCD groups along n (0 = by filter size, 1 = single ordering, 2, 4)
+ *   dwpw_variant fused block kernel: 0 = shipped choice, 1 = round-1 producer/consumer kernels, 2 = unified-wave kernels,
+ *                3 = unified fp32 with the taps read inside the step, 100 + bits = unified with parts switched off */
 int  mbn_tune_set(const char *key, int value);
 int  mbn_tune_get(const char *key, int *value);
 
