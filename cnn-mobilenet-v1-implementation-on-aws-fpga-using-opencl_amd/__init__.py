@@ -97,6 +97,7 @@ def _declare_host(lib):
     lib.readSquezeNetKernel.argtypes = [C.c_void_p, C.c_int]
     lib.readSquezeNetKernel.restype = None
     lib.decode_image.argtypes = [C.c_void_p, C.c_char_p]
+    lib.mbn_shard_range.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     return lib
 
 
@@ -139,6 +140,14 @@ def load():
         lib.mbn_profile_end.argtypes = [vp, C.POINTER(C.c_float), ci, C.POINTER(ci)]
         lib.mbn_profile_pause.argtypes = [vp, ci]
         lib.mbn_mark.argtypes = [vp, vp]
+        lib.mbn_dist_init.argtypes = [ci, C.POINTER(ci), C.POINTER(vp)]
+        lib.mbn_dist_size.argtypes = [vp, C.POINTER(ci)]
+        lib.mbn_dist_context.argtypes = [vp, ci, C.POINTER(vp)]
+        lib.mbn_dist_broadcast.argtypes = [vp, C.POINTER(vp), C.c_size_t, ci]
+        lib.mbn_dist_sync.argtypes = [vp]
+        lib.mbn_dist_shutdown.argtypes = [vp]
+        lib.mbn_dist_last_error.restype = C.c_char_p
+        lib.mbn_dist_last_error.argtypes = [vp]
         lib.mbn_marks_read.argtypes = [vp, C.POINTER(C.c_float), ci, C.POINTER(ci)]
         ext = C.POINTER(LayerExt)
         lib.mbn_convolute.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ext]

@@ -50,7 +50,8 @@ struct DwPw2Args {
     int pad_top, pad_left;
     int mt, nt;
     unsigned in_bytes, wp_bytes;
-    int dbg;                // experiments (tune misc): 1 = no x loads after the first, 2 = no depthwise math, 4 = no output stores, 8 = no filter DMA, 16 = no MFMA
+    int dbg;                // experiments (tune dwpw_variant = 100 + bits): 1 = no x loads after the first, 2 = no depthwise math, 4 = no output stores,
+                            // 8 = no filter DMA, 16 = no MFMA, 32 = unpaired column blocks (4-byte stores)
     unsigned wo_m, wo_s, ho_m, ho_s;   // floor(v / wo) = umulhi(v, wo_m) >> wo_s for v < 2^31 (m == 0: the divisor is 1)
 };
 
@@ -129,11 +130,14 @@ __global__ __launch_bounds__(NT) void dwpw2_f32(DwPw2Args a)
         fr_a[g] = swz(wm + li, 2 * g + lh);
         fr_b[g] = swz(wn + li, 2 * g + lh);
     }
+    const bool paired = !(a.dbg & 32);
     unsigned b_vo[B_LD];                                                        // filter piece offsets: fixed for the kernel, the tile's
 #pragma unroll                                                                  // column origin and the chunk go into the scalar offset
     for (int p = 0; p < B_LD; p++) {
         const int row = (p * NT + tid) >> 3;
-        b_vo[p] = ((unsigned)row * (unsigned)a.cin + (unsigned)(((c4 ^ (row >> 1)) & 7) * 4)) * 4u;
+        // channel-paired column blocks (mbn_epilogue.h): LDS filter row `row` holds output channel mbn_pair_channel(row), so the
+        // epilogue stores 8 bytes per lane, 256 contiguous bytes per pixel row; `pair` = a.dbg bit 5 switches it off (A/B)
+        b_vo[p] = ((unsigned)(paired ? mbn_pair_channel(row) : row) * (unsigned)a.cin + (unsigned)(((c4 ^ (row >> 1)) & 7) * 4)) * 4u;
     }
     const float *wk = wd_s + c4 * 4;                                           // depthwise taps of this lane's 4 channels (+ kc*32 + tap*cin)
     const float *sk = sb_s + c4 * 4;
@@ -279,7 +283,10 @@ __global__ __launch_bounds__(NT) void dwpw2_f32(DwPw2Args a)
         if (validL) lds_barrier<NX>();                                                                                  \
         else lds_barrier<0>();                                                                                          \
         if (kM == nk - 1 && !(a.dbg & 4)) {                                                                             \
-            if (m0M + BM <= mtot) mbn_store_relu6_f32<MI, NI, 0>(orsrc, (unsigned)a.cout, m0M + wm, n0M + wn, lane, acc, a.s3, a.b3, mtot, a.cout); \
+            if (paired) {                                                                                               \
+                if (m0M + BM <= mtot) mbn_store_relu6_f32_pair<MI, NI, 0>(orsrc, (unsigned)a.cout, m0M + wm, n0M + wn, lane, acc, a.s3, a.b3); \
+                else mbn_store_relu6_f32_pair<MI, NI, 1>(orsrc, (unsigned)a.cout, m0M + wm, n0M + wn, lane, acc, a.s3, a.b3);               \
+            } else if (m0M + BM <= mtot) mbn_store_relu6_f32<MI, NI, 0>(orsrc, (unsigned)a.cout, m0M + wm, n0M + wn, lane, acc, a.s3, a.b3, mtot, a.cout); \
             else mbn_store_relu6_f32<MI, NI, 1>(orsrc, (unsigned)a.cout, m0M + wm, n0M + wn, lane, acc, a.s3, a.b3, mtot, a.cout);               \
             zero_acc();                                                                                                 \
         }                                                                                                               \

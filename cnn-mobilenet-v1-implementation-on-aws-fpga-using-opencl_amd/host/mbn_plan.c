@@ -117,3 +117,14 @@ int mbn_plan_build(float alpha, int res, int classes, mbn_plan *plan)
     plan->max_act_floats = max_act;
     return MBN_OK;
 }
+
+/* Batch sharding of the multi-GPU path: rank's contiguous slice of `total` independent images. Same
+ * arithmetic as dist.py shard_range (the torch.distributed form) — tested against each other. */
+int mbn_shard_range(int total, int world, int rank, int *first, int *count)
+{
+    if (!first || !count || world <= 0 || rank < 0 || rank >= world || total < 0) return MBN_EINVAL;
+    const int q = total / world, r = total % world;
+    *first = rank * q + (rank < r ? rank : r);
+    *count = q + (rank < r ? 1 : 0);
+    return MBN_OK;
+}

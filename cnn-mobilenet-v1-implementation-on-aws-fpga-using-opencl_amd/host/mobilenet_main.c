@@ -4,6 +4,7 @@
  *   mobilenet --h5 weights.h5 [--ppm image.ppm] [--batch N] [--res 224] [--alpha 1.0]      fp32 path
  *   mobilenet --synthetic SEED [--alpha A] [--res R] [--batch N]                              fp32, synthetic weights
  *   mobilenet --literal [--weights weights_c.txt] [--image Cat_Image0.ppm] [--ref-args]      the reference's own mode
+ *   mobilenet --gpus G --batch N [--steps K --warmup W] (--h5 F | --synthetic SEED)           N images sharded over G GPUs
  *   mobilenet --inspect weights.h5                                                             list the datasets of a .h5
  *   mobilenet --convert weights.h5 out.txt                                                     folded blob as text (one %.9g per line)
  *
@@ -14,10 +15,12 @@
  * Prints the same two kinds of line as the reference: per-layer kernel time (MobileNet.c:315) and the argmax
  * line (MobileNet.c:2792).
  */
+#include <pthread.h>
 #include <stdio.h>
 #include <unistd.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "mbn.h"
 
@@ -139,12 +142,133 @@ static int convert_h5(const char *path, const char *out)
     return 0;
 }
 
+/* ---------------------------------------------------------------------------------------------- --gpus G
+ * The multi-GPU form of the host (BASELINE config 4): the batch is cut into G contiguous shards
+ * (mbn_shard_range), GPU 0 receives the parameter blob from the host and ONE RCCL broadcast (mbn_dist_broadcast) hands it
+ * to the other GPUs over xGMI, then one host thread per GPU runs the identical single-GPU pipeline on its shard. No
+ * collective on the data path. Timing: W untimed steps, a thread barrier, K steps, device sync, barrier; the job's time
+ * is the slowest GPU's (MAX), images/s = K * N / that. The reference drives exactly one device (MobileNet.c:155). */
+typedef struct {
+    int rank, world, batch, first, count, res, steps, warmup;
+    mbn_dist *dist;
+    const mbn_plan *plan;
+    void *dev_blob;
+    pthread_barrier_t *bar;
+    double seconds;
+    int rc;
+    int top1;            /* class of this shard's first image */
+} gpu_job;
+
+static double now_s(void)
+{
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
+}
+
+static void *gpu_thread(void *arg)
+{
+    gpu_job *j = (gpu_job *)arg;
+    mbn_context *ctx = NULL;
+    mbn_net *net = NULL;
+    void *d_u8 = NULL, *d_logits = NULL, *d_idx = NULL, *d_prob = NULL;
+    unsigned char *u8 = NULL;
+    const int n = j->count > 0 ? j->count : 1;                 /* a rank without images still takes part in the barriers */
+    const size_t img = (size_t)j->res * j->res * 3;
+    int rc = mbn_dist_context(j->dist, j->rank, &ctx);
+    if (rc == MBN_OK) rc = mbn_net_create_from_device_blob(ctx, j->plan, j->dev_blob, n, &net);
+    if (rc == MBN_OK) rc = mbn_net_set_input_u8(net, 1);
+    if (rc == MBN_OK) rc = mbn_alloc(ctx, (size_t)n * img, &d_u8);
+    if (rc == MBN_OK) rc = mbn_alloc(ctx, (size_t)n * j->plan->classes * sizeof(float), &d_logits);
+    if (rc == MBN_OK) rc = mbn_alloc(ctx, sizeof(int) * (size_t)n, &d_idx);
+    if (rc == MBN_OK) rc = mbn_alloc(ctx, sizeof(float) * (size_t)n, &d_prob);
+    if (rc == MBN_OK && !(u8 = malloc((size_t)n * img))) rc = MBN_ENOMEM;
+    if (rc == MBN_OK) {
+        /* image i of the whole batch is generated from its GLOBAL index, so a shard sees the same pixels as the same
+         * images would in a single-GPU run (sharding property: concat of shards == the unsharded batch) */
+        for (int i = 0; i < n; i++) {
+            unsigned long long s = 0xC0FFEEULL + (unsigned long long)(j->first + i) * 0x9E3779B97F4A7C15ULL;
+            unsigned char *p = u8 + (size_t)i * img;
+            for (size_t k = 0; k < img; k++) { s = s * 6364136223846793005ULL + 1442695040888963407ULL; p[k] = (unsigned char)(s >> 56); }
+        }
+        rc = mbn_upload(ctx, d_u8, u8, (size_t)n * img);
+    }
+    for (int w = 0; rc == MBN_OK && w < j->warmup && j->count > 0; w++) rc = mbn_net_forward(net, d_u8, d_logits, n, 0);
+    if (rc == MBN_OK) rc = mbn_sync(ctx);
+    pthread_barrier_wait(j->bar);
+    const double t0 = now_s();
+    for (int k = 0; rc == MBN_OK && k < j->steps && j->count > 0; k++) rc = mbn_net_forward(net, d_u8, d_logits, n, 0);
+    if (rc == MBN_OK) rc = mbn_sync(ctx);
+    j->seconds = now_s() - t0;
+    pthread_barrier_wait(j->bar);
+    if (rc == MBN_OK && j->count > 0) {
+        int idx = -1;
+        rc = mbn_softmax_topk_f32(ctx, NULL, d_idx, d_prob, d_logits, n, j->plan->classes, 1, NULL);
+        if (rc == MBN_OK) rc = mbn_download(ctx, &idx, d_idx, sizeof(int));
+        j->top1 = idx + 1;
+    }
+    if (rc != MBN_OK) fprintf(stderr, "Error: GPU %d: %s (%s)\n", j->rank, mbn_strerror(rc), ctx ? mbn_last_device_error(ctx) : "");
+    if (net) mbn_net_destroy(net);
+    free(u8);
+    j->rc = rc;
+    return NULL;
+}
+
+static int run_multi(int gpus, int batch, int res, int steps, int warmup, const mbn_weights *w)
+{
+    mbn_context *ctx = NULL;                                    /* for CHECK's message */
+    mbn_dist *dist = NULL;
+    int rc = mbn_dist_init(gpus, NULL, &dist);
+    if (rc != MBN_OK) { fprintf(stderr, "Error: mbn_dist_init(%d) -> %s\n", gpus, mbn_strerror(rc)); return 1; }
+    const size_t blob_bytes = (size_t)w->plan.blob_floats * sizeof(float);
+    void **blobs = calloc((size_t)gpus, sizeof(void *));
+    gpu_job *jobs = calloc((size_t)gpus, sizeof(gpu_job));
+    pthread_t *th = calloc((size_t)gpus, sizeof(pthread_t));
+    if (!blobs || !jobs || !th) return 1;
+    for (int r = 0; r < gpus; r++) {
+        CHECK(mbn_dist_context(dist, r, &ctx));
+        CHECK(mbn_alloc(ctx, blob_bytes, &blobs[r]));
+    }
+    CHECK(mbn_dist_context(dist, 0, &ctx));
+    CHECK(mbn_upload(ctx, blobs[0], w->blob, blob_bytes));      /* host -> GPU 0 once ... */
+    rc = mbn_dist_broadcast(dist, blobs, blob_bytes, 0);         /* ... GPU 0 -> everybody over xGMI: the path's one collective */
+    if (rc != MBN_OK) { fprintf(stderr, "Error: mbn_dist_broadcast -> %s (%s)\n", mbn_strerror(rc), mbn_dist_last_error(dist)); return 1; }
+    pthread_barrier_t bar;
+    pthread_barrier_init(&bar, NULL, (unsigned)gpus);
+    for (int r = 0; r < gpus; r++) {
+        gpu_job *j = &jobs[r];
+        j->rank = r; j->world = gpus; j->batch = batch; j->res = res; j->steps = steps; j->warmup = warmup;
+        j->dist = dist; j->plan = &w->plan; j->dev_blob = blobs[r]; j->bar = &bar;
+        CHECK(mbn_shard_range(batch, gpus, r, &j->first, &j->count));
+        if (pthread_create(&th[r], NULL, gpu_thread, j) != 0) { fprintf(stderr, "Error: pthread_create\n"); return 1; }
+    }
+    double worst = 0.0;
+    int bad = 0;
+    for (int r = 0; r < gpus; r++) {
+        pthread_join(th[r], NULL);
+        if (jobs[r].rc != MBN_OK) bad = 1;
+        if (jobs[r].seconds > worst) worst = jobs[r].seconds;
+    }
+    pthread_barrier_destroy(&bar);
+    if (!bad) {
+        for (int r = 0; r < gpus; r++)
+            printf("GPU %d: images [%d, %d) %d steps in %.6f s; first image -> class %d\n", r, jobs[r].first,
+                   jobs[r].first + jobs[r].count, steps, jobs[r].seconds, jobs[r].top1);
+        printf("%d GPUs, batch %d (%s), %d steps: %.1f images/sec (slowest GPU %.6f s, %.3f ms/step)\n", gpus, batch,
+               "contiguous shards, weights broadcast once over RCCL", steps, (double)steps * batch / worst, worst,
+               1000.0 * worst / steps);
+    }
+    mbn_dist_shutdown(dist);                                    /* frees every buffer the contexts own */
+    free(blobs); free(jobs); free(th);
+    return bad;
+}
+
 int main(int argc, char **argv)
 {
     if (argc == 3 && !strcmp(argv[1], "--inspect")) return inspect_h5(argv[2]);
     if (argc == 4 && !strcmp(argv[1], "--convert")) return convert_h5(argv[2], argv[3]);
     const char *h5 = NULL, *ppm = NULL, *wfile = "weights_c.txt", *image = "Cat_Image0.ppm";
-    int literal = 0, ref_args = 0, batch = 1, res = 224, have_seed = 0;
+    int literal = 0, ref_args = 0, batch = 1, res = 224, have_seed = 0, gpus = 0, steps = 20, warmup = 3;
     unsigned long long seed = 0;
     float alpha = 0.f;
     for (int i = 1; i < argc; i++) {
@@ -156,15 +280,36 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[i], "--res") && i + 1 < argc) res = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--alpha") && i + 1 < argc) alpha = (float)atof(argv[++i]);
         else if (!strcmp(argv[i], "--synthetic") && i + 1 < argc) { seed = strtoull(argv[++i], NULL, 0); have_seed = 1; }
+        else if (!strcmp(argv[i], "--gpus") && i + 1 < argc) gpus = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--steps") && i + 1 < argc) steps = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--warmup") && i + 1 < argc) warmup = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--literal")) literal = 1;
         else if (!strcmp(argv[i], "--ref-args")) ref_args = 1;
         else {
-            fprintf(stderr, "usage: %s [--h5 F | --synthetic SEED | --literal] [--ppm F] [--batch N] [--res R] [--alpha A]\n",
-                    argv[0]);
+            fprintf(stderr, "usage: %s [--h5 F | --synthetic SEED | --literal] [--ppm F] [--batch N] [--res R] [--alpha A] "
+                            "[--gpus G [--steps K] [--warmup W]]\n", argv[0]);
             return 2;
         }
     }
     mbn_context *ctx = NULL;
+    if (gpus > 0 && !literal) {
+        if (batch < 1 || steps < 1 || warmup < 0) { fprintf(stderr, "bad --batch/--steps/--warmup\n"); return 2; }
+        char tmpm[] = "/tmp/mbn_synth_XXXXXX.h5";
+        if (!h5) {
+            if (!have_seed) { fprintf(stderr, "need --h5 or --synthetic with --gpus\n"); return 2; }
+            int tfd = mkstemps(tmpm, 3);
+            if (tfd < 0) { fprintf(stderr, "cannot create a temporary file in /tmp\n"); return 2; }
+            close(tfd);
+            CHECK(mbn_weights_synthetic_h5(tmpm, alpha > 0.f ? alpha : 1.0f, 1000, seed));
+            h5 = tmpm;
+        }
+        mbn_weights wm;
+        CHECK(mbn_weights_from_h5(h5, alpha, res, &wm));
+        if (h5 == tmpm) remove(tmpm);
+        int rc = run_multi(gpus, batch, res, steps, warmup, &wm);
+        mbn_weights_free(&wm);
+        return rc;
+    }
     printf("Initializing HIP device...\n");
     CHECK(mbn_init(0, &ctx));
     char name[128];

@@ -440,6 +440,30 @@ int  mbn_net_plan(const mbn_net *net, mbn_plan *plan);
 int  mbn_net_set_keep_activations(mbn_net *net, int keep);
 int  mbn_net_layer_output(mbn_net *net, int index, void **dptr, size_t *floats_per_image);
 
+/* ------------------------------------------------------------------ multi-GPU (north_star: "batched images
+ * shard naturally across the 8 GPUs of one node with an RCCL broadcast of weights over xGMI and no cross-GPU reduction").
+ * The reference takes exactly one device (MobileNet.c:155 clGetDeviceIDs(..., 1, &device_id, ...)); this is the form a C
+ * host uses to drive all GPUs of a node from one process, one thread per GPU:
+ *   mbn_dist_init       one mbn_context per GPU (device_ordinals NULL = 0..n-1) + an RCCL communicator over them
+ *                       (ncclCommInitAll; RCCL is bound with dlopen at this call, n_gpus = 1 needs none);
+ *   mbn_dist_context    rank r's context: every other call of this header works on it, from the thread that owns rank r;
+ *   mbn_dist_broadcast  dev_ptrs[r] = rank r's device buffer of `bytes` bytes; root's bytes overwrite the others' (one
+ *                       grouped ncclBroadcast on the ranks' context streams; returns when all ranks have it). The one
+ *                       collective of the path: the packed parameter blob, once, off the timed path;
+ *   mbn_dist_sync       mbn_sync on every rank;
+ *   mbn_shard_range     the contiguous slice [first, first+count) of `total` images owned by `rank` of `world`: total/world
+ *                       each, the first total%world ranks take one more (host arithmetic; also in libmbn_host.so).
+ * Contexts are independent, so per-GPU threads need no locking among themselves. */
+typedef struct mbn_dist mbn_dist;
+int  mbn_dist_init(int n_gpus, const int *device_ordinals, mbn_dist **dist);
+int  mbn_dist_size(const mbn_dist *dist, int *n_gpus);
+int  mbn_dist_context(mbn_dist *dist, int rank, mbn_context **ctx);
+int  mbn_dist_broadcast(mbn_dist *dist, void *const *dev_ptrs, size_t bytes, int root);
+int  mbn_dist_sync(mbn_dist *dist);
+int  mbn_dist_shutdown(mbn_dist *dist);
+const char *mbn_dist_last_error(const mbn_dist *dist);
+int  mbn_shard_range(int total, int world, int rank, int *first, int *count);
+
 const char *mbn_version(void);
 
 /* Tuning hooks, process-wide: select among built kernel variants / launch heuristics for A/B measurements

@@ -32,6 +32,24 @@ def test_shard_range(pkg):
         mdist.shard_range(8, 2, 2)
 
 
+def test_c_shard_range_matches_python(pkg):
+    """The C host's multi-GPU mode (mobilenet --gpus G, include/mbn.h mbn_shard_range) cuts the batch exactly like the
+    torch.distributed form (dist.py shard_range): contiguous, total/world each, the first total%world ranks one more."""
+    import ctypes as C
+    from mbn_amd_pkg import dist as mdist
+    lib = pkg.host_lib()
+    for total, world in ((2048, 8), (256, 1), (10, 3), (2, 4), (0, 2), (257, 8), (7, 7)):
+        for r in range(world):
+            f, c = C.c_int(), C.c_int()
+            assert lib.mbn_shard_range(total, world, r, C.byref(f), C.byref(c)) == 0
+            lo, hi = mdist.shard_range(total, world, r)
+            assert (f.value, f.value + c.value) == (lo, hi)
+    f, c = C.c_int(), C.c_int()
+    for bad in ((8, 2, 2), (8, 0, 0), (8, 2, -1), (-1, 2, 0)):
+        assert lib.mbn_shard_range(*bad, C.byref(f), C.byref(c)) == pkg.EINVAL
+    assert lib.mbn_shard_range(8, 2, 0, None, C.byref(c)) == pkg.EINVAL
+
+
 @pytest.mark.parametrize("world,total", [(2, 6), (3, 7)])
 def test_gloo_broadcast_and_sharded_forward(pkg, orc, tmp_path, world, total):
     env = dict(os.environ, OMP_NUM_THREADS="2")

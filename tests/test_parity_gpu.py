@@ -1162,3 +1162,45 @@ def test_step_markers(pkg, ctx):
     ms = ctx.marks_read(16)
     assert len(ms) == 4 and all(m >= 0 for m in ms)
     assert ctx.marks_read(16) == []
+
+
+def test_dist_single_gpu_path_and_c_host_gpus_mode(pkg, ctx, tmp_path):
+    """Multi-GPU from C, exercised on the one GPU this box has: mbn_dist_init(1) hands out a context
+    that behaves like mbn_init's, the broadcast is the identity for one rank, asking for more GPUs than exist is an error
+    code, and `mobilenet --gpus 1` runs the sharded-host code path end to end (the 8-GPU run is the driver's)."""
+    import re
+    import subprocess
+    lib = ctx.lib
+    d = C.c_void_p()
+    have = C.c_int()
+    assert lib.mbn_device_count(C.byref(have)) == 0 and have.value >= 1
+    assert lib.mbn_dist_init(have.value + 1, None, C.byref(d)) == pkg.ENODEVICE
+    assert lib.mbn_dist_init(0, None, C.byref(d)) == pkg.EINVAL
+    assert lib.mbn_dist_init(1, None, C.byref(d)) == 0
+    n = C.c_int()
+    assert lib.mbn_dist_size(d, C.byref(n)) == 0 and n.value == 1
+    c0 = C.c_void_p()
+    assert lib.mbn_dist_context(d, 0, C.byref(c0)) == 0 and lib.mbn_dist_context(d, 1, C.byref(c0)) == pkg.EINVAL
+    assert lib.mbn_dist_context(d, 0, C.byref(c0)) == 0
+    buf = C.c_void_p()
+    assert lib.mbn_alloc(c0, 4096, C.byref(buf)) == 0
+    x = np.arange(1024, dtype=np.float32)
+    assert lib.mbn_upload(c0, buf, x.ctypes.data, 4096) == 0
+    ptrs = (C.c_void_p * 1)(buf.value)
+    assert lib.mbn_dist_broadcast(d, ptrs, 4096, 0) == 0
+    assert lib.mbn_dist_broadcast(d, ptrs, 4096, 1) == pkg.EINVAL
+    y = np.empty_like(x)
+    assert lib.mbn_download(c0, y.ctypes.data, buf, 4096) == 0 and np.array_equal(x, y)
+    assert lib.mbn_dist_sync(d) == 0 and lib.mbn_dist_shutdown(d) == 0
+    exe = os.path.join(pkg.PKG_DIR, "mobilenet")
+    out = subprocess.run([exe, "--gpus", "1", "--batch", "5", "--synthetic", "3", "--alpha", "0.25", "--res", "96",
+                          "--steps", "3", "--warmup", "1"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    m = re.search(r"GPU 0: images \[0, 5\) 3 steps in ([0-9.]+) s; first image -> class (\d+)", out.stdout)
+    assert m and 1 <= int(m.group(2)) <= 1000, out.stdout
+    m = re.search(r"1 GPUs, batch 5 .* ([0-9.]+) images/sec", out.stdout)
+    assert m and float(m.group(1)) > 0, out.stdout
+    # asking the host for more GPUs than the box has fails cleanly
+    out = subprocess.run([exe, "--gpus", str(have.value + 1), "--batch", "8", "--synthetic", "3", "--alpha", "0.25", "--res", "64"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "mbn_dist_init" in out.stderr
