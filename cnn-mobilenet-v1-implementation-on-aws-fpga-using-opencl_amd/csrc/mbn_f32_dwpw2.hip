@@ -26,6 +26,11 @@
 // 32x64 wave tile): 4-8 % SLOWER on every block — 64 scattered 16-byte segments per store instruction cost more in the
 // memory pipeline than two full 128-byte lines. Ablation of one step (block 6-7, same file): without the epilogue
 // stores -13 %, without the x-window loads -13 %, without the depthwise math -7 %, without the filter DMA -4 %.
+// Also measured and rejected (profiles/r02/b_block_kernel_variants.txt, second part): issuing a finished tile's epilogue one
+// step later, behind the next step's filter DMA and x loads, so the counted wait in front of the barrier need not drain
+// the stores — the accumulators then stay live across the step (256 VGPRs in the 256-column variants) and every block
+// measured 3-7 % slower than with the epilogue right behind the barrier. The channel-paired 8-byte stores are neutral
+// in fp32 (within 1 %): the epilogue's cost is the burst itself, not the number of store instructions.
 // The loop is unrolled by two so the LDS buffer index is a literal in every address (the waitcnt pass then keeps the
 // LDS-DMA of buffer p^1 apart from the fragment reads of buffer p instead of draining vmcnt before each ds_read).
 #include "mbn_internal.h"
