@@ -65,6 +65,7 @@ static std::atomic<int> *tune_slot(const char *key)
     if (!strcmp(key, "net_stagger")) return &g_mbn_tune.net_stagger;
     if (!strcmp(key, "dwpw_variant")) return &g_mbn_tune.dwpw_variant;
     if (!strcmp(key, "pw_xn")) return &g_mbn_tune.pw_xn;
+    if (!strcmp(key, "pw_ring")) return &g_mbn_tune.pw_ring;
     return nullptr;
 }
 

@@ -523,6 +523,14 @@ int mbn_launch_f32_pointwise(const mbn_call &c, void *out, const void *in, const
         else hipLaunchKernelGGL(pw_generic<float>, grid, dim3(256), 0, c.stream, a);
         return MBN_OK;
     }
+    // bf16: the streaming ring kernel (mbn_bf16_pw_ring.hip) for K = 64, where the tiled GEMM has a single k-tile and no
+    // LDS-DMA pipeline at all (layer 5 at batch 512: 0.179 -> 0.117 ms); measured equal at K = 128 and 25-40 % SLOWER from
+    // K = 256 up (one 8-wave workgroup per CU hides the per-k-tile LDS-DMA issue cost and fragment latency worse than two
+    // 8-wave workgroups of the tiled kernel: profiles/r02/d_bf16_ring_gemm.txt). pw_ring: 1 = never, 2 = wherever eligible.
+    const int ring_mode = g_mbn_tune.pw_ring;
+    if (bf && ring_mode != 1 && (ring_mode == 2 || cin == 64) && g_mbn_tune.pw_tile == 0 &&
+        mbn_launch_bf16_pw_ring(c, out, in, filt, m, cin, op_size) == MBN_OK)
+        return MBN_OK;
     // Tile choice measured per layer on MI355X in fp32 with the software-pipelined loop (tools/layer_bench.py --tune
     // pw_tile=1..8, profiles/r01/e_gemm_tile_sweep_pipelined.txt): 64x64 tiles at 4 workgroups per CU are best from
     // K = 512 up and for K = 256 with wide outputs (133 TFLOP/s = 85 % of the fp32 matrix peak on the 512 -> 512 layers),

@@ -57,6 +57,7 @@ struct mbn_tunables {
     std::atomic<int> pw_stage{0};     // 1 = register staging instead of direct-to-LDS loads
     std::atomic<int> conv_variant{0}; // conv1 kernel variant
     std::atomic<int> misc{0};
+    std::atomic<int> pw_ring{0};      // bf16 pointwise: 0 = ring kernel for K = 64, 1 = always pw_gemm, 2 = ring wherever eligible
     std::atomic<int> pw_xn{0};        // pointwise GEMM: XCD groups along n (0 = by filter size, 1 = off, 2, 4)
     std::atomic<int> dwpw_variant{0}; // fused block kernel: 0 = shipped choice per shape, 1 = round-1 producer/consumer kernel, 2 = unified-wave kernel,
                                       // 3 = unified with the taps read inside the step, 100 + bits = unified with parts switched off (ablation)
@@ -97,6 +98,7 @@ int mbn_launch_f32_depthwise(const mbn_call &c, void *out, const void *in, const
                              int fs, int stride, int channels);
 int mbn_launch_f32_pointwise(const mbn_call &c, void *out, const void *in, const void *filt, long m, int cin,
                              int op_size);
+int mbn_launch_bf16_pw_ring(const mbn_call &c, void *out, const void *in, const void *filt, long m, int cin, int op_size);
 int mbn_launch_f32_pool(const mbn_call &c, void *out, const void *in, int rows, int cols, int fs, int channels);
 // floor(v / d) == umulhi(v, *m) >> *s for every v < 2^31 (d >= 2); d == 1 gives *m = 0 (callers skip the multiply)
 static inline void mbn_udiv_magic(unsigned d, unsigned *m, unsigned *s)

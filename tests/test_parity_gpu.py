@@ -1204,3 +1204,48 @@ def test_dist_single_gpu_path_and_c_host_gpus_mode(pkg, ctx, tmp_path):
     out = subprocess.run([exe, "--gpus", str(have.value + 1), "--batch", "8", "--synthetic", "3", "--alpha", "0.25", "--res", "64"],
                          capture_output=True, text=True, timeout=300)
     assert out.returncode != 0 and "mbn_dist_init" in out.stderr
+
+
+@pytest.mark.parametrize("shape", [(1000, 128, 256), (512, 64, 128), (3 * 3136, 64, 128), (2 * 784 + 5, 256, 256), (50176, 512, 512),
+                                   (8 * 49 * 4, 1024, 1024), (640, 192, 384)])
+def test_bf16_pointwise_ring_kernel(pkg, orc, ctx, shape):
+    """mbn_bf16_pw_ring.hip (4-slot LDS ring, three k-tiles in flight, counted vmcnt waits): against the oracle's bf16
+    emulation, against the tiled pw_gemm<bf16> (tune pw_ring=1) and with exact small integers (operand maps, channel
+    pairing, every slot of the ring: K/64 = 1, 2, 3, 4, 8, 16 k-tiles per tile; ragged last row tile; several tiles per
+    workgroup so the flattened sequence crosses tile boundaries)."""
+    m, cin, cout = shape
+    rng = np.random.default_rng(m + cin + cout)
+    x = orc.bf16_round(rng.uniform(-1, 1, (m, cin)))
+    f = orc.bf16_round(rng.normal(0, (2.0 / cin) ** 0.5, (cout, cin)))
+    sc, sh = rng.uniform(0.5, 1.5, cout).astype(np.float32), rng.normal(0, 0.1, cout).astype(np.float32)
+    d_x, d_f, d_sc, d_sh = _bf16_dev(pkg, ctx, x), _bf16_dev(pkg, ctx, f), ctx.to_device(sc), ctx.to_device(sh)
+    d_o, d_p = ctx.alloc(m * cout * 2), ctx.alloc(m * cout * 2)
+    ext = pkg.make_ext(dtype=pkg.DT_BF16, act=2, scale=d_sc.ptr, shift=d_sh.ptr)
+    try:
+        assert ctx.lib.mbn_tune_set(b"pw_ring", 2) == 0            # the ring kernel wherever the shape is eligible
+        ctx.pointwise(d_o.ptr, d_x.ptr, d_f.ptr, m, 1, cin, cout, ext)
+        assert ctx.lib.mbn_tune_set(b"pw_ring", 1) == 0            # never
+        ctx.pointwise(d_p.ptr, d_x.ptr, d_f.ptr, m, 1, cin, cout, ext)
+        assert ctx.lib.mbn_tune_set(b"pw_ring", 2) == 0
+    finally:
+        pass
+    ctx.sync()
+    got, tiled = _bf16_get(pkg, d_o, (m, cout)), _bf16_get(pkg, d_p, (m, cout))
+    if m * cin * cout <= 2e9:
+        ref = orc.bf16_round(orc.f32_pointwise(x, f, sc, sh, 2))
+        assert_close(got, ref, TOL_BF16, "ring %s vs oracle" % (shape,))
+    # both kernels add the same 64-wide k-groups of exact bf16 products in the same order: identical bits expected
+    assert np.array_equal(got, tiled), "ring vs tiled GEMM %s: max diff %g" % (shape, np.abs(got - tiled).max())
+    # exact integers with an asymmetric filter and identity BN: any slot / operand / channel-pair mix-up shows
+    xi = rng.integers(-3, 4, (m, cin)).astype(np.float32)
+    fi = rng.integers(-2, 3, (cout, cin)).astype(np.float32)
+    fi[:, 0] = np.arange(cout) % 5
+    one, zero = ctx.to_device(np.ones(cout, np.float32)), ctx.to_device(np.zeros(cout, np.float32))
+    d_x.upload(pkg.f32_to_bf16_bits(xi)); d_f.upload(pkg.f32_to_bf16_bits(fi))
+    try:
+        ctx.pointwise(d_o.ptr, d_x.ptr, d_f.ptr, m, 1, cin, cout, pkg.make_ext(dtype=pkg.DT_BF16, act=2, scale=one.ptr, shift=zero.ptr))
+    finally:
+        ctx.lib.mbn_tune_set(b"pw_ring", 0)
+    ctx.sync()
+    want = np.clip(xi[:4096].astype(np.float64) @ fi.astype(np.float64).T, 0, 6)
+    assert np.array_equal(_bf16_get(pkg, d_o, (m, cout))[:4096].astype(np.float64), orc.bf16_round(want.astype(np.float32)).astype(np.float64))
