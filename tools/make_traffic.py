@@ -17,7 +17,7 @@ import sys
 def per_dispatch(d, counter):
     f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
     rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter and
-            ("pw_gemm" in r["Kernel_Name"] or "dw3x3" in r["Kernel_Name"] or "conv3x3" in r["Kernel_Name"])]
+            ("pw_gemm" in r["Kernel_Name"] or "pw_ring" in r["Kernel_Name"] or "pw_generic" in r["Kernel_Name"] or "dw3x3" in r["Kernel_Name"] or "dw_generic" in r["Kernel_Name"] or "conv3x3" in r["Kernel_Name"])]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     return [(r["Kernel_Name"].split("(")[0][-60:], float(r["Counter_Value"])) for r in rows]
 
@@ -31,13 +31,35 @@ def combine():
                       "pointwise_layers": pw["layers"], "depthwise_layers": dw["layers"]}, indent=1))
 
 
+def assemble():
+    """make_traffic.py assemble <dir with {f32,bf16_1x224,bf16_0.5x160}_{pw,dw}.json> <git sha> > profiles/traffic.json
+    The fp32 section stays at the top level (bench.py's default line), the bf16 sections under their own keys."""
+    import datetime
+    d, sha = sys.argv[2], sys.argv[3]
+    cmd = "bash tools/r02_traffic.sh %s (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE --kernel-trace over tools/layer_bench.py --iters 3 --warmup 1)" % sha
+
+    def section(key, workload):
+        pw, dw = json.load(open("%s/%s_pw.json" % (d, key))), json.load(open("%s/%s_dw.json" % (d, key)))
+        return {"workload": workload, "method": pw["method"], "git_sha": sha, "command": cmd,
+                "date": datetime.date.today().isoformat(),
+                "pointwise_avg_bytes_per_launch": pw["avg_bytes_per_launch"],
+                "depthwise_avg_bytes_per_launch": dw["avg_bytes_per_launch"],
+                "pointwise_layers": pw["layers"], "depthwise_layers": dw["layers"]}
+    out = section("f32", "MobileNet-V1 1.0x224 fp32, batch 256 (tools/layer_bench.py), MI355X")
+    out["bf16_1x224"] = section("bf16_1x224", "MobileNet-V1 1.0x224 bf16, batch 512 (tools/layer_bench.py --dtype bf16), MI355X")
+    out["bf16_0.5x160"] = section("bf16_0.5x160", "MobileNet-V1 0.5x160 bf16, batch 512 (tools/layer_bench.py --dtype bf16 --alpha 0.5 --res 160), MI355X")
+    print(json.dumps(out, indent=1))
+
+
 def main():
     if sys.argv[1] == "combine":
         return combine()
+    if sys.argv[1] == "assemble":
+        return assemble()
     fdir, wdir, layers, per = sys.argv[1], sys.argv[2], [int(x) for x in sys.argv[3].split(",")], int(sys.argv[4])
     fe, wr = per_dispatch(fdir, "FETCH_SIZE"), per_dispatch(wdir, "WRITE_SIZE")
     assert len(fe) == len(wr) == per * len(layers), (len(fe), len(wr), per, len(layers))
-    out = {"method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over tools/layer_bench.py (batch 256); "
+    out = {"method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over tools/layer_bench.py; "
                      "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 half-count correction on reads)", "layers": {}}
     tot = 0.0
     for i, L in enumerate(layers):
