@@ -647,7 +647,7 @@ static int stem_fused_impl(mbn_context *ctx, void *out, const void *image, const
     if (!ctx || !out || !image) return MBN_EINVAL;
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     // decide before opening the profiling scope so an unsupported shape does not consume an event slot
-    if (c1 != 32 || c3 != 64 || res < 32 || (res % 32) != 0 || batch <= 0) return MBN_EUNSUPPORTED;
+    if (!((c1 == 32 && c3 == 64) || (c1 == 16 && c3 == 32)) || res < 32 || (res % 32) != 0 || batch <= 0) return MBN_EUNSUPPORTED;
     MBN_SPANS(ctx, { image, (in_u8 ? 1.0 : 4.0) * batch * res * res * 3, "stem image" },
               { out, (bf16 ? 2.0 : 4.0) * batch * (res / 2) * (res / 2) * c3, "stem output" });
     Scope sc(ctx, s);

@@ -16,7 +16,11 @@
 //   D. pointwise 32 -> 64 on v_mfma_f32_32x32x2_f32 (wave w owns rows 32w..32w+31, all 64 columns) + BN + ReLU6,
 //      stored as whole 128-byte lines.
 // The three filters and their scale/shift vectors stay in LDS / registers for the workgroup's lifetime.
-// Shapes: Cin 3, conv1 -> 32 channels, pointwise -> 64 channels (alpha = 1), input side a multiple of 32.
+// Shapes: Cin 3; conv1 -> C1, pointwise -> C3 with (C1, C3) = (32, 64) (alpha = 1) or (16, 32) (alpha = 0.5: BASELINE
+// config 5's 0.5x160, where the three layers were 40 % of the step as separate launches); input side a multiple of 32.
+// The kernel is a template over (C1, C3): with 16 channels a lane still owns 4 of them, so there are 4 channel quads per
+// pixel instead of 8 and every phase hands a lane half as many pixels (3 instead of 6 in conv1, 2 instead of 4 in the
+// depthwise) to keep all 256 lanes busy; A/B tile rows are 64 instead of 128 bytes (four 16-byte slots, their own swizzle).
 #include "mbn_internal.h"
 
 namespace {
@@ -32,7 +36,7 @@ constexpr int TH = 8, TW = 16;                 // output tile (pixels of the 112
 constexpr int CR = TH + 2, CC = TW + 2;        // conv1 region incl. the depthwise halo: 10 x 18
 constexpr int PR = 2 * CR + 1;                     // input patch: 21 rows x 37 pixels
 constexpr int PROW = 112;                      // floats per patch row in LDS (37*3 = 111, padded)
-constexpr int C1 = 32, C3 = 64;
+constexpr int PROWPAD = 4;                     // tail pad of the patch: the last lane's 16-byte reads run 2 floats past a row
 
 struct StemArgs {
     float *out;
@@ -43,10 +47,23 @@ struct StemArgs {
     unsigned ntiles;        // < 2^31 (launcher checks): tile indices stay 32-bit, the per-tile index math is scalar and cheap
 };
 
-__device__ __forceinline__ int swz(int row, int chunk) { return (row << 5) + (((chunk ^ (row >> 1)) & 7) << 2); }
+// fp32 A/B tiles [rows][C1]: 16-byte slots XOR-swizzled so the ds_read_b128 of 16 consecutive rows hit 16 distinct bank
+// quads. C1 = 32: 128-byte rows, 8 slots, slot ^ (row>>1); C1 = 16: 64-byte rows, 4 slots, slot ^ (row>>2).
+template <int C1>
+__device__ __forceinline__ int swz(int row, int chunk)
+{
+    if (C1 == 32) return (row << 5) + (((chunk ^ (row >> 1)) & 7) << 2);
+    return (row << 4) + (((chunk ^ (row >> 2)) & 3) << 2);
+}
 // bf16 mode: A and B tiles hold bf16, 32 channels = 64-byte rows = four 16-byte slots; slot XOR (row>>2)&3 makes the
 // ds_read_b128 of 16 consecutive rows hit 16 distinct bank quads ((row&3)*4 + slot'). Returns the 4-byte-word offset.
-__device__ __forceinline__ int swzb(int row, int slot) { return (row << 4) + (((slot ^ (row >> 2)) & 3) << 2); }
+// (C1 = 16: 32-byte rows, two slots, slot ^ (row>>3)&1: rows r and r+8 share a bank quad pair and take opposite halves.)
+template <int C1>
+__device__ __forceinline__ int swzb(int row, int slot)
+{
+    if (C1 == 32) return (row << 4) + (((slot ^ (row >> 2)) & 3) << 2);
+    return (row << 3) + (((slot ^ (row >> 3)) & 1) << 2);
+}
 __device__ __forceinline__ float relu6(float v) { return fminf(fmaxf(v, 0.f), 6.f); }
 __device__ __forceinline__ f4 bn_relu6(f4 a, f4 s, f4 b)
 {
@@ -100,10 +117,17 @@ __device__ __forceinline__ void patch_store(float *in_s, int tid, const f2 (&pf)
 __device__ __forceinline__ float rbf(float v) { return (float)(__bf16)v; }
 __device__ __forceinline__ f4 rbf4(f4 v) { return f4{ rbf(v.x), rbf(v.y), rbf(v.z), rbf(v.w) }; }
 
-template <bool BF>
+template <int C1, int C3, bool BF>
 __global__ __launch_bounds__(256, 2) void stem_fused_f32(StemArgs a)   // 2 waves/SIMD: two workgroups per CU
 {
-    __shared__ __attribute__((aligned(16))) float in_s[PR * PROW];        //  9.4 KB
+    constexpr int Q1 = C1 / 4;                     // channel quads per pixel (8 / 4)
+    constexpr int PB = 3 * Q1 / 4;                 // conv1 pixels per lane (6 / 3): CR * (CC / PB) * Q1 = 240 busy lanes
+    static_assert(CC % PB == 0 && CR * (CC / PB) * Q1 <= 256, "conv1 lane mapping");
+    constexpr int NXV = (3 * (2 * PB + 1) + 3) / 4;    // float4 reads covering the (2 PB + 1) input pixels x 3 channels of a row (10 / 6)
+    constexpr int PC = 128 * Q1 / 256;             // depthwise pixels per lane (4 / 2)
+    constexpr int NI = C3 / 32;                    // 32-column blocks of the pointwise output (2 / 1)
+    constexpr int KG = C1 / 8;                     // fp32 MFMA k-groups of 8 (4 / 2)
+    __shared__ __attribute__((aligned(16))) float in_s[PR * PROW + PROWPAD]; //  9.4 KB
     __shared__ __attribute__((aligned(16))) float w1_s[27 * C1];          //  3.4 KB
     __shared__ __attribute__((aligned(16))) float c1_s[CR * CC * C1];     // 22.5 KB
     __shared__ __attribute__((aligned(16))) float a_s[TH * TW * 32];      // 16 KB
@@ -111,22 +135,23 @@ __global__ __launch_bounds__(256, 2) void stem_fused_f32(StemArgs a)   // 2 wave
     __shared__ __attribute__((aligned(16))) float sb_s[4 * C1];           // s1 | b1 | s2 | b2
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
-    const int c4 = tid & 7;                                               // this lane's channel quad in phases B, C
+    const int c4 = tid % Q1;                                              // this lane's channel quad in phases B, C
 
     // ---- per-workgroup constants
     for (int i = tid * 4; i < 27 * C1; i += 1024) *reinterpret_cast<f4 *>(w1_s + i) = *reinterpret_cast<const f4 *>(a.w1 + i);
     if (BF) {
-        // bf16 B tile [64][32] bf16, 64-byte rows; LDS row rho holds output channel 2*(rho&31) + (rho>>5) (channel-paired
-        // column blocks: lane l's two accumulators are the adjacent channels 2l, 2l+1 -> packed 4-byte stores, 128 B per pixel)
-        if (tid < C3 * 4) {
-            const int row = tid >> 2, slot = tid & 3, ch = 2 * (row & 31) + (row >> 5);
-            *reinterpret_cast<f4 *>(b_s + swzb(row, slot)) =
-                *reinterpret_cast<const f4 *>(reinterpret_cast<const __bf16 *>(a.wp) + ch * 32 + slot * 8);
+        // bf16 B tile [C3][C1] bf16; with two column blocks (C3 = 64) LDS row rho holds output channel 2*(rho&31) + (rho>>5)
+        // (channel-paired column blocks: lane l's two accumulators are the adjacent channels 2l, 2l+1 -> packed 4-byte stores)
+        constexpr int SL = C1 / 8;                                        // 16-byte slots per row (4 / 2)
+        if (tid < C3 * SL) {
+            const int row = tid / SL, slot = tid % SL, ch = NI == 2 ? 2 * (row & 31) + (row >> 5) : row;
+            *reinterpret_cast<f4 *>(b_s + swzb<C1>(row, slot)) =
+                *reinterpret_cast<const f4 *>(reinterpret_cast<const __bf16 *>(a.wp) + ch * C1 + slot * 8);
         }
     } else
-    for (int i = tid; i < C3 * 8; i += 256) {                             // pointwise filter [64][32] -> swizzled B tile
-        const int row = i >> 3, ch = i & 7;
-        *reinterpret_cast<f4 *>(b_s + swz(row, ch)) = *reinterpret_cast<const f4 *>(a.wp + row * 32 + ch * 4);
+    for (int i = tid; i < C3 * Q1; i += 256) {                            // pointwise filter [C3][C1] -> swizzled B tile
+        const int row = i / Q1, ch = i % Q1;
+        *reinterpret_cast<f4 *>(b_s + swz<C1>(row, ch)) = *reinterpret_cast<const f4 *>(a.wp + row * C1 + ch * 4);
     }
     if (tid < 4 * C1) {
         const float *src = tid < C1 ? a.s1 : tid < 2 * C1 ? a.b1 : tid < 3 * C1 ? a.s2 : a.b2;
@@ -135,10 +160,10 @@ __global__ __launch_bounds__(256, 2) void stem_fused_f32(StemArgs a)   // 2 wave
     f4 wd[9];
 #pragma unroll
     for (int k = 0; k < 9; k++) wd[k] = *reinterpret_cast<const f4 *>(a.wd + k * C1 + c4 * 4);
-    float s3[2], b3[2];
+    float s3[NI], b3[NI];
 #pragma unroll
-    for (int ni = 0; ni < 2; ni++) {                                      // bf16: accumulator ni of lane li is channel 2*li + ni
-        const int ch = BF ? 2 * li + ni : ni * 32 + li;
+    for (int ni = 0; ni < NI; ni++) {                                     // bf16, two blocks: accumulator ni of lane li is channel 2*li + ni
+        const int ch = (BF && NI == 2) ? 2 * li + ni : ni * 32 + li;
         s3[ni] = a.s3[ch]; b3[ni] = a.b3[ch];
     }
 
@@ -149,10 +174,10 @@ __global__ __launch_bounds__(256, 2) void stem_fused_f32(StemArgs a)   // 2 wave
     }
     __syncthreads();
 
-    // phase B item of this lane: conv1 row br, pixels bc .. bc+5 (lanes 240..255 have none)
-    const int bpg = tid >> 3, br = bpg / 3, bc = (bpg % 3) * 6;
-    // phase C item: tile row cy, pixels cx .. cx+3
-    const int cy = tid >> 5, cx = ((tid >> 3) & 3) * 4;
+    // phase B item of this lane: conv1 row br, pixels bc .. bc+PB-1 (lanes 240..255 have none)
+    const int bpg = tid / Q1, br = bpg / (CC / PB), bc = (bpg % (CC / PB)) * PB;
+    // phase C item: tile row cy, pixels cx .. cx+PC-1
+    const int cy = (tid / Q1) / (TW / PC), cx = ((tid / Q1) % (TW / PC)) * PC;
 
     for (unsigned t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
         const int tx = (int)(t % (unsigned)a.tiles_x);
@@ -163,31 +188,43 @@ __global__ __launch_bounds__(256, 2) void stem_fused_f32(StemArgs a)   // 2 wave
         if (tnext < a.ntiles) patch_load(a, tnext, tid, pf);              // in flight while phase B computes
 
         // ---- B. conv1 (3x3x3, stride 2, pad 0 top/left) + BN + ReLU6 over the 10 x 18 region, 6 pixels x 4 ch per lane
-        if (bpg < CR * 3) {
-            f4 acc[6];
+        if (bpg < CR * (CC / PB)) {
+            f4 acc[PB];
 #pragma unroll
-            for (int p = 0; p < 6; p++) acc[p] = f4{ 0.f, 0.f, 0.f, 0.f };
+            for (int p = 0; p < PB; p++) acc[p] = f4{ 0.f, 0.f, 0.f, 0.f };
 #pragma unroll 1
             for (int ky = 0; ky < 3; ky++) {                              // not unrolled: keeps the live set small
-                const float *row = in_s + (2 * br + ky) * PROW + (2 * bc) * 3;    // 13 pixels x 3 channels (+1 pad float)
-                f4 xv[10];
+                const float *row = in_s + (2 * br + ky) * PROW + (2 * bc) * 3;    // 2 PB + 1 pixels x 3 channels (+ pad floats)
+                // the row segment starts at float 6*bc: a multiple of 16 bytes for PB = 6 (bc = 0, 6, 12), only of 8 bytes for
+                // PB = 3 (bc = 3, 9, 15): 16-byte LDS reads there, 8-byte reads here
+                float x[4 * NXV];
+                if constexpr (PB == 6) {
 #pragma unroll
-                for (int j = 0; j < 10; j++) xv[j] = *reinterpret_cast<const f4 *>(row + 4 * j);
-                const float *x = reinterpret_cast<const float *>(xv);
+                    for (int j = 0; j < NXV; j++) {
+                        const f4 t = *reinterpret_cast<const f4 *>(row + 4 * j);
+                        x[4 * j] = t.x; x[4 * j + 1] = t.y; x[4 * j + 2] = t.z; x[4 * j + 3] = t.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 2 * NXV - 1; j++) {
+                        const f2 t = *reinterpret_cast<const f2 *>(row + 2 * j);
+                        x[2 * j] = t.x; x[2 * j + 1] = t.y;
+                    }
+                }
 #pragma unroll
                 for (int kx = 0; kx < 3; kx++)
 #pragma unroll
                     for (int ci = 0; ci < 3; ci++) {
                         const f4 w = *reinterpret_cast<const f4 *>(w1_s + ((ky * 3 + kx) * 3 + ci) * C1 + c4 * 4);
 #pragma unroll
-                        for (int p = 0; p < 6; p++) acc[p] = fma4(x[(2 * p + kx) * 3 + ci], w, acc[p]);
+                        for (int p = 0; p < PB; p++) acc[p] = fma4(x[(2 * p + kx) * 3 + ci], w, acc[p]);
                     }
             }
             const int oy = TH * ty - 1 + br, ox = TW * tx - 1 + bc;      // position in the 112x112 conv1 map
             const bool rowok = oy >= 0 && oy < a.h;
             const f4 s1 = *reinterpret_cast<const f4 *>(sb_s + c4 * 4), b1 = *reinterpret_cast<const f4 *>(sb_s + C1 + c4 * 4);
 #pragma unroll
-            for (int p = 0; p < 6; p++) {                                 // outside the map: the depthwise zero padding
+            for (int p = 0; p < PB; p++) {                                // outside the map: the depthwise zero padding
                 f4 v = (rowok && ox + p >= 0 && ox + p < a.h) ? bn_relu6(acc[p], s1, b1) : f4{ 0.f, 0.f, 0.f, 0.f };
                 if (BF) v = rbf4(v);
                 *reinterpret_cast<f4 *>(c1_s + (br * CC + bc + p) * C1 + c4 * 4) = v;
@@ -198,76 +235,80 @@ __global__ __launch_bounds__(256, 2) void stem_fused_f32(StemArgs a)   // 2 wave
 
         // ---- C. depthwise 3x3 (stride 1, pad 1) + BN + ReLU6: 4 adjacent pixels x 4 ch per lane -> swizzled A tile
         {
-            f4 acc[4];
+            f4 acc[PC];
 #pragma unroll
-            for (int p = 0; p < 4; p++) acc[p] = f4{ 0.f, 0.f, 0.f, 0.f };
+            for (int p = 0; p < PC; p++) acc[p] = f4{ 0.f, 0.f, 0.f, 0.f };
 #pragma unroll
             for (int dy = 0; dy < 3; dy++) {
-                f4 v[6];
+                f4 v[PC + 2];
 #pragma unroll
-                for (int j = 0; j < 6; j++) v[j] = *reinterpret_cast<const f4 *>(c1_s + ((cy + dy) * CC + cx + j) * C1 + c4 * 4);
+                for (int j = 0; j < PC + 2; j++) v[j] = *reinterpret_cast<const f4 *>(c1_s + ((cy + dy) * CC + cx + j) * C1 + c4 * 4);
 #pragma unroll
                 for (int dx = 0; dx < 3; dx++)
 #pragma unroll
-                    for (int p = 0; p < 4; p++) acc[p] = fma4v(v[p + dx], wd[dy * 3 + dx], acc[p]);
+                    for (int p = 0; p < PC; p++) acc[p] = fma4v(v[p + dx], wd[dy * 3 + dx], acc[p]);
             }
             const f4 s2 = *reinterpret_cast<const f4 *>(sb_s + 2 * C1 + c4 * 4), b2 = *reinterpret_cast<const f4 *>(sb_s + 3 * C1 + c4 * 4);
 #pragma unroll
-            for (int p = 0; p < 4; p++) {
+            for (int p = 0; p < PC; p++) {
                 const f4 v = bn_relu6(acc[p], s2, b2);
                 if (BF) {                                                 // the layer output, rounded to bf16 (RNE): 8 bytes per lane
                     const int row = cy * TW + cx + p;
-                    *reinterpret_cast<bf4 *>(a_s + swzb(row, c4 >> 1) + 2 * (c4 & 1)) = bf4{ (__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w };
-                } else *reinterpret_cast<f4 *>(a_s + swz(cy * TW + cx + p, c4)) = v;
+                    *reinterpret_cast<bf4 *>(a_s + swzb<C1>(row, c4 >> 1) + 2 * (c4 & 1)) = bf4{ (__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w };
+                } else *reinterpret_cast<f4 *>(a_s + swz<C1>(cy * TW + cx + p, c4)) = v;
             }
         }
         __syncthreads();
 
-        // ---- D. pointwise 32 -> 64: wave w computes rows 32w .. 32w+31 x 64 columns
-        f16v acc[2];
+        // ---- D. pointwise C1 -> C3: wave w computes rows 32w .. 32w+31 x all C3 columns
+        f16v acc[NI];
 #pragma unroll
-        for (int ni = 0; ni < 2; ni++)
+        for (int ni = 0; ni < NI; ni++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[ni][r] = 0.f;
         if constexpr (BF) {
             // bf16 mode: both operands ARE bf16 (the depthwise output was rounded above, the filter is the bf16 copy), so the
-            // 32-deep product is 2 v_mfma_f32_32x32x16_bf16 per column block instead of 16 fp32 MFMAs: 4 x 32 cycles per wave and
-            // tile instead of 32 x 64 — the fp32 form made the bf16 stem SLOWER per image than the fp32 stem
+            // C1-deep product is C1/16 v_mfma_f32_32x32x16_bf16 per column block instead of C1/2 fp32 MFMAs — the fp32 form made
+            // the bf16 stem SLOWER per image than the fp32 stem
 #pragma unroll
-            for (int ks = 0; ks < 2; ks++) {
-                const f4 av = *reinterpret_cast<const f4 *>(a_s + swzb(wave * 32 + li, 2 * ks + lh));
+            for (int ks = 0; ks < C1 / 16; ks++) {
+                const f4 av = *reinterpret_cast<const f4 *>(a_s + swzb<C1>(wave * 32 + li, 2 * ks + lh));
 #pragma unroll
-                for (int ni = 0; ni < 2; ni++) {
-                    const f4 bv = *reinterpret_cast<const f4 *>(b_s + swzb(ni * 32 + li, 2 * ks + lh));
+                for (int ni = 0; ni < NI; ni++) {
+                    const f4 bv = *reinterpret_cast<const f4 *>(b_s + swzb<C1>(ni * 32 + li, 2 * ks + lh));
                     acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, av), __builtin_bit_cast(bf8, bv), acc[ni], 0, 0, 0);
                 }
             }
-            // channel-paired store: lane li holds channels 2li (acc[0]) and 2li+1 (acc[1]) of pixel row q: one dword per row,
-            // 32 lanes = the pixel's whole 128-byte line
-            unsigned *obase = reinterpret_cast<unsigned *>(reinterpret_cast<__bf16 *>(a.out) + ((n * a.h + TH * ty) * a.h + TW * tx) * C3) + li;
+            __bf16 *otile = reinterpret_cast<__bf16 *>(a.out) + ((n * a.h + TH * ty) * a.h + TW * tx) * C3;
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int q = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 const int y = q >> 4, x = q & 15;
-                const float v0 = relu6(fmaf(acc[0][r], s3[0], b3[0])), v1 = relu6(fmaf(acc[1][r], s3[1], b3[1]));
-                obase[((long)y * a.h + x) * (C3 / 2)] = __builtin_bit_cast(unsigned, bf2{ (__bf16)v0, (__bf16)v1 });
+                if constexpr (NI == 2) {
+                    // channel-paired store: lane li holds channels 2li (acc[0]) and 2li+1 (acc[1]) of pixel row q: one dword per
+                    // row, 32 lanes = the pixel's whole 128-byte line
+                    const float v0 = relu6(fmaf(acc[0][r], s3[0], b3[0])), v1 = relu6(fmaf(acc[1][r], s3[1], b3[1]));
+                    reinterpret_cast<unsigned *>(otile + ((long)y * a.h + x) * C3)[li] = __builtin_bit_cast(unsigned, bf2{ (__bf16)v0, (__bf16)v1 });
+                } else {
+                    otile[((long)y * a.h + x) * C3 + li] = (__bf16)relu6(fmaf(acc[0][r], s3[0], b3[0]));
+                }
             }
         } else {
 #pragma unroll
-        for (int g = 0; g < 4; g++) {
+        for (int g = 0; g < KG; g++) {
             const int chunk = 2 * g + lh;
-            const f4 av = *reinterpret_cast<const f4 *>(a_s + swz(wave * 32 + li, chunk));
-            f4 bv[2];
+            const f4 av = *reinterpret_cast<const f4 *>(a_s + swz<C1>(wave * 32 + li, chunk));
+            f4 bv[NI];
 #pragma unroll
-            for (int ni = 0; ni < 2; ni++) bv[ni] = *reinterpret_cast<const f4 *>(b_s + swz(ni * 32 + li, chunk));
+            for (int ni = 0; ni < NI; ni++) bv[ni] = *reinterpret_cast<const f4 *>(b_s + swz<C1>(ni * 32 + li, chunk));
 #pragma unroll
             for (int s = 0; s < 4; s++)
 #pragma unroll
-                for (int ni = 0; ni < 2; ni++) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[ni][s], acc[ni], 0, 0, 0);
+                for (int ni = 0; ni < NI; ni++) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[ni][s], acc[ni], 0, 0, 0);
         }
         float *obase = a.out + ((n * a.h + TH * ty) * a.h + TW * tx) * C3;
 #pragma unroll
-        for (int ni = 0; ni < 2; ni++)
+        for (int ni = 0; ni < NI; ni++)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int q = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -288,7 +329,7 @@ int mbn_launch_f32_stem(mbn_context *ctx, hipStream_t stream, float *out, const 
                         const float *s1, const float *b1, const float *wd, const float *s2, const float *b2,
                         const float *wp, const float *s3, const float *b3, int batch, int res, int c1, int c3, int in_u8, int bf16)
 {
-    if (c1 != C1 || c3 != C3 || res < 32 || (res % 32) != 0 || batch <= 0) return MBN_EUNSUPPORTED;
+    if (!((c1 == 32 && c3 == 64) || (c1 == 16 && c3 == 32)) || res < 32 || (res % 32) != 0 || batch <= 0) return MBN_EUNSUPPORTED;
     const float *ptrs[] = { w1, s1, b1, wd, s2, b2, wp, s3, b3 };
     for (const float *p : ptrs)
         if (!p || ((uintptr_t)p % 16) != 0) return MBN_EUNSUPPORTED;
@@ -302,7 +343,12 @@ int mbn_launch_f32_stem(mbn_context *ctx, hipStream_t stream, float *out, const 
     a.ntiles = (unsigned)((long)batch * a.tiles_y * a.tiles_x);
     long grid = (long)ctx->num_cus * 2;                  // 59.7 KB of LDS per workgroup: two per CU
     if (grid > (long)a.ntiles) grid = (long)a.ntiles;
-    if (bf16) hipLaunchKernelGGL(stem_fused_f32<true>, dim3((unsigned)grid), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(stem_fused_f32<false>, dim3((unsigned)grid), dim3(256), 0, stream, a);
+    if (c1 == 32) {
+        if (bf16) hipLaunchKernelGGL((stem_fused_f32<32, 64, true>), dim3((unsigned)grid), dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((stem_fused_f32<32, 64, false>), dim3((unsigned)grid), dim3(256), 0, stream, a);
+    } else {
+        if (bf16) hipLaunchKernelGGL((stem_fused_f32<16, 32, true>), dim3((unsigned)grid), dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((stem_fused_f32<16, 32, false>), dim3((unsigned)grid), dim3(256), 0, stream, a);
+    }
     return MBN_OK;
 }

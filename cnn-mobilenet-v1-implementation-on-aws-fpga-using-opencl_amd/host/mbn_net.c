@@ -173,7 +173,8 @@ static int stem_fusable(const mbn_net *net, int last_layer)
     return net->fuse_stem && !net->keep && last_layer >= 3 && net->plan.n_layers >= 3 &&
            (net->dtype == MBN_DT_F32 || (net->dtype == MBN_DT_BF16 && net->bf16_filt[2])) &&
            l[0].kind == MBN_L_CONV && l[1].kind == MBN_L_DW && l[2].kind == MBN_L_PW && l[0].in_ch == 3 &&
-           l[0].out_ch == 32 && l[1].stride == 1 && l[2].out_ch == 64 && (net->plan.res % 32) == 0;
+           ((l[0].out_ch == 32 && l[2].out_ch == 64) || (l[0].out_ch == 16 && l[2].out_ch == 32)) && l[1].stride == 1 &&
+           (net->plan.res % 32) == 0;
 }
 
 int mbn_net_set_fuse_stem(mbn_net *net, int enabled)

@@ -223,8 +223,8 @@ int mbn_pool(mbn_context *ctx, void *output, const void *inp_image, int rows, in
  * depthwise 3x3 stride 1 -> pointwise 1x1, each followed by its folded-BN scale/shift and ReLU6 — in one kernel, so
  * the two 112x112x32 intermediates never reach HBM (MobileNet.c:240-498 does three launches and six PCIe copies).
  * fp32 NHWC only; image [batch][res][res][3], out [batch][res/2][res/2][c3]; filters in the layouts of the separate
- * calls (w1 [3][3][3][c1], wd [3][3][c1], wp [c3][c1]). Returns MBN_EUNSUPPORTED unless c1 = 32, c3 = 64 and res is a
- * multiple of 32 — callers then issue the three layer calls instead. */
+ * calls (w1 [3][3][3][c1], wd [3][3][c1], wp [c3][c1]). Returns MBN_EUNSUPPORTED unless (c1, c3) = (32, 64) (alpha = 1) or
+ * (16, 32) (alpha = 0.5) and res is a multiple of 32 — callers then issue the three layer calls instead. */
 int mbn_stem_fused(mbn_context *ctx, void *out, const void *image, const void *w1, const void *s1, const void *b1,
                    const void *wd, const void *s2, const void *b2, const void *wp, const void *s3, const void *b3,
                    int batch, int res, int c1, int c3, void *stream);

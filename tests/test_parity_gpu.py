@@ -675,23 +675,26 @@ def test_net_full_size_batch1_every_layer(pkg, orc, ctx, tmp_path):
     net.destroy()
 
 
-@pytest.mark.parametrize("res,n", [(224, 2), (64, 3), (96, 1)])
-def test_fused_stem_equals_three_layers_and_oracle(pkg, orc, ctx, tmp_path, res, n):
+@pytest.mark.parametrize("alpha,res,n", [(1.0, 224, 2), (1.0, 64, 3), (1.0, 96, 1), (0.5, 160, 2), (0.5, 64, 3), (0.5, 224, 1)])
+def test_fused_stem_equals_three_layers_and_oracle(pkg, orc, ctx, tmp_path, alpha, res, n):
     """mbn_stem_fused (layers 1-3 in one kernel) vs the three separate layer calls (same fmaf/MFMA order -> expected
-    bit-identical) and vs the oracle's layer-3 activation. Tiles at the image border exercise the zero halo."""
-    hw, net = _make_net(pkg, ctx, tmp_path, 1.0, res, 20, n)
+    bit-identical) and vs the oracle's layer-3 activation. Tiles at the image border exercise the zero halo. alpha = 1:
+    32 -> 32 -> 64 channels; alpha = 0.5 (BASELINE config 5's 0.5x160): 16 -> 16 -> 32, the template's second instance."""
+    hw, net = _make_net(pkg, ctx, tmp_path, alpha, res, 20, n)
+    c3 = hw.plan.layer[2].out_ch
+    assert c3 == int(64 * alpha)
     imgs = np.random.default_rng(res).uniform(-1, 1, (n, res, res, 3)).astype(np.float32)
     h = res // 2
-    d_in, d_a, d_b = ctx.to_device(imgs), ctx.alloc(n * h * h * 64 * 4), ctx.alloc(n * h * h * 64 * 4)
+    d_in, d_a, d_b = ctx.to_device(imgs), ctx.alloc(n * h * h * c3 * 4), ctx.alloc(n * h * h * c3 * 4)
     assert net.fused_layers(3) == 3
     net.forward(d_in.ptr, d_a.ptr, n, 3)                 # fused
     net.set_fuse_stem(False)
     assert net.fused_layers(3) == 0
     net.forward(d_in.ptr, d_b.ptr, n, 3)                 # conv1, dw2, pw3 as separate launches
     ctx.sync()
-    fused, unfused = d_a.download((n, h, h, 64), np.float32), d_b.download((n, h, h, 64), np.float32)
+    fused, unfused = d_a.download((n, h, h, c3), np.float32), d_b.download((n, h, h, c3), np.float32)
     assert np.array_equal(fused, unfused)
-    want, _ = orc.net_forward(orc.plan_build(1.0, res, 20), hw.blob, imgs, last_layer=3, threads=orc.num_threads())
+    want, _ = orc.net_forward(orc.plan_build(alpha, res, 20), hw.blob, imgs, last_layer=3, threads=orc.num_threads())
     assert_close(fused, want, TOL_PW, "fused stem vs oracle")
     # whole net with and without the fused stem
     d_l1, d_l2 = ctx.alloc(n * 20 * 4), ctx.alloc(n * 20 * 4)
@@ -704,12 +707,18 @@ def test_fused_stem_equals_three_layers_and_oracle(pkg, orc, ctx, tmp_path, res,
 
 
 def test_fused_stem_unsupported_shapes_fall_back(pkg, ctx, tmp_path):
-    """alpha != 1 (conv1 != 32 channels): mbn_stem_fused answers MBN_EUNSUPPORTED and the runner issues the 3 calls."""
-    hw, net = _make_net(pkg, ctx, tmp_path, 0.5, 64, 10, 1)
+    """Widths other than alpha = 1 (32 -> 64) and alpha = 0.5 (16 -> 32): mbn_stem_fused answers MBN_EUNSUPPORTED and the
+    runner issues the 3 calls (alpha = 0.25: conv1 has 8 channels)."""
+    hw, net = _make_net(pkg, ctx, tmp_path, 0.25, 64, 10, 1)
     assert net.fused_layers(0) == 0
     d = ctx.alloc(1 << 20)
-    rc = ctx.lib.mbn_stem_fused(ctx.h, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, 1, 64, 16, 32, None)
+    rc = ctx.lib.mbn_stem_fused(ctx.h, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, 1, 64, 8, 16, None)
     assert rc == pkg.EUNSUPPORTED
+    rc = ctx.lib.mbn_stem_fused(ctx.h, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, 1, 64, 16, 64, None)
+    assert rc == pkg.EUNSUPPORTED
+    net.destroy()
+    hw, net = _make_net(pkg, ctx, tmp_path, 0.5, 64, 10, 1)
+    assert net.fused_layers(0) == 3                        # alpha = 0.5 is inside the envelope since round 2
     net.destroy()
 
 
@@ -936,24 +945,26 @@ def test_f32_dwpw_fused_top_left_padding(pkg, orc, ctx):
     assert_close(d_f.download(want.shape, np.float32), want, TOL_PW, "dwpw top/left padding")
 
 
-def test_bf16_fused_stem_vs_oracle_and_separate_layers(pkg, orc, ctx, tmp_path):
+@pytest.mark.parametrize("alpha", [1.0, 0.5])
+def test_bf16_fused_stem_vs_oracle_and_separate_layers(pkg, orc, ctx, tmp_path, alpha):
     """bf16 mode of the fused stem (MBN_STEM_BF16): layer-3 activation vs the oracle's bf16 emulation of layers 1-3 (every
     layer output rounded to bf16, bf16 pointwise filter) and vs the three separate bf16 launches. Not bit-identical to the
     separate launches by construction — their pointwise runs on the bf16 MFMA, the stem's on the fp32 MFMA over the same
     bf16-representable operands, so the fp32 summation order differs — hence the bf16 tolerance on both comparisons."""
     n, res = 2, 64
-    hw, net = _make_net(pkg, ctx, tmp_path, 1.0, res, 20, n)
+    hw, net = _make_net(pkg, ctx, tmp_path, alpha, res, 20, n)
+    c3 = hw.plan.layer[2].out_ch
     net.set_dtype(pkg.DT_BF16)
     imgs = np.random.default_rng(31).uniform(-1, 1, (n, res, res, 3)).astype(np.float32)
     h = res // 2
-    d_in, d_a, d_b = ctx.to_device(imgs), ctx.alloc(n * h * h * 64 * 2), ctx.alloc(n * h * h * 64 * 2)
+    d_in, d_a, d_b = ctx.to_device(imgs), ctx.alloc(n * h * h * c3 * 2), ctx.alloc(n * h * h * c3 * 2)
     assert net.fused_layers(3) == 3
     net.forward(d_in.ptr, d_a.ptr, n, 3)
     net.set_fuse_stem(False)
     net.forward(d_in.ptr, d_b.ptr, n, 3)
     ctx.sync()
-    fused, sep = _bf16_get(pkg, d_a, (n, h, h, 64)), _bf16_get(pkg, d_b, (n, h, h, 64))
-    oplan = orc.plan_build(1.0, res, 20)
+    fused, sep = _bf16_get(pkg, d_a, (n, h, h, c3)), _bf16_get(pkg, d_b, (n, h, h, c3))
+    oplan = orc.plan_build(alpha, res, 20)
     x = imgs
     for i in range(3):
         x = _oracle_layer(orc, oplan, hw.blob, i, x, True)
