@@ -697,8 +697,13 @@ int mbn_dwpw_fused(mbn_context *ctx, void *out, const void *in, const void *wd, 
     // unified-wave kernel (mbn_f32_dwpw2.hip) for the 128-column tile, where it measures 9-12 % faster than the round-1
     // producer/consumer kernel; the 256-column tile stays on the round-1 kernel (within +-3 % of each other there).
     // dwpw_variant: 1 = always round-1, 2 = always unified (A/B hooks, tools/block_bench.py)
+    // small problems (few images): a 256-column tile leaves most CUs idle and every workgroup walks the whole K alone —
+    // batch 1, block 10-11: 40 us fused against 24 us as two launches — so below one 256-wide tile per CU the block runs
+    // on 128-column tiles (twice the workgroups, half the MFMA work per step), i.e. on the unified kernel
     const int dv = g_mbn_tune.dwpw_variant;
-    if (dv != 1 && (dv >= 2 || (cout % 256) != 0))
+    const long tiles256 = (((long)batch * out_rows * out_cols + 127) / 128) * (cout / 256);
+    const bool small = tiles256 < ctx->num_cus;
+    if (dv != 1 && (dv >= 2 || (cout % 256) != 0 || small))
         return sc.finish(mbn_launch_f32_dwpw2(ctx, s, (float *)out, (const float *)in, (const float *)wd, (const float *)s2,
                                               (const float *)b2, (const float *)wp, (const float *)s3, (const float *)b3, batch,
                                               in_rows, in_cols, out_rows, out_cols, cin, cout, stride, pad_top, pad_left));

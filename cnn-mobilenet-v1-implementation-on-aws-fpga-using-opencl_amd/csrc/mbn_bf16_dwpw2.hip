@@ -330,7 +330,8 @@ int mbn_launch_bf16_dwpw2(mbn_context *ctx, hipStream_t stream, void *out, const
     a.in_bytes = (unsigned)(2.0 * batch * in_rows * in_cols * cin);
     a.wp_bytes = (unsigned)(2.0 * cin * cout);
     a.dbg = variant >= 100 ? variant - 100 : 0;
-    const bool wide = (cout % 256) == 0 && g_mbn_tune.pw_tile != 1;      // pw_tile=1: force the 128-column tile (A/B hook)
+    // 256-column tiles only when they alone fill the chip; pw_tile=1: force the 128-column tile (A/B hook)
+    const bool wide = (cout % 256) == 0 && g_mbn_tune.pw_tile != 1 && ((a.m + BM - 1) / BM) * (cout / 256) >= ctx->num_cus;
     if (stride == 1) {
         if (wide) launch2<1, 256>(a, stream, ctx->num_cus);
         else launch2<1, 128>(a, stream, ctx->num_cus);

@@ -297,6 +297,7 @@ int launch_dw(const mbn_call &c, DwArgs &a, int rows, int cols, int fs, int stri
         else if (row_lanes < target) {
             nseg = (int)((target + row_lanes - 1) / row_lanes);
             int max_seg = rows / 4 > 0 ? rows / 4 : 1;
+            if (row_lanes * max_seg < (long)c.ctx->num_cus * 64) max_seg = rows;   // latency-bound (see the fp32 branch)
             if (nseg > max_seg) nseg = max_seg;
         }
         if (nseg > rows) nseg = rows;
@@ -334,7 +335,11 @@ int launch_dw(const mbn_call &c, DwArgs &a, int rows, int cols, int fs, int stri
     if (g_mbn_tune.dw_nseg > 0) nseg = g_mbn_tune.dw_nseg;
     else if (row_lanes < target) {
         nseg = (int)((target + row_lanes - 1) / row_lanes);
-        int max_seg = rows / 4 > 0 ? rows / 4 : 1;     // keep >= 4 output rows per segment
+        int max_seg = rows / 4 > 0 ? rows / 4 : 1;     // keep >= 4 output rows per segment ...
+        // ... unless even that leaves less than one wave per CU (a few images): then the launch is bound by the length of a
+        // lane's row march (one dependent memory round trip per row: 9-10 us for a 14-row map at batch 1), not by bytes, and
+        // one output row per segment is best
+        if (row_lanes * max_seg < (long)c.ctx->num_cus * 64) max_seg = rows;
         if (nseg > max_seg) nseg = max_seg;
     }
     if (nseg > rows) nseg = rows;

@@ -215,6 +215,15 @@ __global__ __launch_bounds__(256) void pool_f32_nhwc(T *__restrict__ out, const 
     const int n = (int)(t / ch);
     const T *ip = in + (long)n * rows * cols * ch + c;
     float acc = 0.f;
+    if (fr == 7 && fc == 7) {
+        // the network's 7x7 window: all 49 loads are issued before the first add (the plain loop below is a chain of
+        // dependent load -> add pairs: 16 us at batch 1, one memory round trip per tap); same left-to-right sum, same bits
+        float v[49];
+#pragma unroll
+        for (int i = 0; i < 49; i++) v[i] = (float)ip[((long)(i / 7) * cols + (i % 7)) * ch];
+#pragma unroll
+        for (int i = 0; i < 49; i++) acc += v[i];
+    } else
     for (int y = 0; y < fr; y++)
         for (int x = 0; x < fc; x++) acc += (float)ip[((long)y * cols + x) * ch];
     out[t] = (T)(acc / (float)(fr * fc));
