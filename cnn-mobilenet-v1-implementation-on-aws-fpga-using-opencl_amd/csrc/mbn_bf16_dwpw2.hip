@@ -28,6 +28,7 @@ typedef mbn_f16v f16v;
 
 constexpr int BM = 128, BKF = 32;              // LDS rows are 128 bytes = 32 words = 64 bf16
 constexpr int NW = 8, NT = 64 * NW;            // 8 waves: 2 per SIMD, 256 VGPRs each
+constexpr int NOUT = 1024;                     // widest pointwise output whose scale/shift the LDS copy holds
 constexpr int CMAX = 1024;                     // largest Cin (depthwise constants resident in LDS: 44 KB)
 constexpr unsigned OOB = 0xF0000000u;          // byte offset beyond any supported tensor: the load returns zeros
 
@@ -100,8 +101,12 @@ __global__ __launch_bounds__(NT) void dwpw2_bf16(DwPw2Args a)
     constexpr int XC = S + 3;                          // input columns feeding 2 adjacent output pixels
     constexpr int NX = 3 * XC;                         // buffer loads per lane per chunk
     constexpr int ABUF = BM * BKF, BBUF = BN * BKF;
-    __shared__ __attribute__((aligned(16))) float lds[2 * ABUF + 2 * BBUF + 11 * CMAX];
+    __shared__ __attribute__((aligned(16))) float lds[2 * ABUF + 2 * BBUF + 11 * CMAX + 2 * NOUT];
     float *const a_s0 = lds, *const b_s0 = lds + 2 * ABUF, *const wd_s = b_s0 + 2 * BBUF, *const sb_s = wd_s + 9 * CMAX;
+    // pointwise scale | shift of all Cout channels: the epilogue reads them with ds_read. As global loads they were the wave's
+    // youngest vector-memory operations, and waiting for them (in-order vmcnt) drained the x-window loads and the filter DMA
+    // already in flight for the next steps: 1700-3100 cycles per tile in the stamps (profiles/r02/g_dwpw2_stamps.txt)
+    float *const sc3_s = sb_s + 2 * CMAX, *const sh3_s = sc3_s + NOUT;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -113,6 +118,7 @@ __global__ __launch_bounds__(NT) void dwpw2_bf16(DwPw2Args a)
         *reinterpret_cast<f4 *>(sb_s + i) = *reinterpret_cast<const f4 *>(a.s2 + i);
         *reinterpret_cast<f4 *>(sb_s + a.cin + i) = *reinterpret_cast<const f4 *>(a.b2 + i);
     }
+    for (int i = tid; i < a.cout; i += NT) { sc3_s[i] = a.s3[i]; sh3_s[i] = a.b3[i]; }
     __syncthreads();
     if ((int)blockIdx.x >= nwg) return;
 
@@ -284,8 +290,8 @@ __global__ __launch_bounds__(NT) void dwpw2_bf16(DwPw2Args a)
         if (validL) lds_barrier<NX>();                                                                                  \
         else lds_barrier<0>();                                                                                          \
         if (kM == nk - 1 && !(a.dbg & 4)) {                                                                             \
-            if (m0M + BM <= mtot) mbn_store_relu6_bf16_pair<MI, NI, 0>(orsrc, (unsigned)a.cout, m0M + wm, n0M + wn, lane, acc, a.s3, a.b3); \
-            else mbn_store_relu6_bf16_pair<MI, NI, 1>(orsrc, (unsigned)a.cout, m0M + wm, n0M + wn, lane, acc, a.s3, a.b3);               \
+            if (m0M + BM <= mtot) mbn_store_relu6_bf16_pair<MI, NI, 0>(orsrc, (unsigned)a.cout, m0M + wm, n0M + wn, lane, acc, sc3_s, sh3_s); \
+            else mbn_store_relu6_bf16_pair<MI, NI, 1>(orsrc, (unsigned)a.cout, m0M + wm, n0M + wn, lane, acc, sc3_s, sh3_s);               \
             zero_acc();                                                                                                 \
         }                                                                                                               \
         if (!validD) break;                                                                                             \

@@ -270,7 +270,7 @@ int mbn_f32_dwpw_check(const float *out, const float *in, const float *wd, const
     const float *ptrs[] = { in, wd, s2, b2, wp, s3, b3, out };
     for (const float *p : ptrs)
         if (!p) return MBN_EINVAL;
-    if (batch <= 0 || (stride != 1 && stride != 2) || cin < 32 || (cin % 32) != 0 || cin > CMAX || cout < 128 ||
+    if (batch <= 0 || (stride != 1 && stride != 2) || cin < 32 || (cin % 32) != 0 || cin > CMAX || cout < 128 || cout > 1024 ||
         (cout % 128) != 0 || (out_cols & 1) || out_rows <= 0 || out_cols <= 0 || in_rows <= 0 || in_cols <= 0 ||
         pad_top < 0 || pad_left < 0)
         return MBN_EUNSUPPORTED;

@@ -43,8 +43,13 @@ typedef mbn_f16v f16v;
 
 constexpr int BM = 128, BKF = 32;
 constexpr int NW = 8, NT = 64 * NW;            // 8 waves: 2 per SIMD, 256 VGPRs each
+constexpr int NOUT = 1024;                     // widest pointwise output whose scale/shift the LDS copy holds
 constexpr int CMAX = 1024;                     // largest Cin (depthwise constants resident in LDS: 44 KB)
 constexpr unsigned OOB = 0xF0000000u;          // byte offset beyond any supported tensor: the load returns zeros
+
+// In-kernel stamps (diagnostic: dwpw_variant = 100 + 64): workgroup 0 records s_memtime at five points of its first 96 steps,
+// per wave; read back with mbn_debug_dwpw2_stamps (tools/stamp_dwpw2.py). No output value depends on them.
+__device__ unsigned long long g_dwpw2_stamps[8][96][6];
 
 struct DwPw2Args {
     float *out;
@@ -105,8 +110,12 @@ __global__ __launch_bounds__(NT) void dwpw2_f32(DwPw2Args a)
     constexpr int XC = S + 3;                          // input columns feeding 2 adjacent output pixels
     constexpr int NX = 3 * XC;                         // buffer loads per lane per chunk
     constexpr int ABUF = BM * BKF, BBUF = BN * BKF;
-    __shared__ __attribute__((aligned(16))) float lds[2 * ABUF + 2 * BBUF + 11 * CMAX];
+    __shared__ __attribute__((aligned(16))) float lds[2 * ABUF + 2 * BBUF + 11 * CMAX + 2 * NOUT];
     float *const a_s0 = lds, *const b_s0 = lds + 2 * ABUF, *const wd_s = b_s0 + 2 * BBUF, *const sb_s = wd_s + 9 * CMAX;
+    // pointwise scale | shift of all Cout channels: the epilogue reads them with ds_read. As global loads they were the wave's
+    // youngest vector-memory operations, and waiting for them (in-order vmcnt) drained the x-window loads and the filter DMA
+    // already in flight for the next steps: 1700-3100 cycles per tile in the stamps (profiles/r02/g_dwpw2_stamps.txt)
+    float *const sc3_s = sb_s + 2 * CMAX, *const sh3_s = sc3_s + NOUT;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -118,6 +127,7 @@ __global__ __launch_bounds__(NT) void dwpw2_f32(DwPw2Args a)
         *reinterpret_cast<f4 *>(sb_s + i) = *reinterpret_cast<const f4 *>(a.s2 + i);
         *reinterpret_cast<f4 *>(sb_s + a.cin + i) = *reinterpret_cast<const f4 *>(a.b2 + i);
     }
+    for (int i = tid; i < a.cout; i += NT) { sc3_s[i] = a.s3[i]; sh3_s[i] = a.b3[i]; }
     __syncthreads();
     if ((int)blockIdx.x >= nwg) return;
 
@@ -257,10 +267,14 @@ __global__ __launch_bounds__(NT) void dwpw2_f32(DwPw2Args a)
     if (validD) lds_barrier<NX>();        // filter chunk 0 landed; the NX newer loads may fly
     else lds_barrier<0>();
 
+    int stepno = 0;
+    const bool stamping = (a.dbg & 64) && blockIdx.x == 0;
+#define STAMP(k) do { if (stamping && stepno < 96) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) g_dwpw2_stamps[wave_u][stepno][k] = t_; } } while (0)
     // One chunk step with the MFMA chunk in buffer P (a literal at both call sites).
     // Returns false when the sequence is finished.
 #define MBN_DWPW2_STEP(P)                                                                                               \
     {                                                                                                                   \
+        STAMP(0);                                                                                                       \
         ldfrag(P, 0, 0);                                                                                                \
         bool validL = false;                                                                                            \
         int vbL = vbD, kL = kD + 1, n0L = n0D;                                                                          \
@@ -273,8 +287,10 @@ __global__ __launch_bounds__(NT) void dwpw2_f32(DwPw2Args a)
                 kL = 0; vbL += gridDim.x; validL = vbL < nwg;                                                           \
                 if (validL) { origin(vbL, m0L, n0L); set_offsets(m0L); }                                                \
             }                                                                                                           \
+            STAMP(1);                                                                                                   \
             if (validL && !(a.dbg & 1)) ldx(kL);                                                                        \
         }                                                                                                               \
+        STAMP(2);                                                                                                       \
         if (!(a.dbg & 16)) {                                                                                            \
         _Pragma("unroll") for (int g = 0; g < 3; g++) {                                                                 \
             ldfrag(P, g + 1, (g + 1) & 1);                                                                              \
@@ -284,17 +300,21 @@ __global__ __launch_bounds__(NT) void dwpw2_f32(DwPw2Args a)
         }                                                                                                               \
         mfma_group(1);                                                                                                  \
         }                                                                                                               \
+        STAMP(3);                                                                                                       \
         if (PRE && validL) ldw(kL);                                                                                     \
         if (validL) lds_barrier<NX>();                                                                                  \
         else lds_barrier<0>();                                                                                          \
+        STAMP(4);                                                                                                       \
         if (kM == nk - 1 && !(a.dbg & 4)) {                                                                             \
             if (paired) {                                                                                               \
-                if (m0M + BM <= mtot) mbn_store_relu6_f32_pair<MI, NI, 0>(orsrc, (unsigned)a.cout, m0M + wm, n0M + wn, lane, acc, a.s3, a.b3); \
-                else mbn_store_relu6_f32_pair<MI, NI, 1>(orsrc, (unsigned)a.cout, m0M + wm, n0M + wn, lane, acc, a.s3, a.b3);               \
-            } else if (m0M + BM <= mtot) mbn_store_relu6_f32<MI, NI, 0>(orsrc, (unsigned)a.cout, m0M + wm, n0M + wn, lane, acc, a.s3, a.b3, mtot, a.cout); \
-            else mbn_store_relu6_f32<MI, NI, 1>(orsrc, (unsigned)a.cout, m0M + wm, n0M + wn, lane, acc, a.s3, a.b3, mtot, a.cout);               \
+                if (m0M + BM <= mtot) mbn_store_relu6_f32_pair<MI, NI, 0>(orsrc, (unsigned)a.cout, m0M + wm, n0M + wn, lane, acc, sc3_s, sh3_s); \
+                else mbn_store_relu6_f32_pair<MI, NI, 1>(orsrc, (unsigned)a.cout, m0M + wm, n0M + wn, lane, acc, sc3_s, sh3_s);               \
+            } else if (m0M + BM <= mtot) mbn_store_relu6_f32<MI, NI, 0>(orsrc, (unsigned)a.cout, m0M + wm, n0M + wn, lane, acc, sc3_s, sh3_s, mtot, a.cout); \
+            else mbn_store_relu6_f32<MI, NI, 1>(orsrc, (unsigned)a.cout, m0M + wm, n0M + wn, lane, acc, sc3_s, sh3_s, mtot, a.cout);               \
             zero_acc();                                                                                                 \
         }                                                                                                               \
+        STAMP(5);                                                                                                       \
+        stepno++;                                                                                                       \
         if (!validD) break;                                                                                             \
         vbM = vbD; kM = kD; m0M = m0D; n0M = n0D;                                                                       \
         vbD = vbL; kD = kL; m0D = m0L; n0D = n0L; validD = validL;                                                      \
@@ -305,6 +325,7 @@ __global__ __launch_bounds__(NT) void dwpw2_f32(DwPw2Args a)
         MBN_DWPW2_STEP(1)
     }
 #undef MBN_DWPW2_STEP
+#undef STAMP
 }
 
 template <int S, int BN>
@@ -349,4 +370,12 @@ int mbn_launch_f32_dwpw2(mbn_context *ctx, hipStream_t stream, float *out, const
         else launch2<2, 128>(a, stream, ctx->num_cus, pre);
     }
     return MBN_OK;
+}
+
+// Diagnostic: copies the stamps of the last stamped launch (workgroup 0: [wave 8][step 96][point 6] 64-bit cycle counts).
+extern "C" int mbn_debug_dwpw2_stamps(unsigned long long *host, size_t bytes)
+{
+    if (!host || bytes < sizeof(g_dwpw2_stamps)) return MBN_EINVAL;
+    if (hipDeviceSynchronize() != hipSuccess) return MBN_EDEVICE;
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_dwpw2_stamps), sizeof(g_dwpw2_stamps)) == hipSuccess ? MBN_OK : MBN_EDEVICE;
 }

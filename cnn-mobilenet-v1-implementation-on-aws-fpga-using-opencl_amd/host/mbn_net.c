@@ -218,7 +218,7 @@ static int block_fusable(const mbn_net *net, int i, int count, int last_layer)
     if (((uintptr_t)net->dev_blob % 16) != 0) return 0;            /* see stem_fusable */
     const mbn_layer_desc *d = &net->plan.layer[i], *p = &net->plan.layer[i + 1];
     if (d->kind != MBN_L_DW || p->kind != MBN_L_PW || (d->stride != 1 && d->stride != 2)) return 0;
-    if (d->in_ch < 32 || (d->in_ch % 32) != 0 || d->in_ch > 1024 || p->out_ch < 128 || (p->out_ch % 128) != 0) return 0;
+    if (d->in_ch < 32 || (d->in_ch % 32) != 0 || d->in_ch > 1024 || p->out_ch < 128 || (p->out_ch % 128) != 0 || p->out_ch > 1024) return 0;
     if ((d->out_cols & 1) || p->in_ch != d->out_ch) return 0;
     const double es = bf ? 2.0 : 4.0;
     if (es * count * d->in_rows * d->in_cols * d->in_ch >= 4026531840.0) return 0;

@@ -249,7 +249,7 @@ int mbn_stem_fused_ex(mbn_context *ctx, void *out, const void *image, const void
  * scale/shift and ReLU6; the depthwise output never reaches HBM. fp32 NHWC: in [batch][in_rows][in_cols][cin],
  * out [batch][out_rows][out_cols][cout]; wd [3][3][cin], wp [cout][cin] as in the separate calls; pad_top/pad_left as in
  * mbn_layer_ext (zero padding; the high side needs none stated). Bit-identical to mbn_depthwise followed by
- * mbn_pointwise. Returns MBN_EUNSUPPORTED unless cin is a multiple of 32 and <= 1024, cout a multiple of 128, out_cols
+ * mbn_pointwise. Returns MBN_EUNSUPPORTED unless cin is a multiple of 32 and <= 1024, cout a multiple of 128 and <= 1024, out_cols
  * even and the input under 3.75 GiB — callers then issue the two layer calls instead. */
 int mbn_dwpw_fused(mbn_context *ctx, void *out, const void *in, const void *wd, const void *s2, const void *b2,
                    const void *wp, const void *s3, const void *b3, int batch, int in_rows, int in_cols, int out_rows,
