@@ -50,10 +50,12 @@ struct PwArgs {
     int out_f32;    // bf16 mode: write fp32 (FC logits)
     int fast_epi;   // 0 = always the general epilogue (A/B hook: tune conv_variant=9)
     int loop2;      // 1 = software-pipelined k-loop (default); 0 = plain loop (A/B hook: tune conv_variant=8)
+    int no_ss;      // 1 = epilogue reads scale/shift from global memory as in round 1 (A/B hook: tune conv_variant=7)
     int xn;         // XCD groups along n (1, 2 or 4): > 1 when the filter does not fit an XCD's L2 next to the streamed A panels
 };
 
 constexpr int BKB = 128;            // k-tile in BYTES per row (32 fp32 / 64 bf16)
+constexpr int SSMAX = 1024;         // widest output whose scale/shift are staged in LDS for the epilogue (8 KB)
 constexpr int BKF = BKB / 4;        // ... in 4-byte LDS words
 
 __device__ __forceinline__ int swz(int row, int chunk) { return (row << 5) + (((chunk ^ (row >> 1)) & 7) << 2); }
@@ -92,7 +94,17 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void pw_gemm(PwArgs a)
     constexpr int A_LD = BM * 8 / NT, B_LD = BN * 8 / NT;     // 16-B loads per thread per k-tile
     constexpr int ST = A_LD > B_LD ? A_LD : B_LD;
     static_assert(A_LD >= 1 && B_LD >= 1 && A_LD * NT == BM * 8 && B_LD * NT == BN * 8, "tile/threads mismatch");
-    __shared__ __attribute__((aligned(16))) float lds[NBUF * (BM + BN) * BKF];
+    __shared__ __attribute__((aligned(16))) float lds[NBUF * (BM + BN) * BKF + (GLDS ? 2 * SSMAX : 0)];
+    // GLDS kernels (every pointwise layer of the network): scale | shift of all N channels sit behind the tiles and the fast
+    // epilogue reads them with ds_read. As global loads they were the wave's youngest vector-memory operations — younger than
+    // the NEXT tile's first LDS-DMA, issued just before the epilogue — so waiting for them (in-order vmcnt) drained that DMA
+    // once per tile (the same stall the stamps of the fused block kernel showed: profiles/r02/g_dwpw2_stamps.txt)
+    float *const sc_s = lds + NBUF * (BM + BN) * BKF, *const sh_s = sc_s + SSMAX;
+    const bool ss_lds = GLDS && a.scale && a.shift && a.n <= SSMAX && !a.no_ss;
+    if (ss_lds) {
+        for (int i = threadIdx.x; i < a.n; i += 64 * (BM / WM) * (BN / WN)) { sc_s[i] = a.scale[i]; sh_s[i] = a.shift[i]; }
+        __syncthreads();
+    }
 
     const T *gin = reinterpret_cast<const T *>(a.in);
     const T *gfilt = reinterpret_cast<const T *>(a.filt);
@@ -382,11 +394,16 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void pw_gemm(PwArgs a)
         if (!(BF && a.out_f32) && a.act == MBN_ACT_RELU6 && a.scale && a.shift && cm0 + BM <= a.m && cn0 + BN <= a.n &&
             g_fast_epilogue && (!PAIRN || (a.n & 1) == 0)) {
             // interior tile of a BN + ReLU6 layer (every pointwise layer of the network): lean stores, mbn_epilogue.h
-            if constexpr (PAIRN)
-                mbn_store_relu6_bf16_pair<MI, NI, 0>(orsrc, (unsigned)a.n, (unsigned)cm0 + wm_u, cn0 + wn_u, lane, acc, a.scale, a.shift);
-            else
-                mbn_store_relu6_f32<MI, NI, 0, T>(orsrc, (unsigned)a.n, (unsigned)cm0 + wm_u, cn0 + wn_u, lane, acc, a.scale,
-                                                  a.shift, (unsigned)a.m, a.n);
+            const float *scp = ss_lds ? sc_s : a.scale, *shp = ss_lds ? sh_s : a.shift;
+            if constexpr (PAIRN) {
+                if (ss_lds) mbn_store_relu6_bf16_pair<MI, NI, 0>(orsrc, (unsigned)a.n, (unsigned)cm0 + wm_u, cn0 + wn_u, lane, acc, sc_s, sh_s);
+                else mbn_store_relu6_bf16_pair<MI, NI, 0>(orsrc, (unsigned)a.n, (unsigned)cm0 + wm_u, cn0 + wn_u, lane, acc, a.scale, a.shift);
+            } else {
+                if (ss_lds) mbn_store_relu6_f32<MI, NI, 0, T>(orsrc, (unsigned)a.n, (unsigned)cm0 + wm_u, cn0 + wn_u, lane, acc, sc_s, sh_s, (unsigned)a.m, a.n);
+                else mbn_store_relu6_f32<MI, NI, 0, T>(orsrc, (unsigned)a.n, (unsigned)cm0 + wm_u, cn0 + wn_u, lane, acc, a.scale,
+                                                       a.shift, (unsigned)a.m, a.n);
+            }
+            (void)scp; (void)shp;
         } else if constexpr (PAIRN) {
             // element-wise path on the channel-paired layout (ragged tiles, the FC layer's fp32 logits, no BN): rare and small
 #pragma unroll
@@ -464,7 +481,7 @@ void launch_cfg(PwArgs &a, hipStream_t s, int num_cus)
     a.mt = (int)((a.m + BM - 1) / BM);
     a.nt = (a.n + BN - 1) / BN;
     const int nbuf = a.k <= BKE ? 1 : 2;
-    const int lds_bytes = nbuf * (BM + BN) * BKB;
+    const int lds_bytes = nbuf * (BM + BN) * BKB + (nbuf == 2 ? 2 * SSMAX * 4 : 0);   // + the staged scale/shift of the GLDS kernels
     // persistent grid: as many workgroups as are resident at once (LDS- and wave-limited)
     int per_cu = 160 * 1024 / lds_bytes;
     const int wave_cap = 32 / (NT / 64);                 // 32 waves per CU
@@ -512,6 +529,7 @@ int mbn_launch_f32_pointwise(const mbn_call &c, void *out, const void *in, const
     a.out_f32 = bf && (c.io_flags & MBN_IO_OUT_F32) ? 1 : 0;
     a.loop2 = (g_mbn_tune.conv_variant == 8 || ((cin / (bf ? 64 : 32)) & 1) || (cin % (bf ? 64 : 32)) ||
                (double)m * cin * (bf ? 2 : 4) >= 4294967296.0 || (double)op_size * cin * (bf ? 2 : 4) >= 4294967296.0) ? 0 : 1;
+    a.no_ss = g_mbn_tune.conv_variant == 7 ? 1 : 0;
     a.fast_epi = (g_mbn_tune.conv_variant == 9 || (double)m * op_size * 4.0 >= 4294967296.0) ? 0 : 1;   // buffer stores: < 4 GiB
     if (m <= 0 || (long)((m + 31) / 32) * ((op_size + 31) / 32) > 0x7fffffffL) return MBN_EINVAL;
     const int epc = bf ? 8 : 4;
