@@ -134,7 +134,12 @@ def main():
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="storage type of activations and pointwise filters (arithmetic is fp32 either way)")
     ap.add_argument("--streams", type=int, default=1,
-                    help="pipeline each step over this many sub-batches on separate HIP streams (mbn_net_set_streams)")
+                    help="default 1. n > 1: pipeline each step over n sub-batches on separate HIP streams (mbn_net_set_streams): the "
+                         "HBM-bound depthwise kernels of one sub-batch overlap the MFMA-bound GEMMs of the other. The steps "
+                         "whose kernels are timed one by one (--profile-every) run on ONE stream, so the per-kernel HIP-event "
+                         "durations behind `roofline` and `stages` are not stretched by a concurrent kernel. Measured at "
+                         "batch 256 fp32: +3.6 %% without per-kernel events, +1.5 %% with every 5th step single-stream; bf16 "
+                         "batch 512: -3 %% (DESIGN.md 5)")
     ap.add_argument("--dist-backend", default="nccl", help="rehearsal only: 'gloo' lets several ranks share one GPU")
     ap.add_argument("--device-override", type=int, default=-1, help="rehearsal only: every rank uses this device")
     ap.add_argument("--graph", action="store_true", help="replay each step as one hipGraph (mbn_net_set_graph)")
@@ -206,7 +211,7 @@ def main():
         net.set_fuse_blocks(args.fuse_blocks)
     if args.graph:
         net.set_graph(True)
-    if args.streams > 1:
+    if args.streams > 1 and args.batch >= 2 * args.streams:
         net.set_streams(args.streams, free_running=True)   # the input batch is resident before timing starts
     bf16 = args.dtype == "bf16"
     if bf16:
@@ -235,7 +240,8 @@ def main():
     profile = not args.no_profile and not args.graph    # per-kernel events cannot be read back from inside a graph
     every = max(1, args.profile_every)
     sampled = [s for s in range(args.steps) if s % every == every // 2] or [0]
-    nsub = args.streams if (args.streams > 1 and args.batch >= args.streams) else 1
+    multi = args.streams > 1 and args.batch >= 2 * args.streams
+    nsub = 1                                    # profiled steps are single-stream: one launch per layer in the event list
     # launches of one sub-batch pass, in order (mbn_net_launches): the fused stem (layers 1-3, mbn_stem_fused), fused
     # depthwise->pointwise blocks (mbn_dwpw_fused) and single layers
     launches = [list(range(f - 1, f - 1 + c)) for f, c in net.launches(args.batch)]
@@ -250,9 +256,13 @@ def main():
     ctx.mark()                                  # one HIP event between steps: per-step durations without a sync in the region
     for step in range(args.steps):
         if profile and step in sampled:
+            if multi:
+                net.set_streams(1)                  # this step's kernels are timed one by one: no concurrent kernel beside them
             ctx.profile_pause(False)
             net.forward(d_in.ptr, d_out.ptr, args.batch)
             ctx.profile_pause(True)
+            if multi:
+                net.set_streams(args.streams, free_running=True)
         else:
             net.forward(d_in.ptr, d_out.ptr, args.batch)
         ctx.mark()
@@ -296,7 +306,11 @@ def main():
                                                                          and args.batch == 256) else ""),
                        "global_batch": args.batch * world, "per_gpu_batch": args.batch,
                        "parallelism": "batch-sharded x%d, weights broadcast once over RCCL" % world,
-                       "streams": args.streams, "device": ctx.name()},
+                       "streams": args.streams if multi else 1,
+                       "streams_note": ("sub-batches of %d images on %d forked streams; the %d steps whose kernels are timed one "
+                                        "by one (stages, roofline) run on one stream" % (args.batch // args.streams, args.streams,
+                                                                                          len(sampled) if profile else 0)) if multi else None,
+                       "device": ctx.name()},
         }
         if layer_ms is not None:
             stages, per_layer, stage_of = stage_table(plan, pkg, launches, layer_ms, args.batch, act_bytes, mfma_peak)
@@ -333,10 +347,12 @@ def main():
             out["step_ms"] = {"median": round(float(np.median(step_ms)), 4), "p10": round(float(np.percentile(step_ms, 10)), 4),
                               "p90": round(float(np.percentile(step_ms, 90)), 4), "n": int(step_ms.size),
                               "how": "HIP event between steps on the kernels' stream, no sync inside the timed region"}
-        if world == 1 and profile and not args.no_unfused_stages and nsub == 1:
+        if world == 1 and profile and not args.no_unfused_stages:
             # all 13 depthwise + 13 pointwise stages as their own launches (the metric names per-stage numbers; the timed
             # configuration above folds layers 1-11 into fused launches). UNTIMED: outside the region `value` comes from.
             saved_mask = net.get_fuse_blocks()
+            if multi:
+                net.set_streams(1)
             net.set_fuse_stem(False)
             net.set_fuse_blocks(0)
             ul = [list(range(f - 1, f - 1 + c)) for f, c in net.launches(args.batch)]

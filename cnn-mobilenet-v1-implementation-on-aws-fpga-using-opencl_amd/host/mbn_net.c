@@ -460,6 +460,7 @@ static int forward_impl(mbn_net *net, const void *images, void *logits, int batc
     if (last_layer <= 0 || last_layer > n) last_layer = n;
     int ns = net->nstreams;
     if (layer_ms || ns > batch) ns = 1;                /* per-layer timing serialises; tiny batches are not split */
+    if (ns <= 1) net->fr_images = NULL;                /* a single-stream forward in between: the next multi-stream one forks again */
     if (ns <= 1 && net->use_graph && !layer_ms) {
         /* launch-bound batches: replay the 29 launches as one hipGraph; re-capture when the call's key changes */
         if (net->graph && (net->g_images != images || net->g_logits != logits || net->g_batch != batch ||

@@ -1260,3 +1260,46 @@ def test_bf16_pointwise_ring_kernel(pkg, orc, ctx, shape):
     ctx.sync()
     want = np.clip(xi[:4096].astype(np.float64) @ fi.astype(np.float64).T, 0, 6)
     assert np.array_equal(_bf16_get(pkg, d_o, (m, cout))[:4096].astype(np.float64), orc.bf16_round(want.astype(np.float32)).astype(np.float64))
+
+
+def test_net_free_running_streams_interleaved_with_single_stream(pkg, ctx, tmp_path):
+    """bench.py's default schedule: free-running two-stream forwards (consecutive steps overlap across the step boundary)
+    with a single-stream forward in between (the steps whose kernels are timed one by one), same buffers throughout, a
+    changed batch, and changed input CONTENTS between forwards. Every forward must equal the plain single-stream result:
+    the runner re-inserts the fork whenever the call differs from the previous multi-stream one or a single-stream
+    forward came in between (the ping-pong activation buffers are shared)."""
+    n = 12
+    hw, net = _make_net(pkg, ctx, tmp_path, 0.5, 96, 30, n)
+    rng = np.random.default_rng(17)
+    a, b = (rng.uniform(-1, 1, (n, 96, 96, 3)).astype(np.float32) for _ in range(2))
+    d_in, d_out = ctx.to_device(a), ctx.alloc(n * 30 * 4)
+    def ref(x, k):
+        net.set_streams(1)
+        d_in.upload(x)
+        net.forward(d_in.ptr, d_out.ptr, k)
+        ctx.sync()
+        return d_out.download((k, 30), np.float32)
+    wa, wb, wa5 = ref(a, n), ref(b, n), ref(a, 5)
+    d_in.upload(a)
+    for rep in range(3):
+        net.set_streams(2, free_running=True)
+        for _ in range(4):
+            net.forward(d_in.ptr, d_out.ptr, n)              # back to back: overlap across the step boundary
+        net.set_streams(1)
+        net.forward(d_in.ptr, d_out.ptr, n)                  # single-stream step in between
+        net.set_streams(2, free_running=True)
+        net.forward(d_in.ptr, d_out.ptr, n)
+        ctx.sync()
+        assert np.array_equal(d_out.download((n, 30), np.float32), wa)
+        net.forward(d_in.ptr, d_out.ptr, 5)                  # another batch: other sub-batch slices of the shared buffers
+        net.forward(d_in.ptr, d_out.ptr, n)
+        ctx.sync()
+        assert np.array_equal(d_out.download((n, 30), np.float32), wa)
+    net.forward(d_in.ptr, d_out.ptr, 5)
+    ctx.sync()
+    assert np.array_equal(d_out.download((5, 30), np.float32), wa5)
+    d_in.upload(b)                                           # blocking upload: the documented precondition of free-running
+    net.forward(d_in.ptr, d_out.ptr, n)
+    ctx.sync()
+    assert np.array_equal(d_out.download((n, 30), np.float32), wb)
+    net.destroy()
