@@ -166,6 +166,19 @@ __device__ __forceinline__ void load_row8(const DwArgs &a, const __bf16 *img, in
     for (int j = 0; j < NC; j++) rf[j] = widen8(r[j]);          // each element is widened once, not once per tap
 }
 
+// the packed half of load_row8: issue the loads of one input row, widen later (row prefetch, stride 1)
+template <int NC>
+__device__ __forceinline__ void load_row8_packed(const DwArgs &a, const __bf16 *img, int iy, int ix0, int c, u4v (&r)[NC])
+{
+    const bool rowok = iy >= 0 && iy < a.in_rows;
+    const __bf16 *row = img + ((long)iy * a.in_cols) * a.ch + c;
+#pragma unroll
+    for (int j = 0; j < NC; j++) {
+        const int ix = ix0 + j;
+        r[j] = (rowok && ix >= 0 && ix < a.in_cols) ? *reinterpret_cast<const u4v *>(row + (long)ix * a.ch) : u4v{ 0u, 0u, 0u, 0u };
+    }
+}
+
 template <int STRIDE, int TW>
 __global__ __launch_bounds__(256) void dw3x3_nhwc_bf16x8(DwArgs a)
 {
@@ -200,11 +213,26 @@ __global__ __launch_bounds__(256) void dw3x3_nhwc_bf16x8(DwArgs a)
     int iy = oy0 * STRIDE - a.pad_top;
     load_row8<NC>(a, img, iy, ix0, c, r0);
     if (STRIDE == 1) load_row8<NC>(a, img, iy + 1, ix0, c, r1);
+    // Stride 1: the new input row of output row oy+1 is requested (packed: 16 VGPRs) BEFORE output row oy is computed, so a
+    // lane has two rows of loads in flight instead of one. With the fp32 window, nine fp32 tap vectors and scale/shift this
+    // kernel sits at ~190 VGPRs = 2 waves per SIMD, and with one row (4 KB per wave) in flight the stride-1 layers were
+    // latency-bound at 3.7-4.3 TB/s (the stride-2 lanes request twice the bytes per step and reach 4.9-5.6).
+    u4v pk[NC];
+    if (STRIDE == 1) load_row8_packed<NC>(a, img, iy + 2, ix0, c, pk);
 
     for (int oy = oy0; oy < oy1; oy++) {
         iy = oy * STRIDE - a.pad_top;
-        if (STRIDE == 2) load_row8<NC>(a, img, iy + 1, ix0, c, r1);
-        load_row8<NC>(a, img, iy + 2, ix0, c, r2);
+        if (STRIDE == 2) {
+            load_row8<NC>(a, img, iy + 1, ix0, c, r1);
+            load_row8<NC>(a, img, iy + 2, ix0, c, r2);
+        } else {
+            u4v nx[NC];
+            if (oy + 1 < oy1) load_row8_packed<NC>(a, img, iy + 3, ix0, c, nx);       // next output row's new input row
+#pragma unroll
+            for (int j = 0; j < NC; j++) r2[j] = widen8(pk[j]);
+#pragma unroll
+            for (int j = 0; j < NC; j++) pk[j] = nx[j];
+        }
 #pragma unroll
         for (int p = 0; p < TW; p++) {
             const int j = p * STRIDE;

@@ -422,6 +422,9 @@ int  mbn_net_get_fuse_blocks(const mbn_net *net, unsigned *mask);
 /* The launches the next forward(batch, last_layer) issues per (sub-)batch: launch j covers n_layers[j] layers starting
  * at the 1-based layer first_layer[j] (3 = fused stem, 2 = fused block, 1 = single layer). *count = number of
  * launches; the arrays (may be NULL) receive at most `capacity` entries. */
+/* (The list assumes what mbn_net_forward's own buffers guarantee — 16-byte aligned tensors; a caller-provided `logits` /
+ * last-layer buffer that is not 16-byte aligned makes the fused call answer MBN_EUNSUPPORTED and the forward issue the two
+ * layer calls instead, one launch more than listed.) */
 int  mbn_net_launches(const mbn_net *net, int batch, int last_layer, int *first_layer, int *n_layers, int capacity, int *count);
 /* images: device fp32 NHWC [batch][res][res][3]; logits: device fp32 [batch][classes]. Asynchronous.
  * last_layer: run layers 1..last_layer only (0 or 29 => all; 5 and 13 = BASELINE configs 1-2), in which
