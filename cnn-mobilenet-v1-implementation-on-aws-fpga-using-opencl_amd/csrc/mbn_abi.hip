@@ -66,6 +66,7 @@ static std::atomic<int> *tune_slot(const char *key)
     if (!strcmp(key, "dwpw_variant")) return &g_mbn_tune.dwpw_variant;
     if (!strcmp(key, "pw_xn")) return &g_mbn_tune.pw_xn;
     if (!strcmp(key, "pw_ring")) return &g_mbn_tune.pw_ring;
+    if (!strcmp(key, "lit_dot")) return &g_mbn_tune.lit_dot;
     return nullptr;
 }
 
@@ -130,6 +131,7 @@ int mbn_shutdown(mbn_context *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto &kv : ctx->allocs) (void)hipFree((void *)kv.first);
+    if (ctx->lit_ws) (void)hipFree(ctx->lit_ws);
     ctx->allocs.clear();
     for (hipEvent_t e : ctx->pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->marks) (void)hipEventDestroy(e);

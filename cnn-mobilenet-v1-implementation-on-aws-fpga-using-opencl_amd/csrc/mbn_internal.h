@@ -30,6 +30,8 @@ struct mbn_context {
     bool pool_on = false;
     std::vector<hipEvent_t> marks;               // mbn_mark / mbn_marks_read: step markers (reused across reads)
     size_t marks_used = 0;
+    void *lit_ws = nullptr;                      // LITERAL pointwise on v_dot4: packed int8 filter + per-channel weight sums + flag
+    size_t lit_ws_bytes = 0;
     std::mutex mu;
     std::map<uintptr_t, size_t> allocs;          // buffers handed out by mbn_alloc: base address -> bytes (ordered: mbn_span_check
                                                  // finds the allocation that CONTAINS an interior pointer)
@@ -57,6 +59,7 @@ struct mbn_tunables {
     std::atomic<int> pw_stage{0};     // 1 = register staging instead of direct-to-LDS loads
     std::atomic<int> conv_variant{0}; // conv1 kernel variant
     std::atomic<int> misc{0};
+    std::atomic<int> lit_dot{0};      // LITERAL pointwise: 0 = v_dot4 path where eligible, 1 = always the scalar kernel
     std::atomic<int> pw_ring{0};      // bf16 pointwise: 0 = ring kernel for K = 64, 1 = always pw_gemm, 2 = ring wherever eligible
     std::atomic<int> pw_xn{0};        // pointwise GEMM: XCD groups along n (0 = by filter size, 1 = off, 2, 4)
     std::atomic<int> dwpw_variant{0}; // fused block kernel: 0 = shipped choice per shape, 1 = round-1 producer/consumer kernel, 2 = unified-wave kernel,

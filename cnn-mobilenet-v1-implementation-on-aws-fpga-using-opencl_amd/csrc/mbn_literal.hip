@@ -140,6 +140,101 @@ __global__ __launch_bounds__(64) void lit_pool_carry_k(uint8_t *__restrict__ out
     }
 }
 
+// ------------------------------------------------------------------------------------------------ pointwise on v_dot4
+// the reference's integer MACs (kernel.cl:106-108: sum += in[p + rows*cols*i] * filter[findex]) on the
+// packed-int8 dot unit. Preconditions, checked on the device: MBN_Q_CARRY_SUM off (channels independent) and every filter
+// value in [-128, 127]; otherwise the kernel runs the scalar loop of lit_pointwise_k for the same work (no host round trip
+// to decide). Bit-exact: int32 arithmetic is modular, so  sum_i w_i x_i  =  sum_i w_i (x_i - 128)  +  128 sum_i w_i  (mod 2^32),
+// and x_i - 128 is x_i ^ 0x80 read as int8 — v_dot4_i32_i8 is signed x signed, the activations are unsigned.
+//   pre-pass  lit_pack_filter_k: int32 [oc][cin] -> int8x4 dwords laid out [cin/4][ocp] (8 consecutive oc = one
+//             s_load_dwordx8), per-oc sum of weights, and the "fits" flag;
+//   main      one workgroup = 64 pixels x all output channels: the uint8 planes of the 64 pixels are gathered once into
+//             LDS as [cin/4][64] dwords of 4 consecutive input channels (conflict-free both ways); wave w owns every 16th
+//             block of 8 output channels: per 4 input channels one ds_read_b32, one scalar x8 weight load, eight v_dot4.
+constexpr int LD_PIX = 64, LD_WAVES = 16, LD_OCR = 8;
+
+__global__ __launch_bounds__(256) void lit_pack_filter_k(unsigned *__restrict__ w8, int *__restrict__ wsum, int *__restrict__ bad,
+                                                         const int *__restrict__ filt, int cin, int op_size, int cin4, int ocp)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)cin4 * ocp) return;
+    const int oc = (int)(t % ocp), g = (int)(t / ocp);
+    unsigned pk = 0;
+    int sum = 0;
+    bool ok = true;
+    if (oc < op_size)
+        for (int j = 0; j < 4; j++) {
+            const int ic = 4 * g + j;
+            const int w = ic < cin ? filt[(long)oc * cin + ic] : 0;
+            ok = ok && w >= -128 && w <= 127;
+            pk |= ((unsigned)w & 0xffu) << (8 * j);
+            sum += w;
+        }
+    w8[t] = pk;
+    if (sum) atomicAdd(&wsum[oc], sum);
+    if (!ok) atomicOr(bad, 1);
+}
+
+__global__ __launch_bounds__(64 * LD_WAVES) void lit_pointwise_dot_k(uint8_t *__restrict__ out, const uint8_t *__restrict__ in,
+                                                                     const int *__restrict__ filt, const unsigned *__restrict__ w8,
+                                                                     const int *__restrict__ wsum, const int *__restrict__ bad,
+                                                                     long plane, int cin, int op_size, int cin4, int ocp, long in_image)
+{
+    extern __shared__ unsigned xs[];                       // [cin4][64] dwords: 4 consecutive input channels of one pixel, x ^ 0x80
+    const int n = blockIdx.z, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long p = (long)blockIdx.x * LD_PIX + lane;
+    const bool pok = p < plane;
+    const uint8_t *ip = in + n * in_image + p;
+    uint8_t *o = out + n * plane * op_size + p;
+    if (*bad) {
+        // a filter value outside int8: the scalar loop (lit_pointwise_k without the carry), output channels split over the waves
+        if (!pok) return;
+        for (int oc = wave; oc < op_size; oc += LD_WAVES) {
+            int sum = 0;
+            const int *f = filt + (long)oc * cin;
+            for (int i = 0; i < cin; i++) sum = mac_i32(sum, ip[plane * i], f[i]);
+            if (sum <= 0) sum = 0;
+            o[plane * oc] = (uint8_t)sum;
+        }
+        return;
+    }
+    // gather: wave w takes the channel quads w, w+16, ...; lanes run along pixels, so the four byte loads are contiguous
+    for (int g = wave; g < cin4; g += LD_WAVES) {
+        unsigned pk = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int ic = 4 * g + j;
+            const unsigned b = (pok && ic < cin) ? ip[plane * ic] : 0u;
+            pk |= b << (8 * j);
+        }
+        xs[g * LD_PIX + lane] = pk ^ 0x80808080u;
+    }
+    __syncthreads();
+    for (int ob = wave * LD_OCR; ob < ocp; ob += LD_WAVES * LD_OCR) {
+        int acc[LD_OCR];
+#pragma unroll
+        for (int j = 0; j < LD_OCR; j++) acc[j] = 0;
+        for (int g = 0; g < cin4; g++) {
+            const int x = (int)xs[g * LD_PIX + lane];
+            const unsigned *wr = w8 + (long)g * ocp + ob;                    // wave-uniform: scalar loads
+#pragma unroll
+            for (int j = 0; j < LD_OCR; j++) acc[j] = __builtin_amdgcn_sdot4(x, (int)wr[j], acc[j], false);
+        }
+        if (pok) {
+#pragma unroll
+            for (int j = 0; j < LD_OCR; j++) {
+                const int oc = ob + j;
+                if (oc < op_size) {
+                    int sum = (int)((unsigned)acc[j] + 128u * (unsigned)wsum[oc]);   // + 128 * sum of weights (mod 2^32)
+                    if (sum <= 0) sum = 0;
+                    o[plane * oc] = (uint8_t)sum;
+                }
+            }
+        }
+    }
+}
+
 }   // namespace
 
 // The emulated NDRange must not make two work-items write one byte (the reference's 224x224 launch over a
@@ -184,6 +279,28 @@ int mbn_launch_lit_pointwise(const mbn_call &c, uint8_t *out, const uint8_t *in,
                              int cols, int cin, int op_size)
 {
     const long plane = (long)rows * cols;
+    // v_dot4 path: channels independent (no carry quirk), on the context's own stream (the packed filter lives
+    // in a per-context workspace), LDS tile within 64 KB; tune lit_dot = 1 keeps the scalar kernel (A/B hook)
+    const int cin4 = (cin + 3) / 4, ocp = (op_size + LD_OCR - 1) / LD_OCR * LD_OCR;
+    if (!(c.quirks & MBN_Q_CARRY_SUM) && c.stream == c.ctx->stream && g_mbn_tune.lit_dot != 1 && cin4 * LD_PIX * 4 <= 65536 &&
+        cin >= 8 && op_size >= 8) {
+        const size_t need = (size_t)cin4 * ocp * 4 + (size_t)ocp * 4 + 256;
+        if (c.ctx->lit_ws_bytes < need) {
+            if (c.ctx->lit_ws) { (void)hipStreamSynchronize(c.stream); (void)hipFree(c.ctx->lit_ws); c.ctx->lit_ws = nullptr; c.ctx->lit_ws_bytes = 0; }
+            if (hipMalloc(&c.ctx->lit_ws, need) != hipSuccess) return MBN_ENOMEM;
+            c.ctx->lit_ws_bytes = need;
+        }
+        unsigned *w8 = (unsigned *)c.ctx->lit_ws;
+        int *wsum = (int *)(w8 + (size_t)cin4 * ocp), *bad = wsum + ocp;
+        (void)hipMemsetAsync(wsum, 0, (size_t)ocp * 4 + 4, c.stream);
+        const long nt = (long)cin4 * ocp;
+        hipLaunchKernelGGL(lit_pack_filter_k, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, c.stream, w8, wsum, bad, filt, cin,
+                           op_size, cin4, ocp);
+        dim3 grid((unsigned)((plane + LD_PIX - 1) / LD_PIX), 1, c.batch);
+        hipLaunchKernelGGL(lit_pointwise_dot_k, grid, dim3(64 * LD_WAVES), (size_t)cin4 * LD_PIX * 4, c.stream, out, in, filt, w8,
+                           wsum, bad, plane, cin, op_size, cin4, ocp, plane * cin);
+        return MBN_OK;
+    }
     dim3 grid((unsigned)((plane + 255) / 256), 1, c.batch);
     // the input image holds `cin` planes (the caller's buffer may hold more; batch stride uses cin)
     hipLaunchKernelGGL(lit_pointwise_k, grid, dim3(256), 0, c.stream, out, in, filt, plane, cin, op_size, c.quirks,

@@ -480,6 +480,7 @@ const char *mbn_version(void);
  *                4-channel lanes
  *   dw_nseg      depthwise: row segments per image
  *   net_stagger  layers between the starts of consecutive sub-batch streams (mbn_net_set_streams)
+ *   lit_dot      LITERAL pointwise: 0 = v_dot4_i32_i8 path where eligible (no carry quirk, filter fits int8), 1 = scalar kernel
  *   pw_ring      bf16 pointwise: 0 = streaming ring kernel for K = 64 (shipped), 1 = always the tiled GEMM, 2 = ring wherever eligible
  *   pw_xn        pointwise GEMM tile order: XCD groups along n (0 = by filter size, 1 = single ordering, 2, 4)
  *   dwpw_variant fused block kernel: 0 = shipped choice, 1 = round-1 producer/consumer kernels, 2 = unified-wave kernels,

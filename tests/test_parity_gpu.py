@@ -1303,3 +1303,39 @@ def test_net_free_running_streams_interleaved_with_single_stream(pkg, ctx, tmp_p
     ctx.sync()
     assert np.array_equal(d_out.download((n, 30), np.float32), wb)
     net.destroy()
+
+
+@pytest.mark.parametrize("shape", [(14, 14, 32, 64, 1), (7, 7, 1024, 1024, 2), (9, 5, 30, 13, 1), (1, 1, 1024, 1000, 3), (28, 28, 130, 20, 1), (56, 56, 64, 128, 1)])
+def test_literal_pointwise_on_dot4_is_bit_exact(pkg, orc, ctx, shape):
+    """the reference's integer pointwise (kernel.cl:94-114, quirks off) on v_dot4_i32_i8 — bit-exact against the
+    oracle and against the scalar LITERAL kernel (tune lit_dot=1): random int8-range filters incl. the extremes -128 / 127,
+    activations over the whole uint8 range (the x - 128 re-centring and its 128 * sum(w) correction), Cin not a multiple of
+    4, Cout not a multiple of 8, planes not a multiple of 64, batch > 1; and a filter with ONE value outside int8, for which
+    the kernel must fall back to the scalar loop on the device."""
+    rows, cols, cin, oc, n = shape
+    rng = np.random.default_rng(rows * 100 + cin + oc)
+    x = rng.integers(0, 256, (n, cin, rows, cols), dtype=np.uint8)
+    f = rng.integers(-128, 128, (oc, cin), dtype=np.int32)
+    f[0, 0], f[-1, -1] = -128, 127
+    d_x, d_f = ctx.to_device(x), ctx.to_device(f)
+    d_o, d_s = ctx.alloc(n * oc * rows * cols), ctx.alloc(n * oc * rows * cols)
+    ext = pkg.make_ext(batch=n, dtype=pkg.DT_U8, quirks=0)
+    for trial in range(2):
+        want = np.stack([orc.lit_pointwise(x[i], f, rows, cols, cin, oc, quirks=0) for i in range(n)])
+        ctx.pointwise(d_o.ptr, d_x.ptr, d_f.ptr, rows, cols, cin, oc, ext)
+        try:
+            assert ctx.lib.mbn_tune_set(b"lit_dot", 1) == 0
+            ctx.pointwise(d_s.ptr, d_x.ptr, d_f.ptr, rows, cols, cin, oc, ext)
+        finally:
+            ctx.lib.mbn_tune_set(b"lit_dot", 0)
+        ctx.sync()
+        got, scalar = d_o.download(want.shape, np.uint8), d_s.download(want.shape, np.uint8)
+        assert np.array_equal(scalar, want)
+        assert np.array_equal(got, want), "trial %d: %d of %d bytes differ" % (trial, int((got != want).sum()), want.size)
+        f[oc // 2, cin // 2] = 300 if trial == 0 else f[oc // 2, cin // 2]       # second trial: one value outside int8 -> device fallback
+        d_f.upload(f)
+    # with the carry quirk the channels are a serial chain: the call must still be right (scalar kernel)
+    wantc = orc.lit_pointwise(x[0], f, rows, cols, cin, oc, quirks=1)
+    ctx.pointwise(d_o.ptr, d_x.ptr, d_f.ptr, rows, cols, cin, oc, pkg.make_ext(dtype=pkg.DT_U8, quirks=1))
+    ctx.sync()
+    assert np.array_equal(d_o.download(wantc.shape, np.uint8), wantc)
