@@ -126,6 +126,7 @@ def load():
         lib.mbn_shutdown.argtypes = [vp]
         lib.mbn_device_count.argtypes = [C.POINTER(ci)]
         lib.mbn_device_name.argtypes = [vp, C.c_char_p, C.c_size_t]
+        lib.mbn_device_cus.argtypes = [vp, C.POINTER(C.c_int)]
         lib.mbn_set_literal_quirks.argtypes = [vp, C.c_uint32]
         lib.mbn_get_stream.argtypes = [vp, C.POINTER(vp)]
         lib.mbn_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]

@@ -66,6 +66,7 @@ static std::atomic<int> *tune_slot(const char *key)
     if (!strcmp(key, "dwpw_variant")) return &g_mbn_tune.dwpw_variant;
     if (!strcmp(key, "pw_xn")) return &g_mbn_tune.pw_xn;
     if (!strcmp(key, "pw_ring")) return &g_mbn_tune.pw_ring;
+    if (!strcmp(key, "pw_splitk")) return &g_mbn_tune.pw_splitk;
     if (!strcmp(key, "lit_dot")) return &g_mbn_tune.lit_dot;
     return nullptr;
 }
@@ -147,6 +148,13 @@ int mbn_device_name(mbn_context *ctx, char *buf, size_t buflen)
 {
     if (!ctx || !buf || buflen == 0) return MBN_EINVAL;
     snprintf(buf, buflen, "%s", ctx->name);
+    return MBN_OK;
+}
+
+int mbn_device_cus(mbn_context *ctx, int *count)
+{
+    if (!ctx || !count) return MBN_EINVAL;
+    *count = ctx->num_cus;
     return MBN_OK;
 }
 

@@ -19,6 +19,7 @@ struct mbn_net {
     mbn_context *ctx;
     mbn_plan plan;
     int max_batch;
+    int num_cus;               /* compute units of the context's GPU (small-batch fusion rule) */
     void *dev_blob;
     int own_blob;
     void *act[2];
@@ -63,6 +64,8 @@ static int net_alloc_common(mbn_context *ctx, const mbn_plan *plan, int max_batc
     net->fuse_blocks = MBN_FUSE_BLOCKS_DEFAULT;
     net->plan = *plan;
     net->max_batch = max_batch;
+    net->num_cus = 256;
+    (void)mbn_device_cus(ctx, &net->num_cus);
     size_t bytes = (size_t)plan->max_act_floats * (size_t)max_batch * sizeof(float);
     int rc = mbn_alloc(ctx, bytes, &net->act[0]);
     if (rc == MBN_OK) rc = mbn_alloc(ctx, bytes, &net->act[1]);
@@ -215,6 +218,17 @@ static int block_fusable(const mbn_net *net, int i, int count, int last_layer)
     /* bf16 default: the block kernel recomputes the depthwise chunk once per 256-column tile and is bound by that VALU work,
      * so a block wider than one tile measures slower fused than as two launches; an explicit mask overrides */
     if (bf && !net->fuse_blocks_set && net->plan.layer[i + 1].out_ch > 256) return 0;
+    /* default, fp32: a block kernel workgroup walks 128 output pixels through the WHOLE block (all depthwise chunks, then
+     * K/2 matrix instructions per chunk, one after the other), so when the launch has fewer 128 x 128 output tiles than half
+     * the compute units the two separate launches — more, shorter workgroups — are faster (batch 1: -28 us per forward,
+     * break-even at batch 4-8 for blocks 4-7 and 16 for blocks 8-11: profiles/r02/i_small_batch.txt). fp32 results are
+     * bit-identical either way, so the choice may depend on the batch. In bf16 the fused blocks stay (measured faster at every
+     * batch from 1 up: the stand-alone bf16 pointwise has no few-tile form). */
+    if (!bf && !net->fuse_blocks_set) {
+        const mbn_layer_desc *q = &net->plan.layer[i + 1];
+        const long tiles = (((long)count * q->out_rows * q->out_cols + 127) / 128) * ((q->out_ch + 127) / 128);
+        if (tiles * 2 < net->num_cus) return 0;
+    }
     if (((uintptr_t)net->dev_blob % 16) != 0) return 0;            /* see stem_fusable */
     const mbn_layer_desc *d = &net->plan.layer[i], *p = &net->plan.layer[i + 1];
     if (d->kind != MBN_L_DW || p->kind != MBN_L_PW || (d->stride != 1 && d->stride != 2)) return 0;
@@ -265,7 +279,7 @@ int mbn_net_launches(const mbn_net *net, int batch, int last_layer, int *first_l
     if (!net || !count || batch <= 0) return MBN_EINVAL;
     if (last_layer <= 0 || last_layer > net->plan.n_layers) last_layer = net->plan.n_layers;
     int ns = net->nstreams;
-    if (ns > batch) ns = 1;
+    if (batch < 5 * ns) ns = 1;                        /* as forward_impl */
     const int sub = ns > 1 ? batch / ns + (batch % ns ? 1 : 0) : batch;      /* the largest sub-batch decides the envelope */
     int n = 0, i = 0;
     while (i < last_layer) {
@@ -459,7 +473,9 @@ static int forward_impl(mbn_net *net, const void *images, void *logits, int batc
     const int n = net->plan.n_layers;
     if (last_layer <= 0 || last_layer > n) last_layer = n;
     int ns = net->nstreams;
-    if (layer_ms || ns > batch) ns = 1;                /* per-layer timing serialises; tiny batches are not split */
+    if (layer_ms || batch < 5 * ns) ns = 1;            /* per-layer timing serialises; sub-batches of fewer than 5 images are not
+                                                        * forked: they would take the 1..4-image kernels (mbn_f32_pw_splitk.hip), whose
+                                                        * summation order differs from the single-stream forward of the whole batch */
     if (ns <= 1) net->fr_images = NULL;                /* a single-stream forward in between: the next multi-stream one forks again */
     if (ns <= 1 && net->use_graph && !layer_ms) {
         /* launch-bound batches: replay the 29 launches as one hipGraph; re-capture when the call's key changes */

@@ -133,6 +133,8 @@ int  mbn_init(int device_ordinal, mbn_context **ctx);
 int  mbn_shutdown(mbn_context *ctx);
 int  mbn_device_count(int *count);                       /* 0 devices => *count = 0, MBN_OK */
 int  mbn_device_name(mbn_context *ctx, char *buf, size_t buflen);
+int  mbn_device_cus(mbn_context *ctx, int *count);       /* compute units of the context's GPU (256 on MI355X): the counterpart of
+                                                          * CL_DEVICE_MAX_COMPUTE_UNITS; the net runner sizes its small-batch choices by it */
 const char *mbn_last_device_error(mbn_context *ctx);     /* text of the last HIP error seen by this context */
 int  mbn_set_literal_quirks(mbn_context *ctx, uint32_t quirks);
 int  mbn_get_stream(mbn_context *ctx, void **stream);    /* the context's hipStream_t */
@@ -209,6 +211,10 @@ int mbn_depthwise(mbn_context *ctx, void *output, const void *inp_image, const v
 /* pointwise (kernel.cl:94): 1x1 conv = per-pixel [op_size x filtersize] mat-vec; FC when rows=cols=1.
  *   filtersize = number of INPUT channels (loop bound kernel.cl:106, plane stride :107)
  *   filter     = [op_size][filtersize] in both modes (int32 / fp32)
+ *   F32 summation order over the input channels: sequential (pw_gemm) for every call of 5 images and more; a call of
+ *   ext->batch <= 4 images of a layer with few output tiles (its 4-image form has fewer 64x64 tiles than half the compute
+ *   units; K >= 128, K % 64 == 0) runs the split-K kernel: K in 4 / 8 / 16 slices (by K alone) summed in fixed order.
+ *   Either way a result depends on the layer and on "1..4 images or more", never on the batch-mates or the slot.
  */
 int mbn_pointwise(mbn_context *ctx, void *output, const void *inp_image, const void *filter_k,
                   int rows, int cols, int filtersize, int op_size, const mbn_layer_ext *ext);
@@ -409,8 +415,12 @@ int  mbn_net_fused_layers(const mbn_net *net, int last_layer, int *count);
 /* Fused depthwise->pointwise blocks (mbn_dwpw_fused): bit L of `mask` (L = 1-based number of a depthwise layer) lets
  * layers L and L+1 run as one launch when the plan is fp32, activations are not kept and the shapes are inside the
  * kernel's envelope. Default (until this is called) = MBN_FUSE_BLOCKS_DEFAULT in fp32, MBN_FUSE_BLOCKS_DEFAULT_BF16 in bf16
- * mode: the blocks measured faster fused at batch 256 / 512 on MI355X; 0 = every layer its own launch. fp32
- * results are bit-identical either way. */
+ * mode: the blocks measured faster fused at batch 256 / 512 on MI355X; 0 = every layer its own launch.
+ * Under the fp32 DEFAULT a block is fused only when its launch has at least (compute units / 2) output tiles of 128 x 128
+ * (1.0x224: blocks 4-7 from 6 images, blocks 8-11 from 11): below that two shorter launches are faster, and batch 1 runs the
+ * stem + 26 single layers; an explicit mask is taken as given. fp32 results are bit-identical either way for calls of 5
+ * images and more; for 1..4 images a stand-alone pointwise layer in the few-tile regime takes the split-K kernel
+ * (mbn_pointwise), whose summation order differs from the block kernel's in the last bits. */
 #define MBN_FUSE_BLOCKS_DEFAULT ((1u << 4) | (1u << 6) | (1u << 8) | (1u << 10))
 /* bf16 mode: the matrix work is a sixteenth of fp32's and a block is bound by HBM and the depthwise VALU work: one launch
  * that never writes the depthwise output wins on every block inside the kernel's envelope whose pointwise layer is at
@@ -473,7 +483,8 @@ const char *mbn_version(void);
  * (tools/layer_bench.py, tools/block_bench.py). 0 always means "the shipped default". Unknown key => MBN_ENOTFOUND.
  *   pw_tile      1..8: GEMM tile shape of mbn_pointwise (see mbn_f32_pw.hip); 1 also forces the 128-column tile of
  *                mbn_dwpw_fused(_bf16)
- *   misc         workgroups per CU of the persistent GEMM grid (1000 = one tile per workgroup)
+ *   misc         workgroups per CU of the persistent GEMM grid (1000 = one tile per workgroup); in the split-K kernel 16 / 32 =
+ *                force the 16x16 / 32x32 workgroup tile
  *   pw_stage     1 = stage GEMM operands through registers instead of direct-to-LDS loads
  *   conv_variant 1 = generic conv1 kernel; 8 = GEMM without the software-pipelined k-loop; 9 = GEMM with the general epilogue
  *   dw_variant   depthwise: bits 0-1 = output columns per lane, bit 4 = lanes across all channels, bit 5 = bf16 with
@@ -482,6 +493,8 @@ const char *mbn_version(void);
  *   net_stagger  layers between the starts of consecutive sub-batch streams (mbn_net_set_streams)
  *   lit_dot      LITERAL pointwise: 0 = v_dot4_i32_i8 path where eligible (no carry quirk, filter fits int8), 1 = scalar kernel
  *   pw_ring      bf16 pointwise: 0 = streaming ring kernel for K = 64 (shipped), 1 = always the tiled GEMM, 2 = ring wherever eligible
+ *   pw_splitk    fp32 pointwise of 1..4 images in the few-tile regime: 0 = split-K kernel (mbn_f32_pw_splitk.hip), 1 = always the
+ *                tiled GEMM, 2 = split-K wherever the shape allows (K >= 128, K % 64 == 0), whatever the batch
  *   pw_xn        pointwise GEMM tile order: XCD groups along n (0 = by filter size, 1 = single ordering, 2, 4)
  *   dwpw_variant fused block kernel: 0 = shipped choice, 1 = round-1 producer/consumer kernels, 2 = unified-wave kernels,
  *                3 = unified fp32 with the taps read inside the step, 100 + bits = unified with parts switched off */

@@ -371,11 +371,20 @@ def test_net_full_size_properties(pkg, ctx, tmp_path):
     net.forward(d_in.ptr, d_out.ptr, 16)
     ctx.sync()
     assert np.array_equal(a[perm], d_out.download((16, 1000), np.float32))
-    d_in.upload(imgs[:3])
-    net.forward(d_in.ptr, d_out.ptr, 3)
+    d_in.upload(imgs[:7])
+    net.forward(d_in.ptr, d_out.ptr, 7)
     ctx.sync()
-    b = d_out.download((3, 1000), np.float32)
-    assert np.array_equal(b, a[:3])                                # a smaller batch changes tiles, not sums
+    b = d_out.download((7, 1000), np.float32)
+    assert np.array_equal(b, a[:7])                                # a smaller batch changes tiles, not sums
+    d_in.upload(imgs[:3])                                          # 1..4 images: the split-K pointwise kernel, another
+    net.forward(d_in.ptr, d_out.ptr, 3)                            # summation order — equal within the fp32 tolerance,
+    ctx.sync()                                                     # and bit-equal among themselves
+    c3 = d_out.download((3, 1000), np.float32)
+    assert_close(c3, a[:3], TOL_NET, "3 images vs the same images in a batch of 16")
+    d_in.upload(imgs[1:3])
+    net.forward(d_in.ptr, d_out.ptr, 2)
+    ctx.sync()
+    assert np.array_equal(d_out.download((2, 1000), np.float32), c3[1:3])
     d_in.upload(imgs)
     ms = net.forward_timed(d_in.ptr, d_out.ptr, 16)
     ctx.sync()
@@ -387,17 +396,29 @@ def test_net_full_size_properties(pkg, ctx, tmp_path):
 def test_net_batch_slice_equals_smaller_batch(pkg, ctx, tmp_path):
     """Sharding property used by the multi-GPU path: forward(images[a:b]) == forward(images)[a:b].
     Tile shapes differ between batch sizes (M changes), so pointwise rows may be summed by different
-    workgroups — but each row's k-order is fixed by the kernel, so results are bit-identical."""
-    hw, net = _make_net(pkg, ctx, tmp_path, 0.5, 128, 100, 8)
-    imgs = np.random.default_rng(4).uniform(-1, 1, (8, 128, 128, 3)).astype(np.float32)
-    d_in, d_out = ctx.to_device(imgs), ctx.alloc(8 * 100 * 4)
-    net.forward(d_in.ptr, d_out.ptr, 8)
+    workgroups — but each row's k-order is fixed by the kernel, so results are bit-identical: among calls of 5 images and
+    more (pw_gemm everywhere) and among calls of 1..4 images (the split-K kernel picks its split by K alone)."""
+    hw, net = _make_net(pkg, ctx, tmp_path, 0.5, 128, 100, 16)
+    imgs = np.random.default_rng(4).uniform(-1, 1, (16, 128, 128, 3)).astype(np.float32)
+    d_in, d_out = ctx.to_device(imgs), ctx.alloc(16 * 100 * 4)
+    net.forward(d_in.ptr, d_out.ptr, 16)
     ctx.sync()
-    full = d_out.download((8, 100), np.float32)
-    d_in.upload(imgs[4:8])
+    full = d_out.download((16, 100), np.float32)
+    for a, b in ((8, 16), (3, 8), (11, 16)):
+        d_in.upload(imgs[a:b])
+        net.forward(d_in.ptr, d_out.ptr, b - a)
+        ctx.sync()
+        assert np.array_equal(full[a:b], d_out.download((b - a, 100), np.float32)), (a, b)
+    d_in.upload(imgs[:4])
     net.forward(d_in.ptr, d_out.ptr, 4)
     ctx.sync()
-    assert np.array_equal(full[4:8], d_out.download((4, 100), np.float32))
+    four = d_out.download((4, 100), np.float32)
+    assert_close(four, full[:4], TOL_NET, "1..4-image kernels vs the large-batch ones")
+    for a, b in ((0, 1), (1, 3), (3, 4), (0, 3)):
+        d_in.upload(imgs[a:b])
+        net.forward(d_in.ptr, d_out.ptr, b - a)
+        ctx.sync()
+        assert np.array_equal(four[a:b], d_out.download((b - a, 100), np.float32)), (a, b)
     net.destroy()
 
 
@@ -595,24 +616,30 @@ def test_bf16_net_per_layer(pkg, orc, ctx, tmp_path, cfg):
 @pytest.mark.parametrize("ns", [2, 3, 8])
 def test_net_multi_stream_equals_single_stream(pkg, ctx, tmp_path, ns):
     """mbn_net_set_streams: sub-batches on forked/joined streams give bit-identical logits, also for a batch that does
-    not divide evenly and for a following operation queued on the context's stream (join ordering)."""
-    hw, net = _make_net(pkg, ctx, tmp_path, 0.5, 96, 40, 11)
-    imgs = np.random.default_rng(6).uniform(-1, 1, (11, 96, 96, 3)).astype(np.float32)
-    d_in, d_out, d_p, d_a = ctx.to_device(imgs), ctx.alloc(11 * 40 * 4), ctx.alloc(11 * 40 * 4), ctx.alloc(11 * 4)
-    net.forward(d_in.ptr, d_out.ptr, 11)
+    not divide evenly and for a following operation queued on the context's stream (join ordering). Sub-batches of fewer
+    than 5 images are not forked (they would take the 1..4-image kernels): such a forward equals the single-stream one."""
+    n = 5 * ns + 1
+    hw, net = _make_net(pkg, ctx, tmp_path, 0.5, 96, 40, n)
+    imgs = np.random.default_rng(6).uniform(-1, 1, (n, 96, 96, 3)).astype(np.float32)
+    d_in, d_out, d_p, d_a = ctx.to_device(imgs), ctx.alloc(n * 40 * 4), ctx.alloc(n * 40 * 4), ctx.alloc(n * 4)
+    net.forward(d_in.ptr, d_out.ptr, n)
     ctx.sync()
-    want = d_out.download((11, 40), np.float32)
+    want = d_out.download((n, 40), np.float32)
+    net.forward(d_in.ptr, d_out.ptr, 2)
+    ctx.sync()
+    want2 = d_out.download((2, 40), np.float32)
     net.set_streams(ns)
     for _ in range(3):
-        ctx.lib.mbn_memset(ctx.h, d_out.ptr, 0xFF, 11 * 40 * 4)       # queued on the context stream BEFORE the fork
-        net.forward(d_in.ptr, d_out.ptr, 11)
-        assert ctx.lib.mbn_softmax_f32(ctx.h, d_p.ptr, d_a.ptr, d_out.ptr, 11, 40, None) == 0   # after the join
+        ctx.lib.mbn_memset(ctx.h, d_out.ptr, 0xFF, n * 40 * 4)        # queued on the context stream BEFORE the fork
+        net.forward(d_in.ptr, d_out.ptr, n)
+        assert ctx.lib.mbn_softmax_f32(ctx.h, d_p.ptr, d_a.ptr, d_out.ptr, n, 40, None) == 0    # after the join
         ctx.sync()
-        assert np.array_equal(d_out.download((11, 40), np.float32), want)
-        assert np.array_equal(d_a.download((11,), np.int32), want.argmax(1))
-    net.forward(d_in.ptr, d_out.ptr, 2)                               # fewer images than streams
+        assert np.array_equal(d_out.download((n, 40), np.float32), want)
+        assert np.array_equal(d_a.download((n,), np.int32), want.argmax(1))
+    net.forward(d_in.ptr, d_out.ptr, 2)                               # too few images to fork
     ctx.sync()
-    assert np.array_equal(d_out.download((2, 40), np.float32), want[:2])
+    assert np.array_equal(d_out.download((2, 40), np.float32), want2)
+    assert_close(want2, want[:2], TOL_NET, "1..4-image kernels vs the large-batch ones")
     net.destroy()
 
 
@@ -753,10 +780,21 @@ def test_f32_dwpw_fused(pkg, orc, ctx, shape):
     assert rc == 0, rc
     ctx.depthwise(d_m.ptr, d[0].ptr, d[1].ptr, oh, oh, 3, stride, cin,
                   pkg.make_ext(batch=n, act=2, pad_top=pad, pad_left=pad, in_rows=h, in_cols=h, scale=d[2].ptr, shift=d[3].ptr))
-    ctx.pointwise(d_u.ptr, d_m.ptr, d[4].ptr, n * oh * oh, 1, cin, cout, pkg.make_ext(batch=1, act=2, scale=d[5].ptr, shift=d[6].ptr))
+    pw_ext = pkg.make_ext(batch=1, act=2, scale=d[5].ptr, shift=d[6].ptr)
+    ctx.pointwise(d_u.ptr, d_m.ptr, d[4].ptr, n * oh * oh, 1, cin, cout, pw_ext)
     ctx.sync()
     fused, unfused = d_f.download(want.shape, np.float32), d_u.download(want.shape, np.float32)
     assert_close(fused, want, TOL_PW, "dwpw %s vs oracle" % (shape,))
+    assert_close(fused, unfused, TOL_PW, "dwpw %s vs depthwise+pointwise" % (shape,))
+    # bit-identical with the pointwise layer on pw_gemm (the kernel every call of 5 and more images takes; a few-tile call of
+    # 1..4 images takes the split-K kernel, whose summation order is another one)
+    try:
+        assert ctx.lib.mbn_tune_set(b"pw_splitk", 1) == 0
+        ctx.pointwise(d_u.ptr, d_m.ptr, d[4].ptr, n * oh * oh, 1, cin, cout, pw_ext)
+    finally:
+        ctx.lib.mbn_tune_set(b"pw_splitk", 0)
+    ctx.sync()
+    unfused = d_u.download(want.shape, np.float32)
     assert np.array_equal(fused, unfused), "fused block differs from depthwise+pointwise by %g" % np.abs(fused - unfused).max()
     for b in d + [d_f, d_m, d_u]:
         b.free()
@@ -779,12 +817,16 @@ def test_net_fused_blocks_equal_separate_layers(pkg, orc, ctx, tmp_path):
     """Net runner with depthwise->pointwise blocks fused (mbn_net_set_fuse_blocks) vs every layer its own launch:
     identical logits and identical partial outputs (last_layer inside/at the end of a fused block); the launch list
     mbn_net_launches reports matches the mask; the oracle bounds the result."""
-    n, res = 3, 64
+    n, res = 5, 64
     hw, net = _make_net(pkg, ctx, tmp_path, 1.0, res, 20, n)
     imgs = np.random.default_rng(11).uniform(-1, 1, (n, res, res, 3)).astype(np.float32)
     d_in = ctx.to_device(imgs)
-    assert net.launches(n)[:5] == [(1, 3), (4, 2), (6, 2), (8, 2), (10, 2)]   # default mask: stem + blocks 4, 6, 8, 10
-    assert (12, 1) in net.launches(n)
+    # default mask: stem + blocks 4, 6, 8, 10 — each only from the batch at which its launch has enough 128 x 128 tiles
+    # (half the compute units; below that two shorter launches are faster: profiles/r02/i_small_batch.txt)
+    assert net.launches(256)[:5] == [(1, 3), (4, 2), (6, 2), (8, 2), (10, 2)]
+    assert (12, 1) in net.launches(256)
+    assert net.launches(n) == [(1, 3)] + [(l, 1) for l in range(4, 30)]
+    assert net.launches(64)[:4] == [(1, 3), (4, 2), (6, 2), (8, 1)]
     outs = {}
     for mask in (0xFFFFFFFE, 0):
         net.set_fuse_blocks(mask)
@@ -991,7 +1033,8 @@ def test_net_full_size_fused_equals_unfused(pkg, ctx, tmp_path, n):
     d_u, d_f = ctx.to_device(u8), ctx.alloc(u8.size * 4)
     assert ctx.lib.mbn_normalize_u8_to_f32(ctx.h, d_f.ptr, d_u.ptr, u8.size, 1 / 127.5, -1.0, None) == 0
     d_a, d_b, d_c = ctx.alloc(n * 4000), ctx.alloc(n * 4000), ctx.alloc(n * 4000)
-    assert [c for _, c in net.launches(n)][:5] == [3, 2, 2, 2, 2]
+    assert [c for _, c in net.launches(n)][:5] == ([3, 2, 2, 2, 2] if n == 24 else [3, 2, 2, 1, 1])   # blocks 8, 10: from batch 11
+    assert [c for _, c in net.launches(1)] == [3] + [1] * 26                                           # batch 1: only the stem
     net.forward(d_f.ptr, d_a.ptr, n)
     net.set_fuse_stem(False)
     net.set_fuse_blocks(0)
@@ -1260,6 +1303,77 @@ def test_bf16_pointwise_ring_kernel(pkg, orc, ctx, shape):
     ctx.sync()
     want = np.clip(xi[:4096].astype(np.float64) @ fi.astype(np.float64).T, 0, 6)
     assert np.array_equal(_bf16_get(pkg, d_o, (m, cout))[:4096].astype(np.float64), orc.bf16_round(want.astype(np.float32)).astype(np.float64))
+
+
+@pytest.mark.parametrize("shape", [(196, 512, 512, 1), (49, 1024, 1024, 1), (4 * 196, 256, 512, 4), (3 * 49 , 512, 1024, 3), (1, 1024, 1000, 1),
+                                   (4, 1024, 1000, 4), (2 * 25, 128, 256, 2), (37, 192, 40, 1), (100, 320, 72, 1), (2 * 81, 384, 104, 2)])
+def test_f32_pointwise_splitk_kernel(pkg, orc, ctx, shape):
+    """mbn_f32_pw_splitk.hip (1..4 images, few tiles: one 16x16 tile per workgroup, K split over its 4/8/16 waves, partial
+    tiles summed in LDS in fixed order): against the oracle, against pw_gemm (tune pw_splitk=1) within the fp32 tolerance,
+    bit-exactly on integer operands with an asymmetric filter (operand / C-D lane maps, k permutation, ragged rows and
+    columns, every S and CH instantiation: K = 128, 192, 256, 320, 384, 512, 1024), and repeatably (no atomics)."""
+    m, cin, cout, batch = shape
+    rng = np.random.default_rng(m + cin + cout)
+    x = rng.uniform(-1, 1, (m, cin)).astype(np.float32)
+    f = rng.normal(0, (2.0 / cin) ** 0.5, (cout, cin)).astype(np.float32)
+    sc, sh = rng.uniform(0.5, 1.5, cout).astype(np.float32), rng.normal(0, 0.1, cout).astype(np.float32)
+    want = orc.f32_pointwise(x, f, sc, sh, 2)
+    d_x, d_f, d_sc, d_sh = (ctx.to_device(a) for a in (x, f, sc, sh))
+    d_o, d_p = ctx.alloc(want.nbytes + 64), ctx.alloc(want.nbytes)
+    ext = pkg.make_ext(batch=batch, act=2, scale=d_sc.ptr, shift=d_sh.ptr)
+    try:
+        assert ctx.lib.mbn_tune_set(b"pw_splitk", 2) == 0          # wherever the shape is eligible
+        ctx.lib.mbn_memset(ctx.h, d_o.ptr, 0xFF, want.nbytes + 64)
+        ctx.pointwise(d_o.ptr, d_x.ptr, d_f.ptr, m // batch, 1, cin, cout, ext)
+        ctx.sync()
+        raw = d_o.download((want.size + 16,), np.float32)
+        assert np.all(raw[want.size:].view(np.uint32) == 0xFFFFFFFF), "stores past the ragged last tile"
+        got = raw[:want.size].reshape(want.shape)
+        ctx.pointwise(d_o.ptr, d_x.ptr, d_f.ptr, m // batch, 1, cin, cout, ext)
+        ctx.sync()
+        assert np.array_equal(got, d_o.download(want.shape, np.float32)), "not repeatable"
+        for tw in (16, 32):                                        # both workgroup tiles: same split, same k map -> same bits
+            assert ctx.lib.mbn_tune_set(b"misc", tw) == 0
+            ctx.pointwise(d_p.ptr, d_x.ptr, d_f.ptr, m // batch, 1, cin, cout, ext)
+            ctx.sync()
+            assert np.array_equal(got, d_p.download(want.shape, np.float32)), "tile %d differs" % tw
+        assert ctx.lib.mbn_tune_set(b"misc", 0) == 0
+        assert ctx.lib.mbn_tune_set(b"pw_splitk", 1) == 0          # never
+        ctx.pointwise(d_p.ptr, d_x.ptr, d_f.ptr, m // batch, 1, cin, cout, ext)
+        ctx.sync()
+        tiled = d_p.download(want.shape, np.float32)
+        assert_close(got, want, TOL_PW, "split-K %s vs oracle" % (shape,))
+        assert_close(got, tiled, TOL_PW, "split-K %s vs pw_gemm" % (shape,))
+        # default mode: a call of 1..4 images of a layer with few tiles takes this kernel by itself -> same bits
+        assert ctx.lib.mbn_tune_set(b"pw_splitk", 0) == 0
+        ctx.pointwise(d_p.ptr, d_x.ptr, d_f.ptr, m // batch, 1, cin, cout, ext)
+        ctx.sync()
+        dflt = d_p.download(want.shape, np.float32)
+        assert np.array_equal(dflt, got) or np.array_equal(dflt, tiled)
+        if -(-4 * (m // batch) // 64) * -(-cout // 64) * 2 <= 256:
+            assert np.array_equal(dflt, got), "default dispatch did not take the split-K kernel"
+        # exact integers, identity BN, no activation (FC form: scale NULL, bias as shift)
+        assert ctx.lib.mbn_tune_set(b"pw_splitk", 2) == 0
+        xi = rng.integers(-8, 9, (m, cin)).astype(np.float32)
+        fi = rng.integers(-8, 9, (cout, cin)).astype(np.float32)
+        fi[:, 0] += np.arange(cout) % 11
+        fi[:, cin - 1] -= np.arange(cout) % 7
+        bias = rng.integers(-50, 51, cout).astype(np.float32)
+        d_x.upload(xi); d_f.upload(fi); d_sh.upload(bias)
+        ctx.pointwise(d_o.ptr, d_x.ptr, d_f.ptr, m // batch, 1, cin, cout, pkg.make_ext(batch=batch, act=0, shift=d_sh.ptr))
+        ctx.sync()
+        wi = xi.astype(np.float64) @ fi.astype(np.float64).T + bias
+        assert np.array_equal(d_o.download(want.shape, np.float32).astype(np.float64), wi)
+        for tw in (16, 32):
+            assert ctx.lib.mbn_tune_set(b"misc", tw) == 0
+            ctx.pointwise(d_o.ptr, d_x.ptr, d_f.ptr, m // batch, 1, cin, cout, pkg.make_ext(batch=batch, act=0, shift=d_sh.ptr))
+            ctx.sync()
+            assert np.array_equal(d_o.download(want.shape, np.float32).astype(np.float64), wi), "tile %d" % tw
+    finally:
+        ctx.lib.mbn_tune_set(b"pw_splitk", 0)
+        ctx.lib.mbn_tune_set(b"misc", 0)
+    for b in (d_x, d_f, d_sc, d_sh, d_o, d_p):
+        b.free()
 
 
 def test_net_free_running_streams_interleaved_with_single_stream(pkg, ctx, tmp_path):
