@@ -25,14 +25,21 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 typedef mbn_f16v f16v;
 
-constexpr int BM = 128, BN = 128, BKE = 64, BKF = 32;      // k-tile: 64 bf16 = 128-byte rows = 32 LDS words
-constexpr int NT = 512, NSLOT = 4, AHEAD = 3;
-constexpr int WM = 32, WN = 64, MI = 1, NI = 2, WAVES_N = BN / WN;
-constexpr int SLOTF = (BM + BN) * BKF;                      // floats per ring slot (32 KB)
-constexpr int LDP = 2;                                      // 16-byte pieces per lane per operand per k-tile
-constexpr int NDMA = 2 * LDP;                               // LDS-DMA instructions per lane per k-tile
-constexpr int NST = 8 * MI * NI;                            // store instructions per lane per epilogue (channel-paired)
-constexpr int NMAX = 2048;                                  // widest output the LDS copy of scale/shift holds (16 KB)
+constexpr int BN = 128, BKE = 64, BKF = 32;                // k-tile: 64 bf16 = 128-byte rows = 32 LDS words
+constexpr int NT = 512;
+constexpr int WN = 64, NI = 2, WAVES_N = BN / WN;
+// Two shapes of the same kernel (template parameters BM = tile rows, AHEAD = k-tiles in flight, NSLOT = AHEAD + 1 ring slots):
+//   <128, 3>: 8 waves of 32 x 64, four 32 KB slots  — shipped for K = 64 (one k-tile per tile: the ring is what pipelines
+//             anything at all: layer 5 at batch 512 0.174 -> 0.115 ms);
+//   <256, 2>: 8 waves of 64 x 64, three 48 KB slots — built to test whether the 32 x 64 wave tile's LDS fragment traffic is
+//             what holds pw_gemm<bf16> at 0.88 PFLOP/s on the 512 -> 512 layers. It is not: 0.74 PFLOP/s there (0.0711 vs
+//             0.0603 ms), 0.0458 vs 0.0401 ms on 256 -> 512, slower on the 7x7 layers; only 256 -> 256 at M = 401 k gains
+//             (0.118 -> 0.0995 ms), a layer the bf16 net runs fused. Reading all fragments of a k-tile before its MFMAs instead
+//             of one group ahead changed nothing (0.0711 vs 0.0686). Reachable only with tune pw_ring = 2
+//             (profiles/r02/d_bf16_ring_gemm.txt). What the numbers say: at K = 512 the layer is 52.6 GFLOP against 206 MB —
+//             0.040 ms at the 1.25-1.5 PFLOP/s a tuned dense bf16 GEMM sustains on this chip under DVFS and 0.041 ms at
+//             5 TB/s — so both bounds sit at ~0.04 ms and pw_gemm is at 68 % of either, not at 39 % of one.
+constexpr int NMAX = 1024;                                  // widest output the LDS copy of scale/shift holds (8 KB)
 
 struct RingArgs {
     __bf16 *out;
@@ -57,8 +64,18 @@ __device__ __forceinline__ void ring_barrier()
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(VM_LEFT) : "memory");
 }
 // nd = k-tiles issued after the awaited one (0..2), ne = epilogues issued after it (0..3)
+template <int NDMA, int NST>
 __device__ __forceinline__ void ring_barrier_dyn(int nd, int ne)
 {
+    if constexpr (3 * NST + 2 * NDMA > 63) {               // the 64x64 shape: nk >= AHEAD = 2, so nd <= 1 and ne <= 1
+        switch (ne * 2 + nd) {
+        case 0: ring_barrier<0>(); break;
+        case 1: ring_barrier<NDMA>(); break;
+        case 2: ring_barrier<NST>(); break;
+        default: ring_barrier<NST + NDMA>(); break;
+        }
+        return;
+    } else
     switch (ne * 3 + nd) {
     case 0: ring_barrier<0>(); break;
     case 1: ring_barrier<NDMA>(); break;
@@ -74,8 +91,8 @@ __device__ __forceinline__ void ring_barrier_dyn(int nd, int ne)
     default: ring_barrier<3 * NST + 2 * NDMA>(); break;
     }
 }
-static_assert(3 * NST + 2 * NDMA <= 63, "vmcnt is a 6-bit field");
 
+template <int LDP>
 __device__ __forceinline__ void dma_rows(__amdgpu_buffer_rsrc_t rsrc, float *lds_tile, const unsigned *voff, int soff, int wave_u)
 {
 #pragma unroll
@@ -84,8 +101,16 @@ __device__ __forceinline__ void dma_rows(__amdgpu_buffer_rsrc_t rsrc, float *lds
                                                  16, voff[p], soff, 0, 0);
 }
 
+template <int BM, int AHEAD>
 __global__ __launch_bounds__(NT) void pw_ring_bf16(RingArgs a)
 {
+    constexpr int NSLOT = AHEAD + 1;
+    constexpr int WM = BM / 4, MI = WM / 32;                    // 4 x 2 waves
+    constexpr int SLOTF = (BM + BN) * BKF;                      // floats per ring slot (32 / 48 KB)
+    constexpr int LDA = BM * 8 / NT, LDB = BN * 8 / NT;         // 16-byte pieces per lane per k-tile: A (2 / 4), B (2)
+    constexpr int NDMA = LDA + LDB;                             // LDS-DMA instructions per lane per k-tile
+    constexpr int NST = 8 * MI * NI;                            // store instructions per lane per epilogue (channel-paired)
+    static_assert(AHEAD * NST + (AHEAD - 1) * NDMA <= 63 || NST + NDMA <= 63, "vmcnt is a 6-bit field");
     __shared__ __attribute__((aligned(16))) float lds[NSLOT * SLOTF + 2 * NMAX];
     // scale | shift of all N channels, read by the epilogue with ds_read: a global load there would be the wave's youngest
     // vector-memory operation and its wait (vmcnt(0)) would drain the three k-tiles in flight once per tile
@@ -117,25 +142,31 @@ __global__ __launch_bounds__(NT) void pw_ring_bf16(RingArgs a)
 
     // ---- issue cursor (runs AHEAD k-tiles in front of the compute cursor)
     int ivb = blockIdx.x, ikt = 0, issued = 0;
-    unsigned a_vo[LDP], b_vo[LDP];
+    int islot = 0;                                                       // ring slot of the next k-tile to issue
+    unsigned a_vo[LDA], b_vo[LDB];
     auto set_issue_tile = [&](int vb) __attribute__((always_inline)) {
         const int lid = xcd_remap(vb, nwg);
         const int n0 = (lid % a.nt) * BN;
         const long m0 = (long)(lid / a.nt) * BM;
 #pragma unroll
-        for (int p = 0; p < LDP; p++) {
+        for (int p = 0; p < LDA; p++) {
             const int row = (p * NT + tid) >> 3;
             long gm = m0 + row;
             if (gm >= a.m) gm = a.m - 1;                                 // rows past M are computed but never stored
             a_vo[p] = ((unsigned)gm * (unsigned)a.k + (unsigned)(((st_ch ^ (row >> 1)) & 7) * 8)) * 2u;
+        }
+#pragma unroll
+        for (int p = 0; p < LDB; p++) {
+            const int row = (p * NT + tid) >> 3;
             const int gn = n0 + mbn_pair_channel(row);                   // channel-paired column blocks (mbn_epilogue.h)
             b_vo[p] = ((unsigned)gn * (unsigned)a.k + (unsigned)(((st_ch ^ (row >> 1)) & 7) * 8)) * 2u;
         }
     };
-    auto issue = [&]() __attribute__((always_inline)) {                   // k-tile `issued` of the flattened sequence -> slot issued % 4
-        float *slot = lds + (issued & (NSLOT - 1)) * SLOTF;
-        dma_rows(arsrc, slot, a_vo, ikt * BKE * 2, wave_u);
-        dma_rows(brsrc, slot + BM * BKF, b_vo, ikt * BKE * 2, wave_u);
+    auto issue = [&]() __attribute__((always_inline)) {                   // k-tile `issued` of the flattened sequence -> the next ring slot
+        float *slot = lds + islot * SLOTF;
+        if (++islot == NSLOT) islot = 0;
+        dma_rows<LDA>(arsrc, slot, a_vo, ikt * BKE * 2, wave_u);
+        dma_rows<LDB>(brsrc, slot + BM * BKF, b_vo, ikt * BKE * 2, wave_u);
         issued++;
         if (++ikt == nk) {
             ikt = 0;
@@ -158,10 +189,10 @@ __global__ __launch_bounds__(NT) void pw_ring_bf16(RingArgs a)
                 for (int r = 0; r < 16; r++) acc[mi][ni][r] = 0.f;
     };
     zero_acc();
-    int cvb = blockIdx.x, ckt = 0;
+    int cvb = blockIdx.x, ckt = 0, cslot = 0;
     int epi_age = 100;                     // iterations since the last epilogue was issued (only 1..3 matter)
     for (int i = 0; i < total; i++) {
-        // k-tile i was issued at iteration i-3 (or in the prologue); behind it: the k-tiles issued since, and the stores of the
+        // k-tile i was issued at iteration i-AHEAD (or in the prologue); behind it: the k-tiles issued since, and the stores of the
         // epilogues of iterations i-3 .. i-1 (an iteration issues its DMA before its epilogue)
         const int nd = issued - 1 - i;
         int ne = 0;
@@ -173,9 +204,10 @@ __global__ __launch_bounds__(NT) void pw_ring_bf16(RingArgs a)
                 if (j >= 0 && (j % nk) == nk - 1) ne++;
             }
         }
-        ring_barrier_dyn(nd, ne);
+        ring_barrier_dyn<NDMA, NST>(nd, ne);
         if (issued < total) issue();                                     // into the slot k-tile i-1 vacated (everybody is past it)
-        const float *As = lds + (i & (NSLOT - 1)) * SLOTF, *Bs = As + BM * BKF;
+        const float *As = lds + cslot * SLOTF, *Bs = As + BM * BKF;
+        if (++cslot == NSLOT) cslot = 0;
         f4 fa[2][MI], fb[2][NI];
 #pragma unroll
         for (int mi = 0; mi < MI; mi++) fa[0][mi] = *reinterpret_cast<const f4 *>(As + fr_a[0] + mi * 32 * BKF);
@@ -218,7 +250,9 @@ int mbn_launch_bf16_pw_ring(const mbn_call &c, void *out, const void *in, const 
 {
     if (c.dtype != MBN_DT_BF16 || (c.io_flags & (MBN_IO_OUT_F32 | MBN_IO_IN_F32)) || c.act != MBN_ACT_RELU6 || !c.scale || !c.shift)
         return MBN_EUNSUPPORTED;
-    if (cin < BKE || (cin % BKE) != 0 || op_size < BN || (op_size % BN) != 0 || op_size > NMAX || m < 4 * BM) return MBN_EUNSUPPORTED;
+    const bool big = cin >= 256 && g_mbn_tune.misc != 128;     // 256 x 128 tiles, 64 x 64 wave tiles (misc = 128: A/B hook, the 128-row shape)
+    const int bm = big ? 256 : 128;
+    if (cin < BKE || (cin % BKE) != 0 || op_size < BN || (op_size % BN) != 0 || op_size > NMAX || m < 4 * bm) return MBN_EUNSUPPORTED;
     if (((uintptr_t)in % 16) != 0 || ((uintptr_t)filt % 16) != 0 || ((uintptr_t)out % 4) != 0 || ((uintptr_t)c.scale % 8) != 0 ||
         ((uintptr_t)c.shift % 8) != 0)
         return MBN_EUNSUPPORTED;
@@ -227,12 +261,13 @@ int mbn_launch_bf16_pw_ring(const mbn_call &c, void *out, const void *in, const 
     RingArgs a;
     a.out = (__bf16 *)out; a.in = (const __bf16 *)in; a.filt = (const __bf16 *)filt; a.scale = c.scale; a.shift = c.shift;
     a.m = m; a.k = cin; a.n = op_size;
-    a.mt = (int)((m + BM - 1) / BM);
+    a.mt = (int)((m + bm - 1) / bm);
     a.nt = op_size / BN;
     const long nwg = (long)a.mt * a.nt;
     if (nwg > 0x7fffffffL) return MBN_EUNSUPPORTED;
-    long grid = c.ctx->num_cus;                            // 128 KB of LDS: one workgroup per CU
+    long grid = c.ctx->num_cus;                            // 136 / 152 KB of LDS: one workgroup per CU
     if (grid > nwg) grid = nwg;
-    hipLaunchKernelGGL(pw_ring_bf16, dim3((unsigned)grid), dim3(NT), 0, c.stream, a);
+    if (big) hipLaunchKernelGGL((pw_ring_bf16<256, 2>), dim3((unsigned)grid), dim3(NT), 0, c.stream, a);
+    else hipLaunchKernelGGL((pw_ring_bf16<128, 3>), dim3((unsigned)grid), dim3(NT), 0, c.stream, a);
     return MBN_OK;
 }
