@@ -565,7 +565,7 @@ int mbn_launch_f32_pointwise(const mbn_call &c, void *out, const void *in, const
         else tile = 2;
     }
     const int cus = c.ctx->num_cus;
-    if (bf) {                                                              // bf16: the three shipped shapes only
+    if (bf) {                                                              // bf16: the shipped shapes (3, 5) + A/B shapes (profiles/r02/d_bf16_ring_gemm.txt: 5 wins everywhere)
         switch (tile) {
         case 3:                                                                  // small problems
             if (op_size >= 128) launch_cfg<__bf16, 64, 128, 32, 64>(a, c.stream, cus);   // 4 waves of 32x64: even NI, channel-paired 4-byte stores
@@ -573,8 +573,6 @@ int mbn_launch_f32_pointwise(const mbn_call &c, void *out, const void *in, const
             break;
         case 1: launch_cfg<__bf16, 128, 128, 64, 64>(a, c.stream, cus); break;   // 4 waves of 64x64
         case 4: launch_cfg<__bf16, 256, 128, 64, 64>(a, c.stream, cus); break;   // 8 waves of 64x64, 96 KB
-        case 6: launch_cfg<__bf16, 128, 256, 64, 64>(a, c.stream, cus); break;   // 8 waves of 64x64, 96 KB
-        case 9: launch_cfg<__bf16, 256, 256, 64, 128>(a, c.stream, cus); break;  // 8 waves of 64x128, 128 KB
         case 5: launch_cfg<__bf16, 128, 128, 32, 64>(a, c.stream, cus); break;
         case 7: launch_cfg<__bf16, 128, 64, 32, 32>(a, c.stream, cus); break;    // 8 waves of 32x32, 48 KB LDS: 3 WG = 24 waves per CU
         case 8: launch_cfg<__bf16, 64, 128, 32, 32>(a, c.stream, cus); break;
