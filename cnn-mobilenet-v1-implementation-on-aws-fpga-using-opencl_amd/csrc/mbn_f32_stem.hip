@@ -117,9 +117,16 @@ __device__ __forceinline__ void patch_store(float *in_s, int tid, const f2 (&pf)
 __device__ __forceinline__ float rbf(float v) { return (float)(__bf16)v; }
 __device__ __forceinline__ f4 rbf4(f4 v) { return f4{ rbf(v.x), rbf(v.y), rbf(v.z), rbf(v.w) }; }
 
-template <int C1, int C3, bool BF>
-__global__ __launch_bounds__(256, 2) void stem_fused_f32(StemArgs a)   // 2 waves/SIMD: two workgroups per CU
+// WPE = workgroups per CU (= waves per SIMD). The alpha = 1 forms need 59.6 KB (fp32) / 48.7 KB (bf16: A/B tiles in bf16) of LDS
+// and 246 / 232 VGPRs: two. With the nine depthwise tap vectors re-read from LDS per tile instead of living in 36 VGPRs for the
+// whole kernel (WDL, WPE >= 3) the bf16 form fits three (150 VGPRs) and the alpha = 0.5 forms four (118 / 126 VGPRs, 28.6 /
+// 33.7 KB): more workgroups put one's conv1 phase (VALU) under the others' barriers and stores. Measured (batch 512,
+// profiles/r02/j_stem_occupancy.txt): alpha = 0.5 bf16 0.196 -> 0.153 ms, fp32 0.221 -> 0.173 ms with four; alpha = 1 bf16:
+// see the launcher.
+template <int C1, int C3, bool BF, int WPE>
+__global__ __launch_bounds__(256, WPE) void stem_fused_f32(StemArgs a)
 {
+    constexpr bool WDL = WPE >= 3;
     constexpr int Q1 = C1 / 4;                     // channel quads per pixel (8 / 4)
     constexpr int PB = 3 * Q1 / 4;                 // conv1 pixels per lane (6 / 3): CR * (CC / PB) * Q1 = 240 busy lanes
     static_assert(CC % PB == 0 && CR * (CC / PB) * Q1 <= 256, "conv1 lane mapping");
@@ -130,9 +137,10 @@ __global__ __launch_bounds__(256, 2) void stem_fused_f32(StemArgs a)   // 2 wave
     __shared__ __attribute__((aligned(16))) float in_s[PR * PROW + PROWPAD]; //  9.4 KB
     __shared__ __attribute__((aligned(16))) float w1_s[27 * C1];          //  3.4 KB
     __shared__ __attribute__((aligned(16))) float c1_s[CR * CC * C1];     // 22.5 KB
-    __shared__ __attribute__((aligned(16))) float a_s[TH * TW * 32];      // 16 KB
-    __shared__ __attribute__((aligned(16))) float b_s[C3 * 32];           //  8 KB
+    __shared__ __attribute__((aligned(16))) float a_s[TH * TW * C1 / (BF ? 2 : 1)];   // 16 KB (fp32, C1 = 32) ... 4 KB (bf16, C1 = 16)
+    __shared__ __attribute__((aligned(16))) float b_s[C3 * C1 / (BF ? 2 : 1)];        //  8 KB ... 1 KB
     __shared__ __attribute__((aligned(16))) float sb_s[4 * C1];           // s1 | b1 | s2 | b2
+    __shared__ __attribute__((aligned(16))) float wd_s[WDL ? 9 * C1 : 4]; // depthwise taps [ky][kx][C1] (WDL)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
     const int c4 = tid % Q1;                                              // this lane's channel quad in phases B, C
@@ -157,9 +165,13 @@ __global__ __launch_bounds__(256, 2) void stem_fused_f32(StemArgs a)   // 2 wave
         const float *src = tid < C1 ? a.s1 : tid < 2 * C1 ? a.b1 : tid < 3 * C1 ? a.s2 : a.b2;
         sb_s[tid] = src[tid & (C1 - 1)];
     }
-    f4 wd[9];
+    f4 wd[WDL ? 1 : 9];
+    if constexpr (WDL) {
+        for (int i = tid * 4; i < 9 * C1; i += 1024) *reinterpret_cast<f4 *>(wd_s + i) = *reinterpret_cast<const f4 *>(a.wd + i);
+    } else {
 #pragma unroll
-    for (int k = 0; k < 9; k++) wd[k] = *reinterpret_cast<const f4 *>(a.wd + k * C1 + c4 * 4);
+        for (int k = 0; k < 9; k++) wd[k] = *reinterpret_cast<const f4 *>(a.wd + k * C1 + c4 * 4);
+    }
     float s3[NI], b3[NI];
 #pragma unroll
     for (int ni = 0; ni < NI; ni++) {                                     // bf16, two blocks: accumulator ni of lane li is channel 2*li + ni
@@ -244,9 +256,13 @@ __global__ __launch_bounds__(256, 2) void stem_fused_f32(StemArgs a)   // 2 wave
 #pragma unroll
                 for (int j = 0; j < PC + 2; j++) v[j] = *reinterpret_cast<const f4 *>(c1_s + ((cy + dy) * CC + cx + j) * C1 + c4 * 4);
 #pragma unroll
-                for (int dx = 0; dx < 3; dx++)
+                for (int dx = 0; dx < 3; dx++) {
+                    f4 wt;
+                    if constexpr (WDL) wt = *reinterpret_cast<const f4 *>(wd_s + (dy * 3 + dx) * C1 + c4 * 4);
+                    else wt = wd[dy * 3 + dx];
 #pragma unroll
-                    for (int p = 0; p < PC; p++) acc[p] = fma4v(v[p + dx], wd[dy * 3 + dx], acc[p]);
+                    for (int p = 0; p < PC; p++) acc[p] = fma4v(v[p + dx], wt, acc[p]);
+                }
             }
             const f4 s2 = *reinterpret_cast<const f4 *>(sb_s + 2 * C1 + c4 * 4), b2 = *reinterpret_cast<const f4 *>(sb_s + 3 * C1 + c4 * 4);
 #pragma unroll
@@ -341,14 +357,19 @@ int mbn_launch_f32_stem(mbn_context *ctx, hipStream_t stream, float *out, const 
     a.tiles_y = a.h / TH; a.tiles_x = a.h / TW;
     if ((long)batch * a.tiles_y * a.tiles_x >= 0x7fffffffL) return MBN_EUNSUPPORTED;
     a.ntiles = (unsigned)((long)batch * a.tiles_y * a.tiles_x);
-    long grid = (long)ctx->num_cus * 2;                  // 59.7 KB of LDS per workgroup: two per CU
+    // alpha = 1 bf16: three workgroups per CU (taps from LDS) 0.448-0.455 ms against 0.472-0.480 with two (taps in registers), same run
+    const int wpe_bf = g_mbn_tune.misc == 2 ? 2 : 3;                                  // A/B hook: misc = 2
+    const int per_cu = c1 == 16 ? 4 : (bf16 ? wpe_bf : 2);
+    long grid = (long)ctx->num_cus * per_cu;
     if (grid > (long)a.ntiles) grid = (long)a.ntiles;
+    const dim3 g((unsigned)grid), b(256);
     if (c1 == 32) {
-        if (bf16) hipLaunchKernelGGL((stem_fused_f32<32, 64, true>), dim3((unsigned)grid), dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((stem_fused_f32<32, 64, false>), dim3((unsigned)grid), dim3(256), 0, stream, a);
+        if (bf16 && wpe_bf == 3) hipLaunchKernelGGL((stem_fused_f32<32, 64, true, 3>), g, b, 0, stream, a);
+        else if (bf16) hipLaunchKernelGGL((stem_fused_f32<32, 64, true, 2>), g, b, 0, stream, a);
+        else hipLaunchKernelGGL((stem_fused_f32<32, 64, false, 2>), g, b, 0, stream, a);
     } else {
-        if (bf16) hipLaunchKernelGGL((stem_fused_f32<16, 32, true>), dim3((unsigned)grid), dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((stem_fused_f32<16, 32, false>), dim3((unsigned)grid), dim3(256), 0, stream, a);
+        if (bf16) hipLaunchKernelGGL((stem_fused_f32<16, 32, true, 4>), g, b, 0, stream, a);
+        else hipLaunchKernelGGL((stem_fused_f32<16, 32, false, 4>), g, b, 0, stream, a);
     }
     return MBN_OK;
 }
