@@ -133,13 +133,14 @@ def main():
     ap.add_argument("--res", type=int, default=224)
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="storage type of activations and pointwise filters (arithmetic is fp32 either way)")
-    ap.add_argument("--streams", type=int, default=1,
-                    help="default 1. n > 1: pipeline each step over n sub-batches on separate HIP streams (mbn_net_set_streams): the "
-                         "HBM-bound depthwise kernels of one sub-batch overlap the MFMA-bound GEMMs of the other. The steps "
-                         "whose kernels are timed one by one (--profile-every) run on ONE stream, so the per-kernel HIP-event "
-                         "durations behind `roofline` and `stages` are not stretched by a concurrent kernel. Measured at "
-                         "batch 256 fp32: +3.6 %% without per-kernel events, +1.5 %% with every 5th step single-stream; bf16 "
-                         "batch 512: -3 %% (DESIGN.md 5)")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="0 (default) = 2 in fp32 at batch >= 64, 1 otherwise. n > 1: pipeline each step over n sub-batches on "
+                         "separate HIP streams (mbn_net_set_streams, bit-identical logits): the HBM-bound depthwise kernels of one "
+                         "sub-batch overlap the MFMA-bound GEMMs of the other. The steps whose kernels are timed one by one "
+                         "(--profile-every) run on ONE stream, so the per-kernel HIP-event durations behind `roofline` and "
+                         "`stages` are not stretched by a concurrent kernel. Same-run A/B at batch 256 fp32 "
+                         "(profiles/r02/k_streams_ab.txt): 84.5 k images/s on one stream, 87.6 k on two with every 10th step "
+                         "profiled, 89.4 k on two without per-kernel events; bf16 batch 512: -3 %% (DESIGN.md 5)")
     ap.add_argument("--dist-backend", default="nccl", help="rehearsal only: 'gloo' lets several ranks share one GPU")
     ap.add_argument("--device-override", type=int, default=-1, help="rehearsal only: every rank uses this device")
     ap.add_argument("--graph", action="store_true", help="replay each step as one hipGraph (mbn_net_set_graph)")
@@ -153,10 +154,15 @@ def main():
     ap.add_argument("--no-unfused-stages", action="store_true", help="skip the untimed one-launch-per-layer pass")
     ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the CPU baseline (cap; box share is 16)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
-    ap.add_argument("--profile-every", type=int, default=5,
+    ap.add_argument("--profile-every", type=int, default=0,
                     help="record the per-kernel HIP event pairs on every Nth timed step (58 event records per step "
-                         "cost ~5%% of a 4 ms step; sampling keeps the live measurement without distorting `value`)")
+                         "cost ~5%% of a 4 ms step; sampling keeps the live measurement without distorting `value`); "
+                         "0 (default) = 5 on one stream, 10 with sub-batch streams (those steps run single-stream)")
     args = ap.parse_args()
+    if args.streams <= 0:
+        args.streams = 2 if (args.dtype == "f32" and args.batch >= 64 and not args.graph) else 1
+    if args.profile_every <= 0:
+        args.profile_every = 10 if args.streams > 1 else 5
 
     from mbn_amd import import_package
     pkg = import_package()
