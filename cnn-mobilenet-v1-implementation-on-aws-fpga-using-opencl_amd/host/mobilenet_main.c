@@ -4,7 +4,7 @@
  *   mobilenet --h5 weights.h5 [--ppm image.ppm] [--batch N] [--res 224] [--alpha 1.0]      fp32 path
  *   mobilenet --synthetic SEED [--alpha A] [--res R] [--batch N]                              fp32, synthetic weights
  *   mobilenet --literal [--weights weights_c.txt] [--image Cat_Image0.ppm] [--ref-args]      the reference's own mode
- *   mobilenet --gpus G --batch N [--steps K --warmup W] (--h5 F | --synthetic SEED)           N images sharded over G GPUs
+ *   mobilenet --gpus G --batch N [--steps K --warmup W --streams S] (--h5 F | --synthetic SEED)  N images sharded over G GPUs
  *   mobilenet --inspect weights.h5                                                             list the datasets of a .h5
  *   mobilenet --convert weights.h5 out.txt                                                     folded blob as text (one %.9g per line)
  *
@@ -166,6 +166,8 @@ static double now_s(void)
     return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
 }
 
+static int g_streams = 1;      /* --streams S: sub-batch streams per GPU in --gpus mode (mbn_net_set_streams) */
+
 static void *gpu_thread(void *arg)
 {
     gpu_job *j = (gpu_job *)arg;
@@ -178,6 +180,10 @@ static void *gpu_thread(void *arg)
     int rc = mbn_dist_context(j->dist, j->rank, &ctx);
     if (rc == MBN_OK) rc = mbn_net_create_from_device_blob(ctx, j->plan, j->dev_blob, n, &net);
     if (rc == MBN_OK) rc = mbn_net_set_input_u8(net, 1);
+    if (rc == MBN_OK && g_streams > 1) {
+        rc = mbn_net_set_streams(net, g_streams);
+        if (rc == MBN_OK) rc = mbn_net_set_free_running(net, 1);   /* the images are uploaded with the blocking mbn_upload below */
+    }
     if (rc == MBN_OK) rc = mbn_alloc(ctx, (size_t)n * img, &d_u8);
     if (rc == MBN_OK) rc = mbn_alloc(ctx, (size_t)n * j->plan->classes * sizeof(float), &d_logits);
     if (rc == MBN_OK) rc = mbn_alloc(ctx, sizeof(int) * (size_t)n, &d_idx);
@@ -282,18 +288,19 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[i], "--synthetic") && i + 1 < argc) { seed = strtoull(argv[++i], NULL, 0); have_seed = 1; }
         else if (!strcmp(argv[i], "--gpus") && i + 1 < argc) gpus = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--steps") && i + 1 < argc) steps = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--streams") && i + 1 < argc) g_streams = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--warmup") && i + 1 < argc) warmup = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--literal")) literal = 1;
         else if (!strcmp(argv[i], "--ref-args")) ref_args = 1;
         else {
             fprintf(stderr, "usage: %s [--h5 F | --synthetic SEED | --literal] [--ppm F] [--batch N] [--res R] [--alpha A] "
-                            "[--gpus G [--steps K] [--warmup W]]\n", argv[0]);
+                            "[--gpus G [--steps K] [--warmup W] [--streams S]]\n", argv[0]);
             return 2;
         }
     }
     mbn_context *ctx = NULL;
     if (gpus > 0 && !literal) {
-        if (batch < 1 || steps < 1 || warmup < 0) { fprintf(stderr, "bad --batch/--steps/--warmup\n"); return 2; }
+        if (batch < 1 || steps < 1 || warmup < 0 || g_streams < 1 || g_streams > 8) { fprintf(stderr, "bad --batch/--steps/--warmup/--streams\n"); return 2; }
         char tmpm[] = "/tmp/mbn_synth_XXXXXX.h5";
         if (!h5) {
             if (!have_seed) { fprintf(stderr, "need --h5 or --synthetic with --gpus\n"); return 2; }

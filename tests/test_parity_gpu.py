@@ -1254,6 +1254,14 @@ def test_dist_single_gpu_path_and_c_host_gpus_mode(pkg, ctx, tmp_path):
     assert m and 1 <= int(m.group(2)) <= 1000, out.stdout
     m = re.search(r"1 GPUs, batch 5 .* ([0-9.]+) images/sec", out.stdout)
     assert m and float(m.group(1)) > 0, out.stdout
+    # --streams 2: each GPU's shard as two free-running sub-batch streams (12 images: sub-batches of 6, forked) -> same class
+    runs = []
+    for extra in ([], ["--streams", "2"]):
+        out = subprocess.run([exe, "--gpus", "1", "--batch", "12", "--synthetic", "3", "--alpha", "0.25", "--res", "96",
+                              "--steps", "3", "--warmup", "1"] + extra, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr
+        runs.append(re.search(r"first image -> class (\d+)", out.stdout).group(1))
+    assert runs[0] == runs[1]
     # asking the host for more GPUs than the box has fails cleanly
     out = subprocess.run([exe, "--gpus", str(have.value + 1), "--batch", "8", "--synthetic", "3", "--alpha", "0.25", "--res", "64"],
                          capture_output=True, text=True, timeout=300)

@@ -20,7 +20,7 @@ print("batch %4s  %9.0f img/s  %.4f ms/step  median %.4f" % (sys.argv[1], d["val
 PY
 done > $O/batch_sweep.txt
 cat $O/batch_sweep.txt
-$R/cnn-mobilenet-v1-implementation-on-aws-fpga-using-opencl_amd/mobilenet --gpus 1 --batch 256 --synthetic 1 --steps 20 --warmup 5 > $O/c_host_gpus1.txt 2>&1; tail -2 $O/c_host_gpus1.txt
+$R/cnn-mobilenet-v1-implementation-on-aws-fpga-using-opencl_amd/mobilenet --gpus 1 --batch 256 --synthetic 1 --steps 20 --warmup 5 > $O/c_host_gpus1.txt 2>&1; $R/cnn-mobilenet-v1-implementation-on-aws-fpga-using-opencl_amd/mobilenet --gpus 1 --batch 256 --synthetic 1 --steps 20 --warmup 5 --streams 2 >> $O/c_host_gpus1.txt 2>&1; tail -4 $O/c_host_gpus1.txt
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --streams 1 --no-cpu-baseline --no-unfused-stages > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err
 cp $(ls $O/stats/*/*kernel_stats.csv | head -1) $O/kernel_stats.csv
