@@ -391,7 +391,9 @@ int  mbn_net_destroy(mbn_net *net);
 int  mbn_net_set_dtype(mbn_net *net, int dtype);
 /* Pipeline every forward over `n` contiguous sub-batches on n streams (1 <= n <= 8; default 1). The HBM-bound
  * depthwise kernels of one sub-batch then overlap the MFMA-bound pointwise kernels of another and fill their tails
- * (measured +5 % at n = 2, +9.5 % at n = 4, batch 256). The call still behaves as ONE asynchronous operation on the
+ * (fp32 1.0x224 batch 256 with the round-2 kernels: +4.7 % at n = 2, -5 % at n = 3, -3 % at n = 4 — smaller sub-batches
+ * quantise the GEMM grids worse; bf16 batch 512: -3 % at n = 2; profiles/r02/k_streams_ab.txt). Sub-batches of fewer
+ * than 5 images are not forked. The call still behaves as ONE asynchronous operation on the
  * context's stream: the sub-streams fork from it and join back into it. */
 int  mbn_net_set_streams(mbn_net *net, int n);
 /* With n > 1 streams: 1 = the caller guarantees that `images` is not being produced by work still pending on the
