@@ -320,8 +320,11 @@ def main():
         }
         if layer_ms is not None:
             stages, per_layer, stage_of = stage_table(plan, pkg, launches, layer_ms, args.batch, act_bytes, mfma_peak)
-            pw = stages["pointwise"]
-            pw_idx = [launches[j][0] for j in range(n_launch) if stage_of[j] == "pointwise"]
+            # dominant kernel: the stand-alone pointwise GEMMs; at 1..4 images every block is one fused launch, so the fused
+            # block launches are the dominant kernel and their pointwise layers carry the flops
+            dom = "pointwise" if "pointwise" in stages else "block_fused"
+            pw = stages[dom]
+            pw_idx = [launches[j][-1] for j in range(n_launch) if stage_of[j] == dom]
             out["launches_per_layer"] = nsub
             flops_per_launch = sum(layer_work(plan.layer[i], args.batch, pkg, act_bytes)[0] for i in pw_idx) / len(pw_idx)
             bytes_per_launch = sum(layer_work(plan.layer[i], args.batch, pkg, act_bytes)[1] for i in pw_idx) / len(pw_idx)
@@ -329,7 +332,8 @@ def main():
             traffic, traffic_src = load_traffic([i + 1 for i in pw_idx], "bf16_%gx%d" % (args.alpha, args.res) if bf16 else "f32")
             if bf16:       # ridge ~312 flop/B: every pointwise layer is HBM-bound in bf16
                 out["roofline"] = {
-                    "kernel": "pw_gemm<bf16> (%d pointwise 1x1 conv launches per step)" % len(pw_idx),
+                    "kernel": ("pw_gemm<bf16> (%d pointwise 1x1 conv launches per step)" if dom == "pointwise" else
+                               "fused depthwise->pointwise blocks (%d launches per step; bytes of their pointwise layers)") % len(pw_idx),
                     "bound": "hbm", "achieved": round(bytes_per_launch / avg_ms / 1e6, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(bytes_per_launch / avg_ms / 1e6 / HBM_PEAK_GBS, 4),
                     "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(avg_ms, 5),
@@ -337,7 +341,8 @@ def main():
                 }
             else:
                 out["roofline"] = {
-                    "kernel": "pw_gemm<float> (%d pointwise 1x1 conv launches per step)" % len(pw_idx),
+                    "kernel": ("pw_gemm<float> (%d pointwise 1x1 conv launches per step)" if dom == "pointwise" else
+                               "dwpw_small_f32 (%d fused depthwise->pointwise launches per step; flops/bytes of their pointwise layers)") % len(pw_idx),
                     "bound": "mfma", "achieved": round(flops_per_launch / avg_ms / 1e9, 2), "peak": MFMA_F32_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(flops_per_launch / avg_ms / 1e9 / MFMA_F32_PEAK_TFLOPS, 4),
                     "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(avg_ms, 5),
