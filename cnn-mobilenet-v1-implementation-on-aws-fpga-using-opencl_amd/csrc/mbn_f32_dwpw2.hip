@@ -60,7 +60,7 @@ struct DwPw2Args {
     int pad_top, pad_left;
     int mt, nt;
     unsigned in_bytes, wp_bytes;
-    int dbg;                // experiments (tune dwpw_variant = 100 + bits): 1 = no x loads after the first, 2 = no depthwise math, 4 = no output stores,
+    int dbg;                // experiments (tune dwpw_variant = 100 + bits): 1 = no x loads after the first, 2 = no depthwise math, 4 = no output stores, 128 = x loads as one burst (before: -2.5 %),
                             // 8 = no filter DMA, 16 = no MFMA, 32 = unpaired column blocks (4-byte stores)
     unsigned wo_m, wo_s, ho_m, ho_s;   // floor(v / wo) = umulhi(v, wo_m) >> wo_s for v < 2^31 (m == 0: the divisor is 1)
 };
@@ -186,6 +186,15 @@ __global__ __launch_bounds__(NT) void dwpw2_f32(DwPw2Args a)
             for (int j = 0; j < XC; j++)
                 xr[dy][j] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(irsrc, off[dy][j], kc * 128, 0));
     };
+    // the same loads in four parts (3+3+3+3 or 4+4+4+3), one in front of each MFMA group of the step: issued as one burst
+    // right after D, the 8 waves' 96-120 loads queue up behind each other in the CU's one address unit — ~800 cycles of issue
+    // stall per wave and step in the stamps (profiles/r02/g_dwpw2_stamps.txt); spread out they issue under the MFMAs
+    auto ldx_part = [&](int kc, const int part) __attribute__((always_inline)) {
+        constexpr int PER = (NX + 3) / 4;
+#pragma unroll
+        for (int i = part * PER; i < (part + 1) * PER && i < NX; i++)
+            xr[i / XC][i % XC] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(irsrc, off[i / XC][i % XC], kc * 128, 0));
+    };
     f4 wreg[11];                                                               // 9 taps, scale, shift of the chunk D works on
     auto ldw = [&](int kc) __attribute__((always_inline)) {
 #pragma unroll
@@ -288,16 +297,20 @@ __global__ __launch_bounds__(NT) void dwpw2_f32(DwPw2Args a)
                 if (validL) { origin(vbL, m0L, n0L); set_offsets(m0L); }                                                \
             }                                                                                                           \
             STAMP(1);                                                                                                   \
-            if (validL && !(a.dbg & 1)) ldx(kL);                                                                        \
+            if (validL && !(a.dbg & 1) && ((a.dbg & 128) || (a.dbg & 16))) ldx(kL);      /* dbg 128: the burst form (A/B) */ \
         }                                                                                                               \
+        const bool spreadL = validL && !(a.dbg & 1) && !(a.dbg & 128) && !(a.dbg & 16);                                 \
         STAMP(2);                                                                                                       \
         if (!(a.dbg & 16)) {                                                                                            \
         _Pragma("unroll") for (int g = 0; g < 3; g++) {                                                                 \
             ldfrag(P, g + 1, (g + 1) & 1);                                                                              \
+            if (spreadL) ldx_part(kL, g);                                                                               \
             __builtin_amdgcn_sched_barrier(0);                                                                          \
             mfma_group(g & 1);                                                                                          \
             __builtin_amdgcn_sched_barrier(0);                                                                          \
         }                                                                                                               \
+        if (spreadL) ldx_part(kL, 3);                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
         mfma_group(1);                                                                                                  \
         }                                                                                                               \
         STAMP(3);                                                                                                       \
