@@ -60,7 +60,7 @@ struct DwPw2Args {
     int pad_top, pad_left;
     int mt, nt;
     unsigned in_bytes, wp_bytes;
-    int dbg;                // experiments (tune dwpw_variant = 100 + bits): 1 = no x loads after the first, 2 = no depthwise math, 4 = no output stores, 128 = x loads as one burst (before: -2.5 %),
+    int dbg;                // experiments (tune dwpw_variant = 100 + bits): 1 = no x loads after the first, 2 = no depthwise math, 4 = no output stores, 128 = x loads as one burst (before: -2.5 %), 256 = no s_setprio around the depthwise part (-1 %),
                             // 8 = no filter DMA, 16 = no MFMA, 32 = unpaired column blocks (4-byte stores)
     unsigned wo_m, wo_s, ho_m, ho_s;   // floor(v / wo) = umulhi(v, wo_m) >> wo_s for v < 2^31 (m == 0: the divisor is 1)
 };
@@ -284,6 +284,7 @@ __global__ __launch_bounds__(NT) void dwpw2_f32(DwPw2Args a)
 #define MBN_DWPW2_STEP(P)                                                                                               \
     {                                                                                                                   \
         STAMP(0);                                                                                                       \
+        if (!(a.dbg & 256)) __builtin_amdgcn_s_setprio(3);       /* depthwise part ahead of the other wave's MFMAs, see below */ \
         ldfrag(P, 0, 0);                                                                                                \
         bool validL = false;                                                                                            \
         int vbL = vbD, kL = kD + 1, n0L = n0D;                                                                          \
@@ -300,6 +301,7 @@ __global__ __launch_bounds__(NT) void dwpw2_f32(DwPw2Args a)
             if (validL && !(a.dbg & 1) && ((a.dbg & 128) || (a.dbg & 16))) ldx(kL);      /* dbg 128: the burst form (A/B) */ \
         }                                                                                                               \
         const bool spreadL = validL && !(a.dbg & 1) && !(a.dbg & 128) && !(a.dbg & 16);                                 \
+        __builtin_amdgcn_s_setprio(0);                                                                                  \
         STAMP(2);                                                                                                       \
         if (!(a.dbg & 16)) {                                                                                            \
         _Pragma("unroll") for (int g = 0; g < 3; g++) {                                                                 \
