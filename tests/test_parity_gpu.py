@@ -315,10 +315,12 @@ def _make_net(pkg, ctx, tmp_path, alpha, res, classes, batch, seed=3):
     return hw, net
 
 
-@pytest.mark.parametrize("cfg", [(0.25, 64, 2), (0.5, 96, 1)])
+@pytest.mark.parametrize("cfg", [(0.25, 64, 2), (0.5, 96, 1), (0.75, 96, 3), (1.0, 64, 4), (0.75, 64, 6)])
 def test_net_per_layer_vs_oracle(pkg, orc, ctx, tmp_path, cfg):
     """BASELINE config 2 in miniature: every layer's output vs the CPU oracle, each GPU layer fed by the GPU's
-    own previous layer (so per-layer error is what the tolerance bounds, not accumulated drift)."""
+    own previous layer (so per-layer error is what the tolerance bounds, not accumulated drift). 1..4 images take the
+    split-K pointwise kernel on their few-tile layers (alpha 0.75: K = 192, 384, 768; alpha 1: K = 128 ... 1024), 6 images
+    the tiled GEMM everywhere."""
     alpha, res, n = cfg
     hw, net = _make_net(pkg, ctx, tmp_path, alpha, res, 50, n)
     imgs = np.random.default_rng(0).uniform(-1, 1, (n, res, res, 3)).astype(np.float32)
