@@ -53,6 +53,7 @@ struct DwArgs {
     const float *filt, *scale, *shift;
     int batch, in_rows, in_cols, rows, cols, ch, pad_top, pad_left, act;
     int seg_rows, nseg;     // output rows per segment / segments per image
+    int prio;               // wave priority of the whole kernel (3: a memory-bound kernel beside another stream's MFMA-streaming GEMM gets its few VALU slots)
     int cw;                 // lanes along channels inside a slab (channels per slab = 4*cw)
     int nslab;              // ch / (4*cw)
     int lcols;              // lane-columns per row = ceil(cols / TW)
@@ -76,6 +77,7 @@ template <int STRIDE, int TW, typename T>
 __global__ __launch_bounds__(256) void dw3x3_nhwc(DwArgs a)
 {
     constexpr int NC = TW * STRIDE + 2;
+    if (a.prio) __builtin_amdgcn_s_setprio(3);
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= a.total) return;
     // lane -> (channel-in-slab fastest, lane-column, slab, segment, image)
@@ -183,6 +185,7 @@ template <int STRIDE, int TW>
 __global__ __launch_bounds__(256) void dw3x3_nhwc_bf16x8(DwArgs a)
 {
     constexpr int NC = TW * STRIDE + 2;
+    if (a.prio) __builtin_amdgcn_s_setprio(3);
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= a.total) return;
     const int cl = (int)(t % a.cw);                  // a.cw = lanes along channels inside a slab (8 channels each)
@@ -397,6 +400,7 @@ int mbn_launch_f32_depthwise(const mbn_call &c, void *out, const void *in, const
     a.pad_top = c.pad_top >= 0 ? c.pad_top : mbn_same_pad(c.in_rows, rows, fs, stride);
     a.pad_left = c.pad_left >= 0 ? c.pad_left : mbn_same_pad(c.in_cols, cols, fs, stride);
     a.act = c.act;
+    a.prio = (g_mbn_tune.dw_variant & 128) ? 0 : 1;       // dw_variant bit 7: A/B hook, no raised priority
     if (c.dtype == MBN_DT_BF16) return launch_dw<__bf16>(c, a, rows, cols, fs, stride, channels);
     return launch_dw<float>(c, a, rows, cols, fs, stride, channels);
 }

@@ -488,9 +488,10 @@ const char *mbn_version(void);
  *   misc         workgroups per CU of the persistent GEMM grid (1000 = one tile per workgroup); in the split-K kernel 16 / 32 =
  *                force the 16x16 / 32x32 workgroup tile
  *   pw_stage     1 = stage GEMM operands through registers instead of direct-to-LDS loads
- *   conv_variant 1 = generic conv1 kernel; 8 = GEMM without the software-pipelined k-loop; 9 = GEMM with the general epilogue
+ *   conv_variant 1 = generic conv1 kernel; 5 = fused stem without raised wave priority over its VALU phases, 6 = with it over the
+ *                epilogue too; 8 = GEMM without the software-pipelined k-loop; 9 = GEMM with the general epilogue
  *   dw_variant   depthwise: bits 0-1 = output columns per lane, bit 4 = lanes across all channels, bit 5 = bf16 with
- *                4-channel lanes
+ *                4-channel lanes, bit 7 = no raised wave priority
  *   dw_nseg      depthwise: row segments per image
  *   net_stagger  layers between the starts of consecutive sub-batch streams (mbn_net_set_streams)
  *   lit_dot      LITERAL pointwise: 0 = v_dot4_i32_i8 path where eligible (no carry quirk, filter fits int8), 1 = scalar kernel
