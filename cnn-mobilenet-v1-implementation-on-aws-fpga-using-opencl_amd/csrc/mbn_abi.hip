@@ -713,7 +713,10 @@ int mbn_dwpw_fused(mbn_context *ctx, void *out, const void *in, const void *wd, 
     const int dv = g_mbn_tune.dwpw_variant;
     const long tiles256 = (((long)batch * out_rows * out_cols + 127) / 128) * (cout / 256);
     const bool small = tiles256 < ctx->num_cus;
-    if (dv != 1 && (dv >= 2 || (cout % 256) != 0 || small))
+    // stride-2 blocks (15 x-window loads per lane and step): with the loads spread under the MFMA groups the unified kernel also wins at
+    // 256 columns (block 8-9: 0.1967 / 0.1964 -> 0.1931 / 0.1893 ms, profiles/r02/b_block_kernel_variants.txt); stride 1 at 256 columns
+    // stays on the round-1 kernel (block 10-11: 0.291 vs 0.308 ms)
+    if (dv != 1 && (dv >= 2 || (cout % 256) != 0 || small || stride == 2))
         return sc.finish(mbn_launch_f32_dwpw2(ctx, s, (float *)out, (const float *)in, (const float *)wd, (const float *)s2,
                                               (const float *)b2, (const float *)wp, (const float *)s3, (const float *)b3, batch,
                                               in_rows, in_cols, out_rows, out_cols, cin, cout, stride, pad_top, pad_left));
