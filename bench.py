@@ -425,6 +425,22 @@ def main():
                 out["cpu_baseline"]["variants"] = var
                 out["cpu_baseline"]["variants_how"] = "median of 5, host cores of this box: %d used of %d visible" % (
                     cores, os.cpu_count() or cores)
+        if world > 1 and not args.no_cpu_baseline:
+            # N > 1: no cpu_baseline leg (contract: rank 0 at N = 1 only), but the logits rank 0's timed steps left on its GPU are
+            # still checked against the oracle on the first 8 images of its shard (~0.3 s of host time after the timed region)
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import oracle as orc   # checker only
+            n_img = min(8, head.shape[0], args.batch)
+            ref, _ = orc.net_forward(orc.plan_build(args.alpha, args.res, 1000), blob_t.cpu().numpy(), head[:n_img],
+                                     threads=min(orc.num_threads(), args.cpu_threads), bf16=bf16)
+            ref = np.asarray(ref, dtype=np.float64).reshape(n_img, 1000)
+            got = logits[:n_img].astype(np.float64)
+            err = float(np.abs(got - ref).max()) / max(float(np.abs(ref).max()), 1e-6)
+            tol = 6e-2 if bf16 else 1e-3
+            out["parity_check"] = {"images": n_img, "max_rel_err": err, "tolerance": tol, "ok": bool(err <= tol),
+                                   "argmax_agree": int((got.argmax(1) == ref.argmax(1)).sum()),
+                                   "against": "oracle/mbn_oracle.c F32 mode%s, logits of the first %d images of rank 0's shard"
+                                              % (" (bf16 storage emulated)" if bf16 else "", n_img)}
         print(json.dumps(out))
         sys.stdout.flush()
         if "parity_check" in out and not out["parity_check"]["ok"]:
