@@ -125,9 +125,11 @@ __device__ __forceinline__ f4 rbf4(f4 v) { return f4{ rbf(v.x), rbf(v.y), rbf(v.
 // 33.7 KB): more workgroups put one's conv1 phase (VALU) under the others' barriers and stores. Measured (batch 512,
 // profiles/r02/j_stem_occupancy.txt): alpha = 0.5 bf16 0.196 -> 0.153 ms, fp32 0.221 -> 0.173 ms with four; alpha = 1 bf16:
 // see the launcher.
-template <int C1, int C3, bool BF, int WPE>
+template <int C1, int C3, bool BF, int WPE, bool MC = false>
 __global__ __launch_bounds__(256, WPE) void stem_fused_f32(StemArgs a)
 {
+    static_assert(!MC || BF, "conv1 on the bf16 MFMA: bf16 mode");
+    constexpr int MH = C1 / 16;                    // MC: 16-channel halves (2 / 1)
     constexpr bool WDL = WPE >= 3;
     constexpr int Q1 = C1 / 4;                     // channel quads per pixel (8 / 4)
     constexpr int PB = 3 * Q1 / 4;                 // conv1 pixels per lane (6 / 3): CR * (CC / PB) * Q1 = 240 busy lanes
@@ -188,6 +190,49 @@ __global__ __launch_bounds__(256, WPE) void stem_fused_f32(StemArgs a)
     }
     __syncthreads();
 
+    // ---- MC (bf16 mode, C1 = 32): conv1 as a GEMM on v_mfma_f32_16x16x32_bf16. The 10 x 18 region is 12 blocks of 16 pixels (three
+    // per wave), K = 27 taps padded to 32 = one instruction deep, the 32 channels two instructions wide. A lane gathers its
+    // pixel's 8 taps k = 8 kg .. 8 kg + 7 from the fp32 patch (k = 9 ky + 3 kx + ci sits at patch row 2r + ky, float 6c + k % 9),
+    // splits them exactly into bf16 hi + bf16 lo, and the products are hi*Whi + lo*Whi + hi*Wlo (the dropped lo*Wlo is 2^-16 of
+    // a product; the result is rounded to bf16 = 2^-9 right after). The weight operands are gathered and split once per kernel.
+    // In fp32 mode this form costs the same SIMD cycles as the packed VALU form (fp32 MFMA = VALU rate); in bf16 it is
+    // ~1100 against ~2500 cycles per wave and tile.
+    [[maybe_unused]] int mc_dl[8];
+    [[maybe_unused]] unsigned mc_kok = 0;                                     // bit j: tap k = 8 kg + j exists (k < 27)
+    [[maybe_unused]] bf8 mc_wh[MH], mc_wl[MH];
+    [[maybe_unused]] f4 mc_s1[MH], mc_b1[MH];                                    // BN of the lane's 4 output channels 16h + 4kg .. +3
+    if constexpr (MC) {
+        const int kg = lane >> 4, pc = lane & 15;
+        unsigned whb[MH][8], wlb[MH][8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int k = 8 * kg + j;
+            mc_dl[j] = (k / 9) * PROW + (k % 9);
+            if (k < 27) mc_kok |= 1u << j;
+#pragma unroll
+            for (int h = 0; h < MH; h++) {
+                const float w = k < 27 ? w1_s[k * C1 + 16 * h + pc] : 0.f;
+                const unsigned wb = __builtin_bit_cast(unsigned, w) & 0xffff0000u;
+                whb[h][j] = wb;
+                wlb[h][j] = __builtin_bit_cast(unsigned, w - __builtin_bit_cast(float, wb));
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < MH; h++) {
+            typedef unsigned u4 __attribute__((ext_vector_type(4)));
+            u4 ph, pl;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                ph[i] = (whb[h][2 * i] >> 16) | (whb[h][2 * i + 1] & 0xffff0000u);
+                pl[i] = (wlb[h][2 * i] >> 16) | (wlb[h][2 * i + 1] & 0xffff0000u);
+            }
+            mc_wh[h] = __builtin_bit_cast(bf8, ph);
+            mc_wl[h] = __builtin_bit_cast(bf8, pl);
+            mc_s1[h] = *reinterpret_cast<const f4 *>(sb_s + 16 * h + 4 * kg);
+            mc_b1[h] = *reinterpret_cast<const f4 *>(sb_s + C1 + 16 * h + 4 * kg);
+        }
+    }
+
     // phase B item of this lane: conv1 row br, pixels bc .. bc+PB-1 (lanes 240..255 have none)
     const int bpg = tid / Q1, br = bpg / (CC / PB), bc = (bpg % (CC / PB)) * PB;
     // phase C item: tile row cy, pixels cx .. cx+PC-1
@@ -203,6 +248,44 @@ __global__ __launch_bounds__(256, WPE) void stem_fused_f32(StemArgs a)
 
         // ---- B. conv1 (3x3x3, stride 2, pad 0 top/left) + BN + ReLU6 over the 10 x 18 region, 6 pixels x 4 ch per lane
         if (a.prio) __builtin_amdgcn_s_setprio(2);                  // VALU phases ahead of the co-resident workgroups' MFMA phase (A/B)
+        if constexpr (MC) {
+            typedef unsigned u4 __attribute__((ext_vector_type(4)));
+            const int kg = lane >> 4, pc = lane & 15;
+#pragma unroll 1
+            for (int bi = 0; bi < 3; bi++) {
+                const int blk = wave * 3 + bi;                            // 16-pixel block 0..11 of the region (pixels 180..191 do not exist)
+                const int q = 16 * blk + pc, p = min(q, CR * CC - 1);
+                const int r = (p * 3641) >> 16, c = p - r * CC;           // p / 18 for p < 192
+                const float *src = in_s + (2 * r) * PROW + 6 * c;
+                unsigned xb[8], lb[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const float x = ((mc_kok >> j) & 1u) ? src[mc_dl[j]] : 0.f;
+                    xb[j] = __builtin_bit_cast(unsigned, x) & 0xffff0000u;
+                    lb[j] = __builtin_bit_cast(unsigned, x - __builtin_bit_cast(float, xb[j]));
+                }
+                u4 ph, pl;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    ph[i] = (xb[2 * i] >> 16) | (xb[2 * i + 1] & 0xffff0000u);
+                    pl[i] = (lb[2 * i] >> 16) | (lb[2 * i + 1] & 0xffff0000u);
+                }
+                const bf8 xh = __builtin_bit_cast(bf8, ph), xl = __builtin_bit_cast(bf8, pl);
+                const int oy = TH * ty - 1 + r, ox = TW * tx - 1 + c;     // position of THIS lane's pixel in the conv1 map
+                const bool inside = oy >= 0 && oy < a.h && ox >= 0 && ox < a.h;
+#pragma unroll
+                for (int h = 0; h < MH; h++) {
+                    // weights as the A operand (rows = channels), pixels as B (columns): C/D puts channels 16h + 4kg .. +3 of
+                    // pixel pc into this lane: one float4 of BN, one 16-byte LDS store, the gather's (r, c) reused
+                    f4 acc = f4{ 0.f, 0.f, 0.f, 0.f };
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mc_wl[h], xh, acc, 0, 0, 0);      // smallest terms first
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mc_wh[h], xl, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mc_wh[h], xh, acc, 0, 0, 0);
+                    const f4 v = inside ? rbf4(bn_relu6(acc, mc_s1[h], mc_b1[h])) : f4{ 0.f, 0.f, 0.f, 0.f };   // outside: the depthwise zero padding
+                    if (q < CR * CC) *reinterpret_cast<f4 *>(c1_s + q * C1 + 16 * h + 4 * kg) = v;
+                }
+            }
+        } else
         if (bpg < CR * (CC / PB)) {
             f4 acc[PB];
 #pragma unroll
@@ -371,11 +454,13 @@ int mbn_launch_f32_stem(mbn_context *ctx, hipStream_t stream, float *out, const 
     if (grid > (long)a.ntiles) grid = (long)a.ntiles;
     const dim3 g((unsigned)grid), b(256);
     if (c1 == 32) {
-        if (bf16 && wpe_bf == 3) hipLaunchKernelGGL((stem_fused_f32<32, 64, true, 3>), g, b, 0, stream, a);
+        if (bf16 && wpe_bf == 3 && g_mbn_tune.conv_variant != 2) hipLaunchKernelGGL((stem_fused_f32<32, 64, true, 3, true>), g, b, 0, stream, a);   // conv1 on the bf16 MFMA (conv_variant=2: VALU form, A/B)
+        else if (bf16 && wpe_bf == 3) hipLaunchKernelGGL((stem_fused_f32<32, 64, true, 3>), g, b, 0, stream, a);
         else if (bf16) hipLaunchKernelGGL((stem_fused_f32<32, 64, true, 2>), g, b, 0, stream, a);
         else hipLaunchKernelGGL((stem_fused_f32<32, 64, false, 2>), g, b, 0, stream, a);
     } else {
-        if (bf16) hipLaunchKernelGGL((stem_fused_f32<16, 32, true, 4>), g, b, 0, stream, a);
+        if (bf16 && g_mbn_tune.conv_variant != 2) hipLaunchKernelGGL((stem_fused_f32<16, 32, true, 4, true>), g, b, 0, stream, a);
+        else if (bf16) hipLaunchKernelGGL((stem_fused_f32<16, 32, true, 4>), g, b, 0, stream, a);
         else hipLaunchKernelGGL((stem_fused_f32<16, 32, false, 4>), g, b, 0, stream, a);
     }
     return MBN_OK;
