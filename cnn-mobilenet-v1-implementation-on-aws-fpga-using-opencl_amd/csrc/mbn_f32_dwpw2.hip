@@ -290,8 +290,12 @@ __global__ __launch_bounds__(NT) void dwpw2_f32(DwPw2Args a)
         int vbL = vbD, kL = kD + 1, n0L = n0D;                                                                          \
         unsigned m0L = m0D;                                                                                             \
         if (validD) {                                                                                                   \
-            if (!(a.dbg & 8)) dma_filter<B_LD>(wrsrc, b_s0 + (P ^ 1) * BBUF, b_vo, (n0D * a.cin + kD * 32) * 4, wave_u); \
+            if (!(a.dbg & 8) && (a.dbg & 512)) dma_filter<B_LD>(wrsrc, b_s0 + (P ^ 1) * BBUF, b_vo, (n0D * a.cin + kD * 32) * 4, wave_u); /* dbg 512: DMA ahead of the depthwise part (before) */ \
             if (!(a.dbg & 2)) dw(kD, P ^ 1);                                                                            \
+            /* the filter DMA BEHIND the depthwise part: issued ahead of it, its two LDS-DMA operations were the wave's youngest */ \
+            /* vector-memory operations when the depthwise math needed the x window, and the compiler's wait for the window     */ \
+            /* (s_waitcnt vmcnt(1), vmcnt(0) in the ISA) waited out the DMA's whole L2 round trip at the start of every step   */ \
+            if (!(a.dbg & 8) && !(a.dbg & 512)) dma_filter<B_LD>(wrsrc, b_s0 + (P ^ 1) * BBUF, b_vo, (n0D * a.cin + kD * 32) * 4, wave_u); \
             validL = true;                                                                                              \
             if (kL >= nk) {                                                                                             \
                 kL = 0; vbL += gridDim.x; validL = vbL < nwg;                                                           \
