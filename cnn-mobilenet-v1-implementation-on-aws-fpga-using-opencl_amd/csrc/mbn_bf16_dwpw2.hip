@@ -90,9 +90,11 @@ __device__ __forceinline__ void dma_filter(__amdgpu_buffer_rsrc_t rsrc, float *l
                                                  16, voff[p], soff, 0, 0);
 }
 
-template <int S, int BN>
+// DBG = false: the shipped kernel, the experiment switches (a.dbg) fold away; DBG = true only for tune dwpw_variant >= 100
+template <int S, int BN, bool DBG>
 __global__ __launch_bounds__(NT) void dwpw2_bf16(DwPw2Args a)
 {
+    const int dbg = DBG ? a.dbg : 0;
     constexpr int WN = 64, WM = BN == 256 ? 64 : 32;   // wave tile: 8 waves as 2 x 4 (BN 256) or 4 x 2 (BN 128)
     constexpr int WAVES_N = BN / WN;
     static_assert((BM / WM) * WAVES_N == NW, "8 waves");
@@ -269,16 +271,16 @@ __global__ __launch_bounds__(NT) void dwpw2_bf16(DwPw2Args a)
         int vbL = vbD, kL = kD + 1, n0L = n0D;                                                                          \
         unsigned m0L = m0D;                                                                                             \
         if (validD) {                                                                                                   \
-            if (!(a.dbg & 8)) dma_filter<B_LD>(wrsrc, b_s0 + (P ^ 1) * BBUF, b_vo, (n0D * a.cin + kD * 64) * 2, wave_u); \
-            if (!(a.dbg & 2)) dw(kD, P ^ 1);                                                                            \
+            if (!(dbg & 8)) dma_filter<B_LD>(wrsrc, b_s0 + (P ^ 1) * BBUF, b_vo, (n0D * a.cin + kD * 64) * 2, wave_u); \
+            if (!(dbg & 2)) dw(kD, P ^ 1);                                                                            \
             validL = true;                                                                                              \
             if (kL >= nk) {                                                                                             \
                 kL = 0; vbL += gridDim.x; validL = vbL < nwg;                                                           \
                 if (validL) { origin(vbL, m0L, n0L); set_offsets(m0L); }                                                \
             }                                                                                                           \
-            if (validL && !(a.dbg & 1)) ldx(kL);                                                                        \
+            if (validL && !(dbg & 1)) ldx(kL);                                                                        \
         }                                                                                                               \
-        if (!(a.dbg & 16)) {                                                                                            \
+        if (!(dbg & 16)) {                                                                                            \
         _Pragma("unroll") for (int g = 0; g < 3; g++) {                                                                 \
             ldfrag(P, g + 1, (g + 1) & 1);                                                                              \
             __builtin_amdgcn_sched_barrier(0);                                                                          \
@@ -289,7 +291,7 @@ __global__ __launch_bounds__(NT) void dwpw2_bf16(DwPw2Args a)
         }                                                                                                               \
         if (validL) lds_barrier<NX>();                                                                                  \
         else lds_barrier<0>();                                                                                          \
-        if (kM == nk - 1 && !(a.dbg & 4)) {                                                                             \
+        if (kM == nk - 1 && !(dbg & 4)) {                                                                             \
             if (m0M + BM <= mtot) mbn_store_relu6_bf16_pair<MI, NI, 0>(orsrc, (unsigned)a.cout, m0M + wm, n0M + wn, lane, acc, sc3_s, sh3_s); \
             else mbn_store_relu6_bf16_pair<MI, NI, 1>(orsrc, (unsigned)a.cout, m0M + wm, n0M + wn, lane, acc, sc3_s, sh3_s);               \
             zero_acc();                                                                                                 \
@@ -314,7 +316,8 @@ void launch2(DwPw2Args &a, hipStream_t s, int num_cus)
     const long nwg = (long)a.mt * a.nt;
     long grid = num_cus;
     if (grid > nwg) grid = nwg;
-    hipLaunchKernelGGL((dwpw2_bf16<S, BN>), dim3((unsigned)grid), dim3(NT), 0, s, a);
+    if (a.dbg) hipLaunchKernelGGL((dwpw2_bf16<S, BN, true>), dim3((unsigned)grid), dim3(NT), 0, s, a);
+    else hipLaunchKernelGGL((dwpw2_bf16<S, BN, false>), dim3((unsigned)grid), dim3(NT), 0, s, a);
 }
 
 }   // namespace

@@ -99,9 +99,12 @@ __device__ __forceinline__ void dma_filter(__amdgpu_buffer_rsrc_t rsrc, float *l
                                                  16, voff[p], soff, 0, 0);
 }
 
-template <int S, int BN, bool PRE>
+// DBG = false: the shipped kernel — every experiment switch (a.dbg) folds away at compile time, which takes ~40 scalar branches and the
+// conservative waits around them out of the step. DBG = true is launched only for tune dwpw_variant >= 100.
+template <int S, int BN, bool PRE, bool DBG>
 __global__ __launch_bounds__(NT) void dwpw2_f32(DwPw2Args a)
 {
+    const int dbg = DBG ? a.dbg : 0;
     constexpr int WN = 64, WM = BN == 256 ? 64 : 32;   // wave tile: 8 waves as 2 x 4 (BN 256) or 4 x 2 (BN 128)
     constexpr int WAVES_N = BN / WN;
     static_assert((BM / WM) * WAVES_N == NW, "8 waves");
@@ -145,13 +148,13 @@ __global__ __launch_bounds__(NT) void dwpw2_f32(DwPw2Args a)
         fr_a[g] = swz(wm + li, 2 * g + lh);
         fr_b[g] = swz(wn + li, 2 * g + lh);
     }
-    const bool paired = !(a.dbg & 32);
+    const bool paired = !(dbg & 32);
     unsigned b_vo[B_LD];                                                        // filter piece offsets: fixed for the kernel, the tile's
 #pragma unroll                                                                  // column origin and the chunk go into the scalar offset
     for (int p = 0; p < B_LD; p++) {
         const int row = (p * NT + tid) >> 3;
         // channel-paired column blocks (mbn_epilogue.h): LDS filter row `row` holds output channel mbn_pair_channel(row), so the
-        // epilogue stores 8 bytes per lane, 256 contiguous bytes per pixel row; `pair` = a.dbg bit 5 switches it off (A/B)
+        // epilogue stores 8 bytes per lane, 256 contiguous bytes per pixel row; `pair` = dbg bit 5 switches it off (A/B)
         b_vo[p] = ((unsigned)(paired ? mbn_pair_channel(row) : row) * (unsigned)a.cin + (unsigned)(((c4 ^ (row >> 1)) & 7) * 4)) * 4u;
     }
     const float *wk = wd_s + c4 * 4;                                           // depthwise taps of this lane's 4 channels (+ kc*32 + tap*cin)
@@ -277,37 +280,37 @@ __global__ __launch_bounds__(NT) void dwpw2_f32(DwPw2Args a)
     else lds_barrier<0>();
 
     int stepno = 0;
-    const bool stamping = (a.dbg & 64) && blockIdx.x == 0;
+    const bool stamping = (dbg & 64) && blockIdx.x == 0;
 #define STAMP(k) do { if (stamping && stepno < 96) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) g_dwpw2_stamps[wave_u][stepno][k] = t_; } } while (0)
     // One chunk step with the MFMA chunk in buffer P (a literal at both call sites).
     // Returns false when the sequence is finished.
 #define MBN_DWPW2_STEP(P)                                                                                               \
     {                                                                                                                   \
         STAMP(0);                                                                                                       \
-        if (!(a.dbg & 256)) __builtin_amdgcn_s_setprio(3);       /* depthwise part ahead of the other wave's MFMAs, see below */ \
+        if (!(dbg & 256)) __builtin_amdgcn_s_setprio(3);       /* depthwise part ahead of the other wave's MFMAs, see below */ \
         ldfrag(P, 0, 0);                                                                                                \
         bool validL = false;                                                                                            \
         int vbL = vbD, kL = kD + 1, n0L = n0D;                                                                          \
         unsigned m0L = m0D;                                                                                             \
         if (validD) {                                                                                                   \
-            if (!(a.dbg & 8) && (a.dbg & 512)) dma_filter<B_LD>(wrsrc, b_s0 + (P ^ 1) * BBUF, b_vo, (n0D * a.cin + kD * 32) * 4, wave_u); /* dbg 512: DMA ahead of the depthwise part (before) */ \
-            if (!(a.dbg & 2)) dw(kD, P ^ 1);                                                                            \
+            if (!(dbg & 8) && (dbg & 512)) dma_filter<B_LD>(wrsrc, b_s0 + (P ^ 1) * BBUF, b_vo, (n0D * a.cin + kD * 32) * 4, wave_u); /* dbg 512: DMA ahead of the depthwise part (before) */ \
+            if (!(dbg & 2)) dw(kD, P ^ 1);                                                                            \
             /* the filter DMA BEHIND the depthwise part: issued ahead of it, its two LDS-DMA operations were the wave's youngest */ \
             /* vector-memory operations when the depthwise math needed the x window, and the compiler's wait for the window     */ \
             /* (s_waitcnt vmcnt(1), vmcnt(0) in the ISA) waited out the DMA's whole L2 round trip at the start of every step   */ \
-            if (!(a.dbg & 8) && !(a.dbg & 512)) dma_filter<B_LD>(wrsrc, b_s0 + (P ^ 1) * BBUF, b_vo, (n0D * a.cin + kD * 32) * 4, wave_u); \
+            if (!(dbg & 8) && !(dbg & 512)) dma_filter<B_LD>(wrsrc, b_s0 + (P ^ 1) * BBUF, b_vo, (n0D * a.cin + kD * 32) * 4, wave_u); \
             validL = true;                                                                                              \
             if (kL >= nk) {                                                                                             \
                 kL = 0; vbL += gridDim.x; validL = vbL < nwg;                                                           \
                 if (validL) { origin(vbL, m0L, n0L); set_offsets(m0L); }                                                \
             }                                                                                                           \
             STAMP(1);                                                                                                   \
-            if (validL && !(a.dbg & 1) && ((a.dbg & 128) || (a.dbg & 16))) ldx(kL);      /* dbg 128: the burst form (A/B) */ \
+            if (validL && !(dbg & 1) && ((dbg & 128) || (dbg & 16))) ldx(kL);      /* dbg 128: the burst form (A/B) */ \
         }                                                                                                               \
-        const bool spreadL = validL && !(a.dbg & 1) && !(a.dbg & 128) && !(a.dbg & 16);                                 \
+        const bool spreadL = validL && !(dbg & 1) && !(dbg & 128) && !(dbg & 16);                                 \
         __builtin_amdgcn_s_setprio(0);                                                                                  \
         STAMP(2);                                                                                                       \
-        if (!(a.dbg & 16)) {                                                                                            \
+        if (!(dbg & 16)) {                                                                                            \
         _Pragma("unroll") for (int g = 0; g < 3; g++) {                                                                 \
             ldfrag(P, g + 1, (g + 1) & 1);                                                                              \
             if (spreadL) ldx_part(kL, g);                                                                               \
@@ -324,7 +327,7 @@ __global__ __launch_bounds__(NT) void dwpw2_f32(DwPw2Args a)
         if (validL) lds_barrier<NX>();                                                                                  \
         else lds_barrier<0>();                                                                                          \
         STAMP(4);                                                                                                       \
-        if (kM == nk - 1 && !(a.dbg & 4)) {                                                                             \
+        if (kM == nk - 1 && !(dbg & 4)) {                                                                             \
             if (paired) {                                                                                               \
                 if (m0M + BM <= mtot) mbn_store_relu6_f32_pair<MI, NI, 0>(orsrc, (unsigned)a.cout, m0M + wm, n0M + wn, lane, acc, sc3_s, sh3_s); \
                 else mbn_store_relu6_f32_pair<MI, NI, 1>(orsrc, (unsigned)a.cout, m0M + wm, n0M + wn, lane, acc, sc3_s, sh3_s);               \
@@ -355,8 +358,11 @@ void launch2(DwPw2Args &a, hipStream_t s, int num_cus, bool pre)
     const long nwg = (long)a.mt * a.nt;
     long grid = num_cus;
     if (grid > nwg) grid = nwg;
-    if (pre) hipLaunchKernelGGL((dwpw2_f32<S, BN, true>), dim3((unsigned)grid), dim3(NT), 0, s, a);
-    else hipLaunchKernelGGL((dwpw2_f32<S, BN, false>), dim3((unsigned)grid), dim3(NT), 0, s, a);
+    if (a.dbg) {
+        if (pre) hipLaunchKernelGGL((dwpw2_f32<S, BN, true, true>), dim3((unsigned)grid), dim3(NT), 0, s, a);
+        else hipLaunchKernelGGL((dwpw2_f32<S, BN, false, true>), dim3((unsigned)grid), dim3(NT), 0, s, a);
+    } else if (pre) hipLaunchKernelGGL((dwpw2_f32<S, BN, true, false>), dim3((unsigned)grid), dim3(NT), 0, s, a);
+    else hipLaunchKernelGGL((dwpw2_f32<S, BN, false, false>), dim3((unsigned)grid), dim3(NT), 0, s, a);
 }
 
 }   // namespace
