@@ -39,7 +39,6 @@ constexpr int PROW = 112;                      // floats per patch row in LDS (3
 constexpr int PROWPAD = 4;                     // tail pad of the patch: the last lane's 16-byte reads run 2 floats past a row
 
 struct StemArgs {
-    int prio;               // experiment: s_setprio around the VALU phases
 
     float *out;
     const float *in, *w1, *s1, *b1, *wd, *s2, *b2, *wp, *s3, *b3;
@@ -247,7 +246,7 @@ __global__ __launch_bounds__(256, WPE) void stem_fused_f32(StemArgs a)
         if (tnext < a.ntiles) patch_load(a, tnext, tid, pf);              // in flight while phase B computes
 
         // ---- B. conv1 (3x3x3, stride 2, pad 0 top/left) + BN + ReLU6 over the 10 x 18 region, 6 pixels x 4 ch per lane
-        if (a.prio) __builtin_amdgcn_s_setprio(2);                  // VALU phases ahead of the co-resident workgroups' MFMA phase (A/B)
+        __builtin_amdgcn_s_setprio(2);                              // VALU phases ahead of the co-resident workgroups' MFMA phase (-3 % / -5 %: profiles/r02/j_stem_occupancy.txt)
         if constexpr (MC) {
             typedef unsigned u4 __attribute__((ext_vector_type(4)));
             const int kg = lane >> 4, pc = lane & 15;
@@ -363,7 +362,7 @@ __global__ __launch_bounds__(256, WPE) void stem_fused_f32(StemArgs a)
         __syncthreads();
 
         // ---- D. pointwise C1 -> C3: wave w computes rows 32w .. 32w+31 x all C3 columns
-        if (a.prio) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(0);
         f16v acc[NI];
 #pragma unroll
         for (int ni = 0; ni < NI; ni++)
@@ -382,7 +381,6 @@ __global__ __launch_bounds__(256, WPE) void stem_fused_f32(StemArgs a)
                     acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, av), __builtin_bit_cast(bf8, bv), acc[ni], 0, 0, 0);
                 }
             }
-            if (a.prio == 2) __builtin_amdgcn_s_setprio(2);
             __bf16 *otile = reinterpret_cast<__bf16 *>(a.out) + ((n * a.h + TH * ty) * a.h + TW * tx) * C3;
 #pragma unroll
             for (int r = 0; r < 16; r++) {
@@ -410,7 +408,6 @@ __global__ __launch_bounds__(256, WPE) void stem_fused_f32(StemArgs a)
 #pragma unroll
                 for (int ni = 0; ni < NI; ni++) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[ni][s], acc[ni], 0, 0, 0);
         }
-        if (a.prio == 2) __builtin_amdgcn_s_setprio(2);
         float *obase = a.out + ((n * a.h + TH * ty) * a.h + TW * tx) * C3;
 #pragma unroll
         for (int ni = 0; ni < NI; ni++)
@@ -442,7 +439,6 @@ int mbn_launch_f32_stem(mbn_context *ctx, hipStream_t stream, float *out, const 
     StemArgs a;
     a.in8 = in_u8 ? (const uint8_t *)in : nullptr;
     a.out = out; a.in = in; a.w1 = w1; a.s1 = s1; a.b1 = b1; a.wd = wd; a.s2 = s2; a.b2 = b2; a.wp = wp; a.s3 = s3; a.b3 = b3;
-    a.prio = g_mbn_tune.conv_variant == 5 ? 0 : g_mbn_tune.conv_variant == 6 ? 2 : 1;   // A/B hooks: 5 = no s_setprio, 6 = also over the epilogue
     a.batch = batch; a.res = res; a.h = res / 2;
     a.tiles_y = a.h / TH; a.tiles_x = a.h / TW;
     if ((long)batch * a.tiles_y * a.tiles_x >= 0x7fffffffL) return MBN_EUNSUPPORTED;
