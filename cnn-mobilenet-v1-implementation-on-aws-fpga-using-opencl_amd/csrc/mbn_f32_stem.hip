@@ -22,6 +22,7 @@
 // pixel instead of 8 and every phase hands a lane half as many pixels (3 instead of 6 in conv1, 2 instead of 4 in the
 // depthwise) to keep all 256 lanes busy; A/B tile rows are 64 instead of 128 bytes (four 16-byte slots, their own swizzle).
 #include "mbn_internal.h"
+#include "mbn_epilogue.h"
 
 namespace {
 
@@ -381,18 +382,23 @@ __global__ __launch_bounds__(256, WPE) void stem_fused_f32(StemArgs a)
                     acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, av), __builtin_bit_cast(bf8, bv), acc[ni], 0, 0, 0);
                 }
             }
-            __bf16 *otile = reinterpret_cast<__bf16 *>(a.out) + ((n * a.h + TH * ty) * a.h + TW * tx) * C3;
+            // Buffer stores as in mbn_epilogue.h: descriptor = this image's output map (< 4 GiB whatever the batch), the per-lane
+            // byte offset is ONE VGPR for all 16 stores (the lane's half lh shifts the pixel by 4 columns: row q = 32 wave + (r & 3) +
+            // 8 (r >> 2) + 4 lh sits at y = 2 wave + (r >> 3), x = (r & 3) + 8 ((r >> 2) & 1) + 4 lh of the 8 x 16 tile), the
+            // wave-uniform rest is the scalar offset: no 64-bit address arithmetic per store.
+            const __amdgpu_buffer_rsrc_t orsrc = mbn_make_rsrc(reinterpret_cast<__bf16 *>(a.out) + n * a.h * a.h * C3, (unsigned)(a.h * a.h * C3 * 2));
+            const unsigned lane_off = (unsigned)(4 * lh * C3) * 2u + (unsigned)li * (NI == 2 ? 4u : 2u);
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const int q = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int y = q >> 4, x = q & 15;
+                const int y = TH * ty + 2 * __builtin_amdgcn_readfirstlane(wave) + (r >> 3), x = TW * tx + (r & 3) + 8 * ((r >> 2) & 1);
+                const unsigned soff = (unsigned)((y * a.h + x) * C3) * 2u;
                 if constexpr (NI == 2) {
                     // channel-paired store: lane li holds channels 2li (acc[0]) and 2li+1 (acc[1]) of pixel row q: one dword per
                     // row, 32 lanes = the pixel's whole 128-byte line
                     const float v0 = relu6(fmaf(acc[0][r], s3[0], b3[0])), v1 = relu6(fmaf(acc[1][r], s3[1], b3[1]));
-                    reinterpret_cast<unsigned *>(otile + ((long)y * a.h + x) * C3)[li] = __builtin_bit_cast(unsigned, bf2{ (__bf16)v0, (__bf16)v1 });
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, bf2{ (__bf16)v0, (__bf16)v1 }), orsrc, lane_off, soff, 0);
                 } else {
-                    otile[((long)y * a.h + x) * C3 + li] = (__bf16)relu6(fmaf(acc[0][r], s3[0], b3[0]));
+                    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (__bf16)relu6(fmaf(acc[0][r], s3[0], b3[0]))), orsrc, lane_off, soff, 0);
                 }
             }
         } else {
@@ -408,15 +414,30 @@ __global__ __launch_bounds__(256, WPE) void stem_fused_f32(StemArgs a)
 #pragma unroll
                 for (int ni = 0; ni < NI; ni++) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[ni][s], acc[ni], 0, 0, 0);
         }
-        float *obase = a.out + ((n * a.h + TH * ty) * a.h + TW * tx) * C3;
+        if constexpr (C1 == 32) {
+            // alpha = 1 in fp32 keeps plain global stores: the buffer-store form below measured 1.2 % SLOWER here (0.3077 against 0.3040 ms,
+            // same call, three repetitions) although it drops ~80 address instructions and 32 VGPRs; it wins at alpha = 0.5 (-6 %) and in bf16
+            float *obase = a.out + ((n * a.h + TH * ty) * a.h + TW * tx) * C3;
+#pragma unroll
+            for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int q = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const int y = q >> 4, x = q & 15;
+                    obase[((long)y * a.h + x) * C3 + ni * 32 + li] = relu6(fmaf(acc[ni][r], s3[ni], b3[ni]));
+                }
+        } else {
+        const __amdgpu_buffer_rsrc_t orsrc = mbn_make_rsrc(a.out + n * a.h * a.h * C3, (unsigned)(a.h * a.h * C3 * 4));   // see the bf16 branch
+        const unsigned lane_off = (unsigned)(4 * lh * C3 + li) * 4u;
 #pragma unroll
         for (int ni = 0; ni < NI; ni++)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const int q = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int y = q >> 4, x = q & 15;
-                obase[((long)y * a.h + x) * C3 + ni * 32 + li] = relu6(fmaf(acc[ni][r], s3[ni], b3[ni]));
+                const int y = TH * ty + 2 * __builtin_amdgcn_readfirstlane(wave) + (r >> 3), x = TW * tx + (r & 3) + 8 * ((r >> 2) & 1);
+                const unsigned soff = (unsigned)((y * a.h + x) * C3 + ni * 32) * 4u;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, relu6(fmaf(acc[ni][r], s3[ni], b3[ni]))), orsrc, lane_off, soff, 0);
             }
+        }
         }
         // No barrier here: the next tile's B writes c1_s (last read in C, one barrier ago) and its C writes a_s only after
         // the barrier that follows B, which every wave reaches after finishing the a_s reads above.
@@ -455,7 +476,11 @@ int mbn_launch_f32_stem(mbn_context *ctx, hipStream_t stream, float *out, const 
         else if (bf16) hipLaunchKernelGGL((stem_fused_f32<32, 64, true, 2>), g, b, 0, stream, a);
         else hipLaunchKernelGGL((stem_fused_f32<32, 64, false, 2>), g, b, 0, stream, a);
     } else {
-        if (bf16 && g_mbn_tune.conv_variant != 2) hipLaunchKernelGGL((stem_fused_f32<16, 32, true, 4, true>), g, b, 0, stream, a);
+        if (bf16 && g_mbn_tune.conv_variant != 2) {            // MFMA conv1 + buffer-store epilogue: 92 VGPRs, 28.6 KB of LDS: five workgroups per CU (0.1163 -> 0.1108 ms)
+            long g5 = (long)ctx->num_cus * 5;
+            if (g5 > (long)a.ntiles) g5 = (long)a.ntiles;
+            hipLaunchKernelGGL((stem_fused_f32<16, 32, true, 5, true>), dim3((unsigned)g5), b, 0, stream, a);
+        }
         else if (bf16) hipLaunchKernelGGL((stem_fused_f32<16, 32, true, 4>), g, b, 0, stream, a);
         else hipLaunchKernelGGL((stem_fused_f32<16, 32, false, 4>), g, b, 0, stream, a);
     }
