@@ -81,6 +81,8 @@ constexpr int NPF = (PR * PAIRS + 255) / 256;  // float2 prefetch registers per 
 
 // Phase A, first half: this lane's float2 pieces of tile t's input patch (rows 16ty-2 .. 16ty+18, floats 96tx-6 ..
 // 96tx+105 of each row), zero outside the image. Pair boundaries never straddle the image edge (96tx-6 and 3*res even).
+// Branch-free: buffer loads against this image's descriptor; a piece outside the image (or past the patch) carries an out-of-range
+// offset and the hardware returns zeros (the exec-masked form compiled to two branches per load and a vmcnt(0) drain behind them).
 __device__ __forceinline__ void patch_load(const StemArgs &a, unsigned t, int tid, f2 (&pf)[NPF])
 {
     const int tx = (int)(t % (unsigned)a.tiles_x);
@@ -89,19 +91,28 @@ __device__ __forceinline__ void patch_load(const StemArgs &a, unsigned t, int ti
     const long n = q0 / (unsigned)a.tiles_y;
     const long img = n * a.res * a.res * 3;
     const int iy0 = 2 * (TH * ty - 1), fx0 = 6 * (TW * tx - 1), rowf = a.res * 3;
+    constexpr unsigned OOB = 0xF0000000u;
+    const unsigned img_elems = (unsigned)(a.res * a.res * 3);
+    if (a.in8) {
+        const __amdgpu_buffer_rsrc_t rsrc = mbn_make_rsrc(a.in8 + img, img_elems);
 #pragma unroll
-    for (int k = 0; k < NPF; k++) {
-        const int i = tid + k * 256, r = i / PAIRS, j = i % PAIRS;
-        const int iy = iy0 + r, fx = fx0 + 2 * j;
-        f2 v = f2{ 0.f, 0.f };                                            // the zero padding is zero AFTER normalisation
-        if (i < PR * PAIRS && iy >= 0 && iy < a.res && fx >= 0 && fx < rowf) {
-            const long e = img + (long)iy * rowf + fx;
-            if (a.in8) {                                                  // same fmaf as normalize_u8_f32: bit-identical
-                const unsigned u = *reinterpret_cast<const unsigned short *>(a.in8 + e);
-                v = f2{ fmaf((float)(u & 0xff), 1.0f / 127.5f, -1.0f), fmaf((float)(u >> 8), 1.0f / 127.5f, -1.0f) };
-            } else v = *reinterpret_cast<const f2 *>(a.in + e);
+        for (int k = 0; k < NPF; k++) {
+            const int i = tid + k * 256, r = i / PAIRS, j = i % PAIRS;
+            const int iy = iy0 + r, fx = fx0 + 2 * j;
+            const bool ok = i < PR * PAIRS && iy >= 0 && iy < a.res && fx >= 0 && fx < rowf;
+            const unsigned u = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsrc, ok ? (unsigned)(iy * rowf + fx) : OOB, 0, 0);
+            // same fmaf as normalize_u8_f32: bit-identical; the zero padding is zero AFTER normalisation
+            pf[k] = ok ? f2{ fmaf((float)(u & 0xff), 1.0f / 127.5f, -1.0f), fmaf((float)(u >> 8), 1.0f / 127.5f, -1.0f) } : f2{ 0.f, 0.f };
         }
-        pf[k] = v;
+    } else {
+        const __amdgpu_buffer_rsrc_t rsrc = mbn_make_rsrc(a.in + img, img_elems * 4u);
+#pragma unroll
+        for (int k = 0; k < NPF; k++) {
+            const int i = tid + k * 256, r = i / PAIRS, j = i % PAIRS;
+            const int iy = iy0 + r, fx = fx0 + 2 * j;
+            const bool ok = i < PR * PAIRS && iy >= 0 && iy < a.res && fx >= 0 && fx < rowf;
+            pf[k] = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, ok ? (unsigned)(iy * rowf + fx) * 4u : OOB, 0, 0));
+        }
     }
 }
 __device__ __forceinline__ void patch_store(float *in_s, int tid, const f2 (&pf)[NPF])
