@@ -145,6 +145,12 @@ def main():
     ap.add_argument("--device-override", type=int, default=-1, help="rehearsal only: every rank uses this device")
     ap.add_argument("--graph", action="store_true", help="replay each step as one hipGraph (mbn_net_set_graph)")
     ap.add_argument("--tune", action="append", default=[], help="key=value passed to mbn_tune_set (experiments)")
+    ap.add_argument("--pw-emul", type=int, default=0, choices=[0, 6, 9],
+                    help="fp32 only, OPT-IN: run the stand-alone pointwise layers on mbn_f32_pw_x6.hip (every fp32 operand split exactly "
+                         "into three bf16 values, 6 or 9 bf16 MFMA partial products per product, fp32 accumulate; include/mbn.h "
+                         "tune key pw_emul). The default line measures the fp32-MFMA kernels and reports this form beside it "
+                         "as `pw_emul_alt`")
+    ap.add_argument("--no-pw-emul-alt", action="store_true", help="skip the untimed-by-`value` pw_emul=6 pass of the default fp32 line")
     ap.add_argument("--no-fuse-stem", action="store_true", help="run layers 1-3 as three launches instead of mbn_stem_fused")
     ap.add_argument("--fuse-blocks", type=lambda v: int(v, 0), default=None,
                     help="mask for mbn_net_set_fuse_blocks (bit L = fuse depthwise layer L with pointwise L+1); default: library's")
@@ -181,6 +187,8 @@ def main():
     for kv in args.tune:
         k, v = kv.split("=")
         assert lib.mbn_tune_set(k.encode(), int(v)) == 0, kv
+    if args.pw_emul and args.dtype == "f32":
+        assert lib.mbn_tune_set(b"pw_emul", args.pw_emul) == 0
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
@@ -292,6 +300,29 @@ def main():
     if not np.isfinite(logits).all():
         sys.exit("non-finite logits")
 
+    # ---- the opt-in split form of the pointwise GEMM beside the default line (N = 1, fp32): same net, same buffers, same
+    # stream configuration, 3 warm-up + 10 timed steps without per-kernel events. Never part of `value`.
+    alt = None
+    if world == 1 and not bf16 and not args.pw_emul and not args.no_pw_emul_alt and not args.graph:
+        assert lib.mbn_tune_set(b"pw_emul", 6) == 0
+        for _ in range(3):
+            net.forward(d_in.ptr, d_out.ptr, args.batch)
+        torch.cuda.synchronize()
+        a0 = time.perf_counter()
+        for _ in range(10):
+            net.forward(d_in.ptr, d_out.ptr, args.batch)
+        torch.cuda.synchronize()
+        a1 = time.perf_counter()
+        assert lib.mbn_tune_set(b"pw_emul", 0) == 0
+        alt_logits = d_out.download((args.batch, 1000), np.float32)
+        alt = {"pw_emul": 6, "value": args.batch * 10 / (a1 - a0), "unit": "images/sec", "ms_per_step": 100.0 * (a1 - a0),
+               "steps": 10, "warmup": 3,
+               "max_rel_diff_to_default_logits": float(np.abs(alt_logits.astype(np.float64) - logits).max() / max(float(np.abs(logits).max()), 1e-6)),
+               "what": "mbn_tune_set(\"pw_emul\", 6): the stand-alone pointwise layers on mbn_f32_pw_x6.hip - fp32 in/out, every "
+                       "operand split exactly into three bf16 values, 6 bf16 MFMA partial products per fp32 product (the dropped "
+                       "three are < 2^-24 of it), fp32 accumulate; measured error against float64 <= the fp32 MFMA kernel's "
+                       "(profiles/r02/m_pw_emul.txt). Opt-in: `value` above is the fp32-MFMA path"}
+
     if rank == 0:
         total_images = args.batch * world * args.steps
         out = {
@@ -381,6 +412,20 @@ def main():
                                      "stages": ust, "layers": ulayers, "sum_kernel_ms": round(float(ums.sum()), 4)}
             net.set_fuse_stem(not args.no_fuse_stem)
             net.set_fuse_blocks(saved_mask)
+        if alt is not None:
+            out["pw_emul_alt"] = alt
+        if args.pw_emul and not bf16:
+            out["config"]["pw_emul"] = args.pw_emul
+            out["config"]["arithmetic"] = ("stand-alone pointwise layers: fp32 operands split exactly into three bf16 values, %d bf16 "
+                                           "MFMA partial products per product, fp32 accumulate (mbn_f32_pw_x6.hip)" % args.pw_emul)
+            if "roofline" in out and out["roofline"].get("bound") == "mfma":
+                r = out["roofline"]
+                r["kernel"] = "pw_gemm_x (%d bf16 partial products per fp32 product) " % args.pw_emul + r["kernel"]
+                r["fp32_equivalent_tflops"] = r["achieved"]
+                r["achieved"] = round(r["achieved"] * args.pw_emul, 2)
+                r["peak"] = 2500.0
+                r["frac"] = round(r["achieved"] / 2500.0, 4)
+                r["note"] = "achieved = %d x the algorithmic fp32 flops (the bf16 MFMA work actually issued) against the dense bf16 peak" % args.pw_emul
         if world == 1 and not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import oracle as orc   # cpu_baseline leg: the oracle is the thing timed here, never the product path
@@ -402,6 +447,10 @@ def main():
             scale = max(float(np.abs(ref).max()), 1e-6)
             err = float(np.abs(got - ref).max()) / scale
             tol = 6e-2 if bf16 else 1e-3
+            if alt is not None:
+                aerr = float(np.abs(alt_logits[:n_img].astype(np.float64) - ref).max()) / scale
+                alt["parity_check"] = {"images": n_img, "max_rel_err": aerr, "tolerance": tol, "ok": bool(aerr <= tol),
+                                       "argmax_agree": int((alt_logits[:n_img].argmax(1) == ref.argmax(1)).sum())}
             out["parity_check"] = {"images": n_img, "max_rel_err": err, "tolerance": tol, "ok": bool(err <= tol),
                                    "argmax_agree": int((got.argmax(1) == ref.argmax(1)).sum()),
                                    "against": "oracle/mbn_oracle.c F32 mode%s, logits of the first %d images of the timed batch"
@@ -437,6 +486,10 @@ def main():
             got = logits[:n_img].astype(np.float64)
             err = float(np.abs(got - ref).max()) / max(float(np.abs(ref).max()), 1e-6)
             tol = 6e-2 if bf16 else 1e-3
+            if alt is not None:
+                aerr = float(np.abs(alt_logits[:n_img].astype(np.float64) - ref).max()) / scale
+                alt["parity_check"] = {"images": n_img, "max_rel_err": aerr, "tolerance": tol, "ok": bool(aerr <= tol),
+                                       "argmax_agree": int((alt_logits[:n_img].argmax(1) == ref.argmax(1)).sum())}
             out["parity_check"] = {"images": n_img, "max_rel_err": err, "tolerance": tol, "ok": bool(err <= tol),
                                    "argmax_agree": int((got.argmax(1) == ref.argmax(1)).sum()),
                                    "against": "oracle/mbn_oracle.c F32 mode%s, logits of the first %d images of rank 0's shard"

@@ -67,6 +67,7 @@ static std::atomic<int> *tune_slot(const char *key)
     if (!strcmp(key, "pw_xn")) return &g_mbn_tune.pw_xn;
     if (!strcmp(key, "pw_ring")) return &g_mbn_tune.pw_ring;
     if (!strcmp(key, "pw_splitk")) return &g_mbn_tune.pw_splitk;
+    if (!strcmp(key, "pw_emul")) return &g_mbn_tune.pw_emul;
     if (!strcmp(key, "lit_dot")) return &g_mbn_tune.lit_dot;
     return nullptr;
 }

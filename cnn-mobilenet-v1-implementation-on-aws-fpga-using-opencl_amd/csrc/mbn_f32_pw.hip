@@ -546,6 +546,9 @@ int mbn_launch_f32_pointwise(const mbn_call &c, void *out, const void *in, const
     // K = 256 up (one 8-wave workgroup per CU hides the per-k-tile LDS-DMA issue cost and fragment latency worse than two
     // 8-wave workgroups of the tiled kernel: profiles/r02/d_bf16_ring_gemm.txt). pw_ring: 1 = never, 2 = wherever eligible.
     const int ring_mode = g_mbn_tune.pw_ring;
+    // opt-in: fp32 products on the bf16 matrix cores from exact operand splits (mbn_f32_pw_x6.hip; pw_emul = 6 | 9)
+    if (!bf && g_mbn_tune.pw_emul != 0 && mbn_launch_f32_pw_emul(c, (float *)out, (const float *)in, (const float *)filt, m, cin, op_size) == MBN_OK)
+        return MBN_OK;
     // fp32, few tiles (batch 1..4): K split over the waves of a 16x16-tile workgroup (mbn_f32_pw_splitk.hip)
     if (!bf && g_mbn_tune.pw_tile == 0 && mbn_launch_f32_pw_splitk(c, (float *)out, (const float *)in, (const float *)filt, m, cin, op_size) == MBN_OK)
         return MBN_OK;

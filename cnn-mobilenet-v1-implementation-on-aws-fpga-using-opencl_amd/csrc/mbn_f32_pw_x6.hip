@@ -1,0 +1,323 @@
+// mbn_f32_pw_x6.hip — OPT-IN form of the fp32 1x1 pointwise GEMM (kernel.cl:94-114) that computes the fp32 products on the
+// bf16 matrix cores from an EXACT three-way split of every operand. Not the default: mbn_tune_set("pw_emul", 6 | 9).
+//
+// Every fp32 x is written as x = h + m + l with h = bf16(x), m = bf16(x - h), l = x - h - m: both subtractions are exact in
+// fp32 and l has at most 8 significant bits, so the three bf16 values carry all 24 bits of x (checked bit for bit by the
+// parity tests on random data: h + m + l == x). a*b is then the sum of nine bf16 x bf16 products, each of them EXACT in the
+// fp32 accumulator of v_mfma_f32_32x32x16_bf16; pw_emul = 9 issues all nine, pw_emul = 6 drops m*l, l*m and l*l, whose sum is
+// below 2^-24 |a*b| — less than the rounding of the one fp32 product they belong to. What differs from pw_gemm<float> is
+// therefore the ORDER of the fp32 additions (as between pw_gemm and the split-K kernel), not the precision of the terms:
+// tests/test_parity_gpu.py holds both forms to the same per-layer bound against the double-precision oracle as the fp32
+// MFMA kernel, and profiles/r02/m_pw_emul.txt lists the three error figures side by side.
+//
+// Why: v_mfma_f32_32x32x2_f32 retires 64 FLOP/clk/SIMD, v_mfma_f32_32x32x16_bf16 1024: six bf16 MFMAs per 16 k replace
+// eight fp32 MFMAs of twice the duration each — 2.7x fewer matrix-pipe cycles (1.8x with nine). The split itself is VALU
+// work (about 5 instructions per element: 2 conversions, 2 subtractions, shifts), and VALU time ADDS to MFMA time on a SIMD
+// (DESIGN §3.6), so it is done ONCE per workgroup tile on the way into LDS — global -> registers -> three bf16 planes in LDS —
+// not per wave in the fragment path; a 128x128 tile splits (128 + 128) x 32 values per 32 k for 4 x 48 MFMAs.
+//
+// LDS: per buffer three planes [rows][64 B] for A and three for B (32 k of bf16 per row); the 16-byte chunk index is XORed
+// with (row >> 2) & 3, which makes both the staging ds_write_b128 (4 lanes per row) and the fragment ds_read_b128 (16
+// consecutive rows, one chunk) hit 16 distinct 16-byte slots of the 256-byte bank row. Double-buffered over K, one barrier
+// per k-tile; persistent workgroups with the XCD-contiguous tile order of pw_gemm; scale/shift staged in LDS; the same
+// buffer-store epilogue (mbn_epilogue.h).
+#include "mbn_internal.h"
+#include "mbn_epilogue.h"
+
+namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef mbn_f16v f16v;
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+
+struct XArgs {
+    float *out;
+    const float *in, *filt, *scale, *shift;
+    long m;
+    int k, n, act;
+    int mt, nt;
+    int fast_epi;
+};
+
+constexpr int KT = 32;            // k per k-tile
+constexpr int PW = 16;            // 4-byte words per plane row (32 bf16)
+
+__device__ __forceinline__ int pswz(int row, int c) { return row * PW + (((c ^ (row >> 2)) & 3) << 2); }
+
+__device__ __forceinline__ int x_remap(int vb, int nwg)
+{
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = vb & 7;
+    return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (vb >> 3);
+}
+
+// 8 consecutive k of one row -> the three bf16 planes (exact: h + m + l == x)
+__device__ __forceinline__ void split8(const f4 &x0, const f4 &x1, u4 &H, u4 &M, u4 &L)
+{
+    const f2 v[4] = { f2{ x0.x, x0.y }, f2{ x0.z, x0.w }, f2{ x1.x, x1.y }, f2{ x1.z, x1.w } };
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const bf2 h = __builtin_convertvector(v[j], bf2);
+        const f2 r = v[j] - __builtin_convertvector(h, f2);
+        const bf2 m = __builtin_convertvector(r, bf2);
+        const f2 l = r - __builtin_convertvector(m, f2);
+        const bf2 lo = __builtin_convertvector(l, bf2);
+        H[j] = __builtin_bit_cast(unsigned, h);
+        M[j] = __builtin_bit_cast(unsigned, m);
+        L[j] = __builtin_bit_cast(unsigned, lo);
+    }
+}
+
+// product list: plane of A, plane of B (0 = h, 1 = m, 2 = l); smallest terms first
+template <int NP> struct Prod;
+template <> struct Prod<9> { static constexpr int pa[9] = { 2, 2, 1, 2, 0, 1, 1, 0, 0 }, pb[9] = { 2, 1, 2, 0, 2, 1, 0, 1, 0 }; };
+template <> struct Prod<6> { static constexpr int pa[6] = { 2, 0, 1, 1, 0, 0 }, pb[6] = { 0, 2, 1, 0, 1, 0 }; };
+template <> struct Prod<3> { static constexpr int pa[3] = { 1, 0, 0 }, pb[3] = { 0, 1, 0 }; };      // measurement only: 2^-16
+template <> struct Prod<1> { static constexpr int pa[1] = { 0 }, pb[1] = { 0 }; };                  // measurement only: bf16 operands
+
+template <int BM, int BN, int WM, int WN, int NP, int NBUF, int OCC>
+__global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void pw_gemm_x(XArgs a)
+{
+    constexpr int WAVES_N = BN / WN, NT = 64 * (BM / WM) * WAVES_N;
+    constexpr int MI = WM / 32, NI = WN / 32;
+    constexpr int RP = NT / 4;                               // rows per staging pass (4 lanes x 32 B per row)
+    constexpr int A_LD = BM / RP, B_LD = BN / RP;
+    static_assert(A_LD >= 1 && B_LD >= 1 && A_LD * RP == BM && B_LD * RP == BN, "tile/threads mismatch");
+    constexpr int PLANE_A = BM * PW, PLANE_B = BN * PW, BUF = 3 * (PLANE_A + PLANE_B);
+    constexpr int NPL = NP == 1 ? 1 : NP == 3 ? 2 : 3;       // planes actually used
+    // behind the planes: scale | shift of this tile's BN columns, two slots by tile parity (written at the top of a tile, read in
+    // its epilogue; the slot is rewritten two tiles later, with that tile's barriers in between)
+    __shared__ __attribute__((aligned(16))) unsigned lds[NBUF * BUF + 4 * BN];
+    float *const ss_s = reinterpret_cast<float *>(lds + NBUF * BUF);
+    const bool ss_lds = a.scale && a.shift;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nwg = a.mt * a.nt;
+    const int wm = (wave / WAVES_N) * WM, wn = (wave % WAVES_N) * WN;
+    const int li = lane & 31, lh = lane >> 5;
+    const int nk = a.k / KT;
+    const int st_c = tid & 3, st_r = tid >> 2;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int wm_u = (wave_u / WAVES_N) * WM, wn_u = (wave_u % WAVES_N) * WN;
+    const __amdgpu_buffer_rsrc_t orsrc = mbn_make_rsrc(a.out, a.fast_epi ? (unsigned)(a.m * a.n * 4L) : 0u);
+
+    const float *a_src[A_LD], *b_src[B_LD];
+    f4 a_reg[A_LD][2], b_reg[B_LD][2];
+    int st_off[A_LD > B_LD ? A_LD : B_LD];
+#pragma unroll
+    for (int p = 0; p < (A_LD > B_LD ? A_LD : B_LD); p++) st_off[p] = pswz(p * RP + st_r, st_c);
+
+    auto set_tile = [&](int vb, long &m0, int &n0) {
+        const int lid = x_remap(vb, nwg);
+        m0 = (long)(lid / a.nt) * BM;
+        n0 = (lid % a.nt) * BN;
+#pragma unroll
+        for (int p = 0; p < A_LD; p++) {
+            long gm = m0 + p * RP + st_r;
+            if (gm >= a.m) gm = a.m - 1;                     // rows past M are computed but never stored
+            a_src[p] = a.in + gm * a.k + st_c * 8;
+        }
+#pragma unroll
+        for (int p = 0; p < B_LD; p++) {
+            int gn = n0 + p * RP + st_r;
+            if (gn >= a.n) gn = a.n - 1;
+            b_src[p] = a.filt + (long)gn * a.k + st_c * 8;
+        }
+    };
+    auto stage_load = [&](int k0) {
+#pragma unroll
+        for (int p = 0; p < A_LD; p++) {
+            a_reg[p][0] = *reinterpret_cast<const f4 *>(a_src[p] + k0);
+            a_reg[p][1] = *reinterpret_cast<const f4 *>(a_src[p] + k0 + 4);
+        }
+#pragma unroll
+        for (int p = 0; p < B_LD; p++) {
+            b_reg[p][0] = *reinterpret_cast<const f4 *>(b_src[p] + k0);
+            b_reg[p][1] = *reinterpret_cast<const f4 *>(b_src[p] + k0 + 4);
+        }
+    };
+    auto stage_store = [&](int buf) {
+        unsigned *base = lds + buf * BUF;
+#pragma unroll
+        for (int p = 0; p < A_LD; p++) {
+            u4 H, M, L;
+            split8(a_reg[p][0], a_reg[p][1], H, M, L);
+            *reinterpret_cast<u4 *>(base + st_off[p]) = H;
+            if (NPL > 1) *reinterpret_cast<u4 *>(base + PLANE_A + st_off[p]) = M;
+            if (NPL > 2) *reinterpret_cast<u4 *>(base + 2 * PLANE_A + st_off[p]) = L;
+        }
+#pragma unroll
+        for (int p = 0; p < B_LD; p++) {
+            u4 H, M, L;
+            split8(b_reg[p][0], b_reg[p][1], H, M, L);
+            *reinterpret_cast<u4 *>(base + 3 * PLANE_A + st_off[p]) = H;
+            if (NPL > 1) *reinterpret_cast<u4 *>(base + 3 * PLANE_A + PLANE_B + st_off[p]) = M;
+            if (NPL > 2) *reinterpret_cast<u4 *>(base + 3 * PLANE_A + 2 * PLANE_B + st_off[p]) = L;
+        }
+    };
+
+    // fragment offsets: k16-step s of a k-tile reads chunk 2s + lh of rows wm + 32 mi + li (the swizzle depends on the row
+    // only through (row >> 2) & 3 and 32 mi does not change it: one offset per step)
+    int fr_a[2], fr_b[2];
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        fr_a[s] = pswz(wm + li, 2 * s + lh);
+        fr_b[s] = pswz(wn + li, 2 * s + lh);
+    }
+
+    long m0;
+    int n0;
+    int vb = blockIdx.x, tpar = 0;
+    if (vb >= nwg) return;
+    set_tile(vb, m0, n0);
+    stage_load(0);
+
+    for (;;) {
+        f16v acc[MI][NI];
+#pragma unroll
+        for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+            for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[mi][ni][r] = 0.f;
+
+        float *const sc_s = ss_s + (tpar ? 2 * BN : 0), *const sh_s = sc_s + BN;
+        if (ss_lds && tid < BN) {
+            const int col = n0 + tid < a.n ? n0 + tid : a.n - 1;
+            sc_s[tid] = a.scale[col];
+            sh_s[tid] = a.shift[col];
+        }
+        tpar ^= 1;
+        stage_store(0);
+        __syncthreads();
+        for (int kt = 0; kt < nk; kt++) {
+            const int cur = NBUF == 2 ? (kt & 1) : 0;
+            if (kt + 1 < nk) stage_load((kt + 1) * KT);
+            const unsigned *As = lds + cur * BUF, *Bs = As + 3 * PLANE_A;
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                u4 fa[NPL][MI], fb[NPL][NI];
+#pragma unroll
+                for (int pl = 0; pl < NPL; pl++) {
+#pragma unroll
+                    for (int mi = 0; mi < MI; mi++) fa[pl][mi] = *reinterpret_cast<const u4 *>(As + pl * PLANE_A + fr_a[s] + mi * 32 * PW);
+#pragma unroll
+                    for (int ni = 0; ni < NI; ni++) fb[pl][ni] = *reinterpret_cast<const u4 *>(Bs + pl * PLANE_B + fr_b[s] + ni * 32 * PW);
+                }
+#pragma unroll
+                for (int q = 0; q < NP; q++)
+#pragma unroll
+                    for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ni++)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, fa[Prod<NP>::pa[q]][mi]),
+                                                                                  __builtin_bit_cast(bf8, fb[Prod<NP>::pb[q]][ni]), acc[mi][ni], 0, 0, 0);
+            }
+            if (NBUF == 1) __syncthreads();                   // single buffer: everyone has read tile kt before it is overwritten
+            if (kt + 1 < nk) stage_store(NBUF == 2 ? cur ^ 1 : 0);
+            __syncthreads();
+        }
+
+        // next tile: first global loads before this tile's epilogue stores
+        const long cm0 = m0;
+        const int cn0 = n0;
+        const int nvb = vb + gridDim.x;
+        const bool more = nvb < nwg;
+        if (more) {
+            set_tile(nvb, m0, n0);
+            stage_load(0);
+        }
+
+        if (a.act == MBN_ACT_RELU6 && ss_lds && cm0 + BM <= a.m && cn0 + BN <= a.n && a.fast_epi) {
+            // the staged constants are indexed by column inside the tile: pass pointers shifted by the tile's first column
+            mbn_store_relu6_f32<MI, NI, 0, float>(orsrc, (unsigned)a.n, (unsigned)cm0 + wm_u, cn0 + wn_u, lane, acc, sc_s - cn0, sh_s - cn0, (unsigned)a.m, a.n);
+        } else {
+#pragma unroll
+            for (int ni = 0; ni < NI; ni++) {
+                const int col = cn0 + wn + ni * 32 + li;
+                const bool cok = col < a.n;
+                const int cc = cok ? col : a.n - 1;
+                const float sc = a.scale ? a.scale[cc] : 1.f;
+                const float sh = a.shift ? a.shift[cc] : 0.f;
+#pragma unroll
+                for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const long row = cm0 + wm + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        float v = fmaf(acc[mi][ni][r], sc, sh);
+                        if (a.act == MBN_ACT_RELU6) v = fminf(fmaxf(v, 0.f), 6.f);
+                        else if (a.act == MBN_ACT_RELU) v = fmaxf(v, 0.f);
+                        if (cok && row < a.m) a.out[row * a.n + col] = v;
+                    }
+            }
+        }
+        if (!more) break;
+        vb = nvb;
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int NP, int NBUF, int OCC>
+void launch_x(XArgs &a, hipStream_t s, int num_cus)
+{
+    constexpr int NT = 64 * (BM / WM) * (BN / WN);
+    a.mt = (int)((a.m + BM - 1) / BM);
+    a.nt = (a.n + BN - 1) / BN;
+    const int lds_bytes = NBUF * 3 * (BM + BN) * PW * 4 + 16 * BN;
+    int per_cu = 160 * 1024 / lds_bytes;
+    if (per_cu > OCC * 4 / (NT / 64)) per_cu = OCC * 4 / (NT / 64);
+    if (per_cu > 4) per_cu = 4;
+    if (g_mbn_tune.misc > 0) per_cu = g_mbn_tune.misc;
+    const long nwg = (long)a.mt * a.nt;
+    long grid = (long)num_cus * per_cu;
+    if (grid > nwg) grid = nwg;
+    hipLaunchKernelGGL((pw_gemm_x<BM, BN, WM, WN, NP, NBUF, OCC>), dim3((unsigned)grid), dim3(NT), 0, s, a);
+}
+
+template <int NP>
+int launch_np(XArgs &a, hipStream_t s, int num_cus, int tile)
+{
+    switch (tile) {
+    case 1: launch_x<128, 128, 64, 64, NP, 2, 1>(a, s, num_cus); break;     // 4 waves of 64x64, 98 KB
+    case 2: launch_x<128, 64, 64, 32, NP, 2, 2>(a, s, num_cus); break;      // 4 waves of 64x32, 73 KB: 2 workgroups per CU
+    case 3: launch_x<64, 64, 32, 32, NP, 2, 3>(a, s, num_cus); break;       // 4 waves of 32x32, 49 KB: 3 workgroups per CU
+    case 4: launch_x<256, 128, 64, 64, NP, 2, 2>(a, s, num_cus); break;     // 8 waves of 64x64, 146 KB
+    case 5: launch_x<128, 128, 32, 64, NP, 2, 2>(a, s, num_cus); break;     // 8 waves of 32x64, 98 KB
+    case 6: launch_x<128, 128, 64, 64, NP, 1, 2>(a, s, num_cus); break;     // single buffer, 50 KB: 3 workgroups per CU
+    case 7: launch_x<128, 64, 64, 32, NP, 1, 3>(a, s, num_cus); break;      // single buffer, 37 KB: 4 workgroups per CU
+    case 8: launch_x<256, 128, 64, 64, NP, 1, 2>(a, s, num_cus); break;     // 8 waves, single buffer, 74 KB
+    case 9: launch_x<128, 128, 64, 64, NP, 1, 3>(a, s, num_cus); break;     // single buffer, 3 workgroups per CU (168 VGPRs)
+    default: return MBN_EINVAL;
+    }
+    return MBN_OK;
+}
+
+}   // namespace
+
+// MBN_OK if launched; MBN_EUNSUPPORTED if the mode is off or the shape is outside this kernel's envelope.
+int mbn_launch_f32_pw_emul(const mbn_call &c, float *out, const float *in, const float *filt, long m, int cin, int op_size)
+{
+    const int np = g_mbn_tune.pw_emul;
+    if (np == 0 || c.dtype != MBN_DT_F32) return MBN_EUNSUPPORTED;
+    if (np != 1 && np != 3 && np != 6 && np != 9) return MBN_EUNSUPPORTED;
+    if (cin < KT || (cin % KT) != 0 || m <= 0) return MBN_EUNSUPPORTED;
+    if (((uintptr_t)in % 16) || ((uintptr_t)filt % 16)) return MBN_EUNSUPPORTED;
+    if ((long)((m + 63) / 64) * ((op_size + 63) / 64) > 0x7fffffffL) return MBN_EUNSUPPORTED;
+    XArgs a;
+    a.out = out; a.in = in; a.filt = filt; a.scale = c.scale; a.shift = c.shift;
+    a.m = m; a.k = cin; a.n = op_size; a.act = c.act; a.mt = a.nt = 0;
+    a.fast_epi = (double)m * op_size * 4.0 < 4294967296.0 ? 1 : 0;
+    const int cus = c.ctx->num_cus;
+    int tile = g_mbn_tune.pw_tile;
+    if (tile == 0) {
+        // fewer 128x128 tiles than CUs (the FC layer, small batches): pw_gemm's 64x64 tiles fill the chip better
+        if (((m + 127) / 128) * ((op_size + 127) / 128) < cus) return MBN_EUNSUPPORTED;
+        tile = op_size >= 128 ? 6 : 7;
+    }
+    switch (np) {
+    case 9: return launch_np<9>(a, c.stream, cus, tile);
+    case 6: return launch_np<6>(a, c.stream, cus, tile);
+    case 3: return launch_np<3>(a, c.stream, cus, tile);
+    default: return launch_np<1>(a, c.stream, cus, tile);
+    }
+}

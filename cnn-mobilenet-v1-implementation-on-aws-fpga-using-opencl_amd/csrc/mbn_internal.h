@@ -62,6 +62,7 @@ struct mbn_tunables {
     std::atomic<int> lit_dot{0};      // LITERAL pointwise: 0 = v_dot4 path where eligible, 1 = always the scalar kernel
     std::atomic<int> pw_ring{0};      // bf16 pointwise: 0 = ring kernel for K = 64, 1 = always pw_gemm, 2 = ring wherever eligible
     std::atomic<int> pw_splitk{0};    // fp32 pointwise in the few-tile regime: 0 = split-K kernel (mbn_f32_pw_splitk.hip), 1 = always pw_gemm, 2 = split-K wherever eligible
+    std::atomic<int> pw_emul{0};      // fp32 pointwise on the bf16 matrix cores from exact three-way operand splits (mbn_f32_pw_x6.hip): 0 = off, 6 or 9 products
     std::atomic<int> pw_xn{0};        // pointwise GEMM: XCD groups along n (0 = by filter size, 1 = off, 2, 4)
     std::atomic<int> dwpw_variant{0}; // fused block kernel: 0 = shipped choice per shape, 1 = round-1 producer/consumer kernel, 2 = unified-wave kernel,
                                       // 3 = unified with the taps read inside the step, 100 + bits = unified with parts switched off (ablation)
@@ -103,6 +104,7 @@ int mbn_launch_f32_depthwise(const mbn_call &c, void *out, const void *in, const
 int mbn_launch_f32_pointwise(const mbn_call &c, void *out, const void *in, const void *filt, long m, int cin,
                              int op_size);
 int mbn_launch_f32_pw_splitk(const mbn_call &c, float *out, const float *in, const float *filt, long m, int cin, int op_size);
+int mbn_launch_f32_pw_emul(const mbn_call &c, float *out, const float *in, const float *filt, long m, int cin, int op_size);
 int mbn_launch_bf16_pw_ring(const mbn_call &c, void *out, const void *in, const void *filt, long m, int cin, int op_size);
 int mbn_launch_f32_pool(const mbn_call &c, void *out, const void *in, int rows, int cols, int fs, int channels);
 // floor(v / d) == umulhi(v, *m) >> *s for every v < 2^31 (d >= 2); d == 1 gives *m = 0 (callers skip the multiply)

@@ -497,6 +497,13 @@ const char *mbn_version(void);
  *   pw_ring      bf16 pointwise: 0 = streaming ring kernel for K = 64 (shipped), 1 = always the tiled GEMM, 2 = ring wherever eligible
  *   pw_splitk    fp32 pointwise of 1..4 images in the few-tile regime: 0 = split-K kernel (mbn_f32_pw_splitk.hip), 1 = always the
  *                tiled GEMM, 2 = split-K wherever the shape allows (K >= 128, K % 64 == 0), whatever the batch
+ *   pw_emul      fp32 pointwise, OPT-IN arithmetic form (mbn_f32_pw_x6.hip): 0 = v_mfma_f32_32x32x2_f32 (default); 6 or 9 = every fp32
+ *                operand split EXACTLY into three bf16 values (x = h + m + l, 24 bits kept) and the product formed from 6 (or all 9)
+ *                bf16 x bf16 partial products on v_mfma_f32_32x32x16_bf16 with the fp32 accumulator; fp32 in, fp32 out. The 3 dropped
+ *                partial products of 6 are below 2^-24 of the product. Measured error against a float64 product on the network's
+ *                layer shapes: equal to or smaller than the fp32 MFMA kernel's (profiles/r02/m_pw_emul.txt); layers 13-27 at
+ *                batch 256: 1.49 -> 1.24 ms, whole step +12 %. Applies to pointwise calls with K % 32 == 0 and at least as many
+ *                128x128 tiles as CUs; everything else takes the default kernels.
  *   pw_xn        pointwise GEMM tile order: XCD groups along n (0 = by filter size, 1 = single ordering, 2, 4)
  *   dwpw_variant fused block kernel: 0 = shipped choice, 1 = round-1 producer/consumer kernels, 2 = unified-wave kernels,
  *                3 = unified fp32 with the taps read inside the step, 100 + bits = unified with parts switched off */

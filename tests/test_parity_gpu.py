@@ -1095,6 +1095,144 @@ def _headline_images(n, res, seed):
     return out
 
 
+def _emul_modes(ctx, form, tile):
+    assert ctx.lib.mbn_tune_set(b"pw_splitk", 1) == 0
+    assert ctx.lib.mbn_tune_set(b"pw_emul", form) == 0
+    assert ctx.lib.mbn_tune_set(b"pw_tile", tile) == 0
+
+
+def _emul_reset(ctx):
+    for k in (b"pw_splitk", b"pw_emul", b"pw_tile"):
+        assert ctx.lib.mbn_tune_set(k, 0) == 0
+
+
+@pytest.mark.parametrize("form", [6, 9])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_f32_pointwise_emul_split_is_exact(pkg, ctx, form, tile):
+    """mbn_f32_pw_x6.hip (opt-in, tune pw_emul = 6 | 9): every fp32 operand is split into three bf16 values that carry all 24
+    bits. Proof on the device, for every tile instantiation: with one operand a (signed) power of two per row, the output is a
+    single product x * 2^e, which the kernel must return BIT FOR BIT for x with random full 24-bit significands — once with the
+    activations random (A split: h, m and l all needed) and once with the filter random (B split). Replaces the arithmetic of
+    kernel.cl:94-114 for the pointwise call sites MobileNet.c:1218-2576."""
+    m, k, n = 517, 96, 200                      # ragged in m and n for every tile shape
+    rng = np.random.default_rng(form * 100 + tile)
+
+    def full24(shape):
+        bits = rng.integers(0, 1 << 23, shape, dtype=np.uint32) | (rng.integers(120, 134, shape, dtype=np.uint32) << 23)
+        bits |= rng.integers(0, 2, shape, dtype=np.uint32) << 31
+        return bits.view(np.float32)
+
+    ext = pkg.make_ext(batch=1, act=0)
+    d_o = ctx.alloc(m * n * 4)
+    try:
+        _emul_modes(ctx, form, tile)
+        # activations random, filter one-hot powers of two
+        x = full24((m, k))
+        f = np.zeros((n, k), np.float32)
+        kk = (np.arange(n) * 7) % k
+        f[np.arange(n), kk] = (2.0 ** ((np.arange(n) % 5) - 2)) * np.where(np.arange(n) % 3 == 0, -1.0, 1.0)
+        d_x, d_f = ctx.to_device(x), ctx.to_device(f)
+        ctx.pointwise(d_o.ptr, d_x.ptr, d_f.ptr, m, 1, k, n, ext)
+        ctx.sync()
+        want = x[:, kk] * f[np.arange(n), kk][None, :]
+        assert np.array_equal(d_o.download((m, n), np.float32).view(np.uint32), want.view(np.uint32)), "A split loses bits"
+        # filter random, activations one-hot powers of two
+        x = np.zeros((m, k), np.float32)
+        km = (np.arange(m) * 5) % k
+        x[np.arange(m), km] = 2.0 ** (np.arange(m) % 3)
+        f = full24((n, k))
+        d_x.upload(x); d_f.upload(f)
+        ctx.pointwise(d_o.ptr, d_x.ptr, d_f.ptr, m, 1, k, n, ext)
+        ctx.sync()
+        want = f[:, km].T * x[np.arange(m), km][:, None]
+        assert np.array_equal(d_o.download((m, n), np.float32).view(np.uint32), want.view(np.uint32)), "B split loses bits"
+    finally:
+        _emul_reset(ctx)
+
+
+@pytest.mark.parametrize("shape", [(4099, 512, 512), (1000, 96, 200), (777, 32, 64), (1500, 1024, 1000), (6272, 256, 256)])
+def test_f32_pointwise_emul_accuracy(pkg, orc, ctx, shape):
+    """pw_emul = 6 and 9 against (a) the oracle's pointwise + BN + ReLU6 at the fp32 pointwise tolerance, (b) a float64
+    product of the same fp32 operands, in units of sum_k |a_k b_k| * 2^-24: the bound is the one the fp32 MFMA kernel itself
+    is held to here (16 units; it measures 4-8) and the split forms may not be worse than 1.5x the fp32 kernel's own maximum
+    on the same data (measured: equal or smaller, profiles/r02/m_pw_emul.txt). No stores past a ragged last tile; repeatable;
+    a K outside the envelope (K % 32 != 0) falls through to the default kernel, bit for bit."""
+    m, cin, cout = shape
+    rng = np.random.default_rng(m + cin + cout)
+    x = np.clip(rng.normal(1.0, 1.5, (m, cin)), 0, 6).astype(np.float32)
+    f = rng.normal(0, (2.0 / cin) ** 0.5, (cout, cin)).astype(np.float32)
+    sc, sh = rng.uniform(0.5, 1.5, cout).astype(np.float32), rng.normal(0, 0.1, cout).astype(np.float32)
+    want = orc.f32_pointwise(x, f, sc, sh, 2)
+    ref = x.astype(np.float64) @ f.astype(np.float64).T
+    unit = (np.abs(x).astype(np.float64) @ np.abs(f).astype(np.float64).T) * 2.0 ** -24
+    d_x, d_f, d_sc, d_sh = (ctx.to_device(a) for a in (x, f, sc, sh))
+    d_o = ctx.alloc(want.nbytes + 64)
+    ext_bn = pkg.make_ext(batch=1, act=2, scale=d_sc.ptr, shift=d_sh.ptr)
+    ext_raw = pkg.make_ext(batch=1, act=0)
+    worst = {}
+    try:
+        for form in (0, 6, 9):
+            _emul_modes(ctx, form, 0 if form == 0 else (6 if cout >= 128 else 7))
+            ctx.lib.mbn_memset(ctx.h, d_o.ptr, 0xFF, want.nbytes + 64)
+            ctx.pointwise(d_o.ptr, d_x.ptr, d_f.ptr, m, 1, cin, cout, ext_bn)
+            ctx.sync()
+            raw = d_o.download((want.size + 16,), np.float32)
+            assert np.all(raw[want.size:].view(np.uint32) == 0xFFFFFFFF), "stores past the ragged last tile (form %d)" % form
+            got = raw[:want.size].reshape(want.shape)
+            assert_close(got, want, TOL_PW, "pw_emul %d %s vs oracle" % (form, shape))
+            ctx.pointwise(d_o.ptr, d_x.ptr, d_f.ptr, m, 1, cin, cout, ext_bn)
+            ctx.sync()
+            assert np.array_equal(got, d_o.download(want.shape, np.float32)), "not repeatable"
+            ctx.pointwise(d_o.ptr, d_x.ptr, d_f.ptr, m, 1, cin, cout, ext_raw)
+            ctx.sync()
+            e = np.abs(d_o.download(want.shape, np.float32).astype(np.float64) - ref) / unit
+            worst[form] = float(e.max())
+            assert worst[form] <= 16.0, "form %d: %.2f units of the magnitude sum's fp32 rounding" % (form, worst[form])
+        assert worst[6] <= 1.5 * worst[0] + 1.0 and worst[9] <= 1.5 * worst[0] + 1.0, worst
+        # outside the envelope: K = 40 -> the default kernel answers, whatever pw_emul says
+        xs = rng.uniform(0, 6, (m, 40)).astype(np.float32)
+        fs = rng.normal(0, 0.2, (cout, 40)).astype(np.float32)
+        d_xs, d_fs = ctx.to_device(xs), ctx.to_device(fs)
+        outs = []
+        for form in (0, 6):
+            _emul_modes(ctx, form, 0)
+            ctx.pointwise(d_o.ptr, d_xs.ptr, d_fs.ptr, m, 1, 40, cout, ext_bn)
+            ctx.sync()
+            outs.append(d_o.download(want.shape, np.float32))
+        assert np.array_equal(outs[0], outs[1])
+    finally:
+        _emul_reset(ctx)
+
+
+def test_headline_fp32_batch256_pw_emul(pkg, orc, ctx, tmp_path):
+    """The opt-in split form on the headline configuration (1.0x224 fp32, batch 256, default runner): with pw_emul = 6 the
+    stand-alone pointwise layers 13-27 run on mbn_f32_pw_x6.hip; logits of four images against the oracle at the SAME bound
+    as the default path (TOL_NET), and against the default path's own logits."""
+    n = 256
+    hw, net = _make_net(pkg, ctx, tmp_path, 1.0, 224, 1000, n)
+    imgs = _headline_images(n, 224, 20261005)
+    d_in, d_out = ctx.to_device(imgs), ctx.alloc(n * 1000 * 4)
+    net.forward(d_in.ptr, d_out.ptr, n)
+    ctx.sync()
+    base = d_out.download((n, 1000), np.float32)
+    try:
+        assert ctx.lib.mbn_tune_set(b"pw_emul", 6) == 0
+        net.forward(d_in.ptr, d_out.ptr, n)
+        ctx.sync()
+        got = d_out.download((n, 1000), np.float32)
+    finally:
+        assert ctx.lib.mbn_tune_set(b"pw_emul", 0) == 0
+    assert np.isfinite(got).all() and not np.array_equal(got, base), "the split kernel was not on the path"
+    pick = [0, 85, 170, 255]
+    oplan = orc.plan_build(1.0, 224, 1000)
+    want, _ = orc.net_forward(oplan, hw.blob, imgs[pick], threads=orc.num_threads())
+    want = np.asarray(want).reshape(len(pick), 1000)
+    assert_close(got[pick], want, TOL_NET, "pw_emul 6, batch-256 logits of images %s" % pick)
+    assert_close(got, base, 1e-4, "pw_emul 6 vs the fp32 MFMA path, all 256 images")
+    assert (got.argmax(1) == base.argmax(1)).all()
+    net.destroy()
+
+
 def test_headline_fp32_batch256_vs_oracle(pkg, orc, ctx, tmp_path):
     """BASELINE.json configs[2] itself — MobileNet-V1 1.0x224 fp32, batch 256, the runner's DEFAULT configuration (fused
     stem, fused blocks, persistent GEMM tiles walking many tiles per workgroup) — checked for correctness, not just
