@@ -134,6 +134,7 @@ int mbn_shutdown(mbn_context *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     for (auto &kv : ctx->allocs) (void)hipFree((void *)kv.first);
     if (ctx->lit_ws) (void)hipFree(ctx->lit_ws);
+    for (auto &kv : ctx->emul_ws) (void)hipFree(kv.second.first);
     ctx->allocs.clear();
     for (hipEvent_t e : ctx->pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->marks) (void)hipEventDestroy(e);

@@ -16,11 +16,22 @@
 // (DESIGN §3.6), so it is done ONCE per workgroup tile on the way into LDS — global -> registers -> three bf16 planes in LDS —
 // not per wave in the fragment path; a 128x128 tile splits (128 + 128) x 32 values per 32 k for 4 x 48 MFMAs.
 //
-// LDS: per buffer three planes [rows][64 B] for A and three for B (32 k of bf16 per row); the 16-byte chunk index is XORed
-// with (row >> 2) & 3, which makes both the staging ds_write_b128 (4 lanes per row) and the fragment ds_read_b128 (16
-// consecutive rows, one chunk) hit 16 distinct 16-byte slots of the 256-byte bank row. Double-buffered over K, one barrier
-// per k-tile; persistent workgroups with the XCD-contiguous tile order of pw_gemm; scale/shift staged in LDS; the same
+// LDS: three planes [rows][64 B] for A and three for B (32 k of bf16 per row); the 16-byte chunk index is XORed with
+// (row >> 2) & 3, which makes both the staging ds_write_b128 (4 lanes per row) and the fragment ds_read_b128 (16 consecutive
+// rows, one chunk) hit 16 distinct 16-byte slots of the 256-byte bank row (SQ_LDS_BANK_CONFLICT = 0 measured). Persistent
+// workgroups with the XCD-contiguous tile order of pw_gemm; scale/shift of the tile's columns staged in LDS; the same
 // buffer-store epilogue (mbn_epilogue.h).
+//
+// Two kernels. pw_gemm_xb (shipped for outputs of 128 columns and wider): the FILTER is split once per launch by a small
+// pre-kernel (split_filter, ~4 us) into a per-filter workspace laid out as the LDS tile images, and streamed from there by
+// LDS-DMA one k-tile ahead (double-buffered); only the activations are split in the GEMM (single-buffered planes, loads
+// issued two k-tiles ahead, explicit s_waitcnt counters at the barriers). pw_gemm_x: both operands split on the way in,
+// no workspace (narrow outputs; first use inside a hipGraph capture, where nothing may be allocated).
+//
+// Measured (profiles/r02/m_pw_emul.txt, batch 256): 512 -> 512 at 14x14 0.195 ms (pw_gemm<float>) -> 0.151-0.160; the step
+// 85-88 k -> 95-102 k images/s. The matrix pipe is busy 47 % of the kernel (SQ_VALU_MFMA_BUSY_CYCLES), the clock holds
+// 2.05 GHz (GRBM_GUI_ACTIVE; 2.09 under pw_gemm<float>): the rest is the two barriers per k-tile at two waves per SIMD —
+// three 2-byte planes per operand make the 128x128 tile 74 KB of LDS, so only two workgroups fit a CU.
 #include "mbn_internal.h"
 #include "mbn_epilogue.h"
 
@@ -40,6 +51,9 @@ struct XArgs {
     int k, n, act;
     int mt, nt;
     int fast_epi;
+    const unsigned *bws;          // pw_gemm_xb: the filter's three bf16 planes, pre-split, in LDS tile-image order (split_filter)
+    unsigned bws_bytes;
+    int prio;
 };
 
 constexpr int KT = 32;            // k per k-tile
@@ -257,6 +271,294 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) __attribute__((amdgpu_w
     }
 }
 
+// ---- filter pre-split: [N][K] fp32 -> per (n-tile, k-tile) the three planes of BN rows x 64 B in the LDS image order of
+// pw_gemm_xb (rows past N repeat row N-1). One thread per (row, 16-byte chunk): 4 * BN threads per block.
+template <int BN>
+__global__ __launch_bounds__(4 * BN) void split_filter(unsigned *ws, const float *filt, int n, int k)
+{
+    const int ntile = blockIdx.x, kt = blockIdx.y, nk = gridDim.y;
+    const int row = threadIdx.x >> 2, c = threadIdx.x & 3;
+    const int gn = min(ntile * BN + row, n - 1);
+    const float *src = filt + (long)gn * k + kt * KT + c * 8;
+    u4 H, M, L;
+    split8(*reinterpret_cast<const f4 *>(src), *reinterpret_cast<const f4 *>(src + 4), H, M, L);
+    unsigned *dst = ws + (size_t)(ntile * nk + kt) * 3 * BN * PW + pswz(row, c);
+    *reinterpret_cast<u4 *>(dst) = H;
+    *reinterpret_cast<u4 *>(dst + BN * PW) = M;
+    *reinterpret_cast<u4 *>(dst + 2 * BN * PW) = L;
+}
+
+// s_barrier with explicit counters (as in mbn_bf16_pw_ring.hip): __syncthreads would drain vmcnt(0) — the A loads issued two
+// k-tiles ahead included — at every barrier while an LDS-DMA is outstanding. VM_LEFT < 0: vector memory is not waited for.
+template <int VM_LEFT>
+__device__ __forceinline__ void xb_barrier()
+{
+    if constexpr (VM_LEFT < 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(VM_LEFT) : "memory");
+}
+
+__device__ __forceinline__ void dma_pieces(const __amdgpu_buffer_rsrc_t rsrc, unsigned *lds_dst, const unsigned *voff, unsigned soff, int wave_u,
+                                           const int NPC, const int NW)
+{
+#pragma unroll
+    for (int p = 0; p < NPC; p++)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(lds_dst + (p * NW + wave_u) * 256), 16, voff[p], soff, 0, 0);
+}
+
+// ---- the GEMM with the filter planes streamed by LDS-DMA from the pre-split image (double-buffered: a k-tile ahead) and only
+// the activations split on the way in (single-buffered planes, two barriers per k-tile): half the VALU work and LDS writes of
+// pw_gemm_x, 16 staging VGPRs less.
+template <int BM, int BN, int WM, int WN, int NP, int OCC>
+__global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void pw_gemm_xb(XArgs a)
+{
+    constexpr int WAVES_N = BN / WN, NW = (BM / WM) * WAVES_N, NT = 64 * NW;
+    constexpr int MI = WM / 32, NI = WN / 32;
+    constexpr int RP = NT / 4;
+    constexpr int A_LD = BM / RP;
+    static_assert(A_LD >= 1 && A_LD * RP == BM, "tile/threads mismatch");
+    constexpr int PLANE_A = BM * PW, PLANE_B = BN * PW, IMG_B = 3 * PLANE_B;        // words
+    constexpr int NPC = IMG_B / 256 / NW;                                          // 1-KB DMA pieces per wave per k-tile
+    static_assert(NPC * NW * 256 == IMG_B, "filter image / waves mismatch");
+    __shared__ __attribute__((aligned(16))) unsigned lds[3 * PLANE_A + 2 * IMG_B + 4 * BN];
+    unsigned *const Bbuf = lds + 3 * PLANE_A;
+    float *const ss_s = reinterpret_cast<float *>(lds + 3 * PLANE_A + 2 * IMG_B);
+    const bool ss_lds = a.scale && a.shift;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nwg = a.mt * a.nt;
+    const int wm = (wave / WAVES_N) * WM, wn = (wave % WAVES_N) * WN;
+    const int li = lane & 31, lh = lane >> 5;
+    const int nk = a.k / KT;
+    const int st_c = tid & 3, st_r = tid >> 2;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int wm_u = (wave_u / WAVES_N) * WM, wn_u = (wave_u % WAVES_N) * WN;
+    const __amdgpu_buffer_rsrc_t orsrc = mbn_make_rsrc(a.out, a.fast_epi ? (unsigned)(a.m * a.n * 4L) : 0u);
+    const __amdgpu_buffer_rsrc_t brsrc = mbn_make_rsrc(a.bws, a.bws_bytes);
+
+    const float *a_src[A_LD];
+    f4 a_r0[A_LD][2], a_r1[A_LD][2];          // two register sets: the loads of a k-tile are issued TWO k-tiles before their split
+    int st_off[A_LD];
+    unsigned b_vo[NPC];
+#pragma unroll
+    for (int p = 0; p < A_LD; p++) st_off[p] = pswz(p * RP + st_r, st_c);
+#pragma unroll
+    for (int p = 0; p < NPC; p++) b_vo[p] = (unsigned)((p * NW + wave) * 1024 + lane * 16);
+
+    int ntile_cur = 0;
+    auto set_tile = [&](int vb, long &m0, int &n0) {
+        const int lid = x_remap(vb, nwg);
+        m0 = (long)(lid / a.nt) * BM;
+        ntile_cur = lid % a.nt;
+        n0 = ntile_cur * BN;
+#pragma unroll
+        for (int p = 0; p < A_LD; p++) {
+            long gm = m0 + p * RP + st_r;
+            if (gm >= a.m) gm = a.m - 1;
+            a_src[p] = a.in + gm * a.k + st_c * 8;
+        }
+    };
+    auto stage_load = [&](f4 (&r)[A_LD][2], int k0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < A_LD; p++) {
+            r[p][0] = *reinterpret_cast<const f4 *>(a_src[p] + k0);
+            r[p][1] = *reinterpret_cast<const f4 *>(a_src[p] + k0 + 4);
+        }
+    };
+    auto stage_store = [&](const f4 (&r)[A_LD][2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < A_LD; p++) {
+            u4 H, M, L;
+            split8(r[p][0], r[p][1], H, M, L);
+            *reinterpret_cast<u4 *>(lds + st_off[p]) = H;
+            *reinterpret_cast<u4 *>(lds + PLANE_A + st_off[p]) = M;
+            *reinterpret_cast<u4 *>(lds + 2 * PLANE_A + st_off[p]) = L;
+        }
+    };
+    auto dma_b = [&](int kt, int buf) __attribute__((always_inline)) {
+        dma_pieces(brsrc, Bbuf + buf * IMG_B, b_vo, (unsigned)(ntile_cur * nk + kt) * (unsigned)(IMG_B * 4), wave_u, NPC, NW);
+    };
+
+    int fr_a[2], fr_b[2];
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        fr_a[s] = pswz(wm + li, 2 * s + lh);
+        fr_b[s] = pswz(wn + li, 2 * s + lh);
+    }
+
+    long m0;
+    int n0;
+    int vb = blockIdx.x, tpar = 0;
+    if (vb >= nwg) return;
+    set_tile(vb, m0, n0);
+    stage_load(a_r0, 0);
+    if (nk > 1) stage_load(a_r1, KT);
+    dma_b(0, 0);
+
+    for (;;) {
+        f16v acc[MI][NI];
+#pragma unroll
+        for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+            for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[mi][ni][r] = 0.f;
+
+        auto compute = [&](const unsigned *Bs) __attribute__((always_inline)) {
+            const unsigned *As = lds;
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                u4 fa[3][MI], fb[3][NI];
+#pragma unroll
+                for (int pl = 0; pl < 3; pl++) {
+#pragma unroll
+                    for (int mi = 0; mi < MI; mi++) fa[pl][mi] = *reinterpret_cast<const u4 *>(As + pl * PLANE_A + fr_a[s] + mi * 32 * PW);
+#pragma unroll
+                    for (int ni = 0; ni < NI; ni++) fb[pl][ni] = *reinterpret_cast<const u4 *>(Bs + pl * PLANE_B + fr_b[s] + ni * 32 * PW);
+                }
+#pragma unroll
+                for (int q = 0; q < NP; q++)
+#pragma unroll
+                    for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ni++)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, fa[Prod<NP>::pa[q]][mi]),
+                                                                                  __builtin_bit_cast(bf8, fb[Prod<NP>::pb[q]][ni]), acc[mi][ni], 0, 0, 0);
+            }
+        };
+        float *const sc_s = ss_s + (tpar ? 2 * BN : 0), *const sh_s = sc_s + BN;
+        if (ss_lds && tid < BN) {
+            const int col = n0 + tid < a.n ? n0 + tid : a.n - 1;
+            sc_s[tid] = a.scale[col];
+            sh_s[tid] = a.shift[col];
+        }
+        tpar ^= 1;
+        stage_store(a_r0);
+        __syncthreads();                                      // A planes of k-tile 0 written, filter image 0 landed (vmcnt(0) ahead of the barrier)
+        // one k-tile: PEND holds the loads of k-tile kt + 1 (issued a k-tile ago), FRESH receives those of kt + 2. HAS1 / HAS2 =
+        // "k-tile kt + 1 / kt + 2 exists": literal constants in the steady state and in the even tail, so that the loop body is
+        // straight-line code (with branches in it the compiler's counter model turns conservative and drains vmcnt(0) right
+        // behind the DMA issue)
+#define XB_KTILE(KTV, PEND, FRESH, HAS1, HAS2)                                                                              \
+        {                                                                                                                  \
+            const int kt_ = (KTV);                                                                                         \
+            if (HAS1) dma_b(kt_ + 1, (kt_ + 1) & 1);                  /* older than the A loads below: vmcnt(their count) covers it */ \
+            if (HAS2) stage_load(FRESH, (kt_ + 2) * KT);                                                                   \
+            __builtin_amdgcn_sched_barrier(0);                /* loads in flight before the first MFMA */                  \
+            compute(Bbuf + (kt_ & 1) * IMG_B);                                                                             \
+            xb_barrier<-1>();                                 /* everyone has read the A planes of k-tile kt */            \
+            __builtin_amdgcn_sched_barrier(0);                /* keep the split (and the wait for its loads) behind the MFMAs */ \
+            if (a.prio) __builtin_amdgcn_s_setprio(3);        /* the split is VALU work: not behind the other workgroup's MFMA stream */ \
+            if (HAS1) stage_store(PEND);                                                                                   \
+            if (a.prio) __builtin_amdgcn_s_setprio(0);                                                                     \
+            if (HAS2) xb_barrier<2 * A_LD>();                 /* A planes of kt + 1 written, filter image kt + 1 landed */ \
+            else xb_barrier<0>();                                                                                          \
+        }
+        int kt = 0;
+        for (; kt + 3 < nk; kt += 2) {
+            XB_KTILE(kt, a_r1, a_r0, true, true)
+            XB_KTILE(kt + 1, a_r0, a_r1, true, true)
+        }
+        if (nk - kt == 2) {
+            XB_KTILE(kt, a_r1, a_r0, true, false)
+            XB_KTILE(kt + 1, a_r0, a_r1, false, false)
+        } else {
+            for (; kt < nk; kt += 2) {                        // odd K / 32 (not in the network): at most three k-tiles, run-time conditions
+                XB_KTILE(kt, a_r1, a_r0, kt + 1 < nk, kt + 2 < nk)
+                if (kt + 1 < nk) XB_KTILE(kt + 1, a_r0, a_r1, kt + 2 < nk, kt + 3 < nk)
+            }
+        }
+#undef XB_KTILE
+
+        const long cm0 = m0;
+        const int cn0 = n0;
+        const int nvb = vb + gridDim.x;
+        const bool more = nvb < nwg;
+        if (more) {
+            set_tile(nvb, m0, n0);
+            stage_load(a_r0, 0);
+            if (nk > 1) stage_load(a_r1, KT);
+            dma_b(0, 0);                                      // both filter buffers are free after the loop's last barrier
+        }
+
+        if (a.act == MBN_ACT_RELU6 && ss_lds && cm0 + BM <= a.m && cn0 + BN <= a.n && a.fast_epi) {
+            mbn_store_relu6_f32<MI, NI, 0, float>(orsrc, (unsigned)a.n, (unsigned)cm0 + wm_u, cn0 + wn_u, lane, acc, sc_s - cn0, sh_s - cn0, (unsigned)a.m, a.n);
+        } else {
+#pragma unroll
+            for (int ni = 0; ni < NI; ni++) {
+                const int col = cn0 + wn + ni * 32 + li;
+                const bool cok = col < a.n;
+                const int cc = cok ? col : a.n - 1;
+                const float sc = a.scale ? a.scale[cc] : 1.f;
+                const float sh = a.shift ? a.shift[cc] : 0.f;
+#pragma unroll
+                for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const long row = cm0 + wm + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        float v = fmaf(acc[mi][ni][r], sc, sh);
+                        if (a.act == MBN_ACT_RELU6) v = fminf(fmaxf(v, 0.f), 6.f);
+                        else if (a.act == MBN_ACT_RELU) v = fmaxf(v, 0.f);
+                        if (cok && row < a.m) a.out[row * a.n + col] = v;
+                    }
+            }
+        }
+        if (!more) break;
+        vb = nvb;
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int NP, int OCC>
+int launch_xb(XArgs &a, const mbn_call &c)
+{
+    constexpr int NT = 64 * (BM / WM) * (BN / WN);
+    a.mt = (int)((a.m + BM - 1) / BM);
+    a.nt = (a.n + BN - 1) / BN;
+    const int nk = a.k / KT;
+    const size_t need = (size_t)a.nt * nk * 3 * BN * PW * 4;
+    if (need >= 0xFFFFFFFFull) return MBN_EUNSUPPORTED;
+    // workspace per filter pointer (two sub-batch streams run different layers at the same time; the same layer's image is
+    // rewritten with identical bytes by every launch, so the filter may change between calls like any other argument)
+    void *ws = nullptr;
+    {
+        std::lock_guard<std::mutex> g(c.ctx->mu);
+        auto it = c.ctx->emul_ws.find((uintptr_t)a.filt);
+        if (it != c.ctx->emul_ws.end() && it->second.second >= need) ws = it->second.first;
+        else {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            (void)hipStreamIsCapturing(c.stream, &cs);
+            if (cs != hipStreamCaptureStatusNone) return MBN_EUNSUPPORTED;     // no allocation inside a capture: the default kernels answer
+            if (it != c.ctx->emul_ws.end()) { (void)hipDeviceSynchronize(); (void)hipFree(it->second.first); c.ctx->emul_ws.erase(it); }
+            if (hipMalloc(&ws, need) != hipSuccess) return MBN_EUNSUPPORTED;
+            c.ctx->emul_ws[(uintptr_t)a.filt] = std::make_pair(ws, need);
+        }
+    }
+    a.bws = (const unsigned *)ws;
+    a.bws_bytes = (unsigned)need;
+    hipLaunchKernelGGL((split_filter<BN>), dim3(a.nt, nk), dim3(4 * BN), 0, c.stream, (unsigned *)ws, a.filt, a.n, a.k);
+    const int lds_bytes = (3 * BM * PW + 2 * 3 * BN * PW + 4 * BN) * 4;
+    int per_cu = 160 * 1024 / lds_bytes;
+    if (per_cu > OCC * 4 / (NT / 64)) per_cu = OCC * 4 / (NT / 64);
+    if (per_cu < 1) per_cu = 1;
+    if (g_mbn_tune.misc > 0) per_cu = g_mbn_tune.misc;
+    const long nwg = (long)a.mt * a.nt;
+    long grid = (long)c.ctx->num_cus * per_cu;
+    if (grid > nwg) grid = nwg;
+    hipLaunchKernelGGL((pw_gemm_xb<BM, BN, WM, WN, NP, OCC>), dim3((unsigned)grid), dim3(NT), 0, c.stream, a);
+    return MBN_OK;
+}
+
+template <int NP>
+int launch_np_b(XArgs &a, const mbn_call &c, int tile)
+{
+    switch (tile) {
+    case 11: return launch_xb<128, 128, 64, 64, NP, 2>(a, c);     // 4 waves of 64x64, 74 KB: 2 workgroups per CU
+    case 12: return launch_xb<128, 64, 64, 32, NP, 3>(a, c);      // 4 waves of 64x32, 49 KB: 3 workgroups per CU
+    case 13: return launch_xb<256, 128, 64, 64, NP, 2>(a, c);     // 8 waves of 64x64, 98 KB
+    case 14: return launch_xb<128, 128, 32, 64, NP, 2>(a, c);     // 8 waves of 32x64, 74 KB, 1 workgroup per CU
+    case 15: return launch_xb<128, 128, 32, 64, NP, 4>(a, c);     // 8 waves of 32x64, 2 workgroups per CU (128 VGPRs)
+    default: return MBN_EINVAL;
+    }
+}
+
 template <int BM, int BN, int WM, int WN, int NP, int NBUF, int OCC>
 void launch_x(XArgs &a, hipStream_t s, int num_cus)
 {
@@ -307,12 +609,26 @@ int mbn_launch_f32_pw_emul(const mbn_call &c, float *out, const float *in, const
     a.out = out; a.in = in; a.filt = filt; a.scale = c.scale; a.shift = c.shift;
     a.m = m; a.k = cin; a.n = op_size; a.act = c.act; a.mt = a.nt = 0;
     a.fast_epi = (double)m * op_size * 4.0 < 4294967296.0 ? 1 : 0;
+    a.bws = nullptr; a.bws_bytes = 0;
+    a.prio = (g_mbn_tune.conv_variant & 16) ? 0 : 1;          // A/B hook: conv_variant bit 4 = no raised priority over the split
     const int cus = c.ctx->num_cus;
     int tile = g_mbn_tune.pw_tile;
     if (tile == 0) {
         // fewer 128x128 tiles than CUs (the FC layer, small batches): pw_gemm's 64x64 tiles fill the chip better
         if (((m + 127) / 128) * ((op_size + 127) / 128) < cus) return MBN_EUNSUPPORTED;
+        // 128-column outputs and wider: the filter pre-split once per launch and streamed by LDS-DMA (3-8 % faster than
+        // splitting it per tile, profiles/r02/m_pw_emul.txt); without a workspace (first use inside a graph capture) and for
+        // narrow outputs: both operands split on the way in
+        if (op_size >= 128 && (np == 6 || np == 9)) {
+            const int rc = np == 9 ? launch_np_b<9>(a, c, 11) : launch_np_b<6>(a, c, 11);
+            if (rc == MBN_OK) return rc;
+        }
         tile = op_size >= 128 ? 6 : 7;
+    }
+    if (tile >= 11) {
+        if (np == 9) return launch_np_b<9>(a, c, tile);
+        if (np == 6) return launch_np_b<6>(a, c, tile);
+        return MBN_EUNSUPPORTED;
     }
     switch (np) {
     case 9: return launch_np<9>(a, c.stream, cus, tile);

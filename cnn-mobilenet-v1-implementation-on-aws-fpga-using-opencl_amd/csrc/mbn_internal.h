@@ -32,6 +32,7 @@ struct mbn_context {
     size_t marks_used = 0;
     void *lit_ws = nullptr;                      // LITERAL pointwise on v_dot4: packed int8 filter + per-channel weight sums + flag
     size_t lit_ws_bytes = 0;
+    std::map<uintptr_t, std::pair<void *, size_t>> emul_ws;   // pw_emul: pre-split filter images, by filter pointer (mbn_f32_pw_x6.hip)
     std::mutex mu;
     std::map<uintptr_t, size_t> allocs;          // buffers handed out by mbn_alloc: base address -> bytes (ordered: mbn_span_check
                                                  // finds the allocation that CONTAINS an interior pointer)
