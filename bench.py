@@ -146,7 +146,7 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay each step as one hipGraph (mbn_net_set_graph)")
     ap.add_argument("--tune", action="append", default=[], help="key=value passed to mbn_tune_set (experiments)")
     ap.add_argument("--pw-emul", type=int, default=0, choices=[0, 6, 9],
-                    help="fp32 only, OPT-IN: run the stand-alone pointwise layers on mbn_f32_pw_x6.hip (every fp32 operand split exactly "
+                    help="fp32 only, OPT-IN: run the pointwise layers (stand-alone: mbn_f32_pw_x6.hip; inside fused blocks 4-11: mbn_f32_dwpw2_x6.hip) with every fp32 operand split exactly "
                          "into three bf16 values, 6 or 9 bf16 MFMA partial products per product, fp32 accumulate; include/mbn.h "
                          "tune key pw_emul). The default line measures the fp32-MFMA kernels and reports this form beside it "
                          "as `pw_emul_alt`")
@@ -318,7 +318,8 @@ def main():
         alt = {"pw_emul": 6, "value": args.batch * 10 / (a1 - a0), "unit": "images/sec", "ms_per_step": 100.0 * (a1 - a0),
                "steps": 10, "warmup": 3,
                "max_rel_diff_to_default_logits": float(np.abs(alt_logits.astype(np.float64) - logits).max() / max(float(np.abs(logits).max()), 1e-6)),
-               "what": "mbn_tune_set(\"pw_emul\", 6): the stand-alone pointwise layers on mbn_f32_pw_x6.hip - fp32 in/out, every "
+               "what": "mbn_tune_set(\"pw_emul\", 6): the pointwise layers 13-27 on mbn_f32_pw_x6.hip and the pointwise halves of the "
+                       "fused blocks 4-11 on mbn_f32_dwpw2_x6.hip - fp32 in/out, every "
                        "operand split exactly into three bf16 values, 6 bf16 MFMA partial products per fp32 product (the dropped "
                        "three are < 2^-24 of it), fp32 accumulate; measured error against float64 <= the fp32 MFMA kernel's "
                        "(profiles/r02/m_pw_emul.txt). Opt-in: `value` above is the fp32-MFMA path"}
@@ -416,8 +417,9 @@ def main():
             out["pw_emul_alt"] = alt
         if args.pw_emul and not bf16:
             out["config"]["pw_emul"] = args.pw_emul
-            out["config"]["arithmetic"] = ("stand-alone pointwise layers: fp32 operands split exactly into three bf16 values, %d bf16 "
-                                           "MFMA partial products per product, fp32 accumulate (mbn_f32_pw_x6.hip)" % args.pw_emul)
+            out["config"]["arithmetic"] = ("pointwise layers 13-27 and the pointwise halves of the fused blocks 4-11: fp32 operands split exactly "
+                                           "into three bf16 values, %d bf16 MFMA partial products per product, fp32 accumulate "
+                                           "(mbn_f32_pw_x6.hip, mbn_f32_dwpw2_x6.hip); stem, depthwise, pool, FC unchanged" % args.pw_emul)
             if "roofline" in out and out["roofline"].get("bound") == "mfma":
                 r = out["roofline"]
                 r["kernel"] = "pw_gemm_x (%d bf16 partial products per fp32 product) " % args.pw_emul + r["kernel"]

@@ -712,6 +712,12 @@ int mbn_dwpw_fused(mbn_context *ctx, void *out, const void *in, const void *wd, 
     // small problems (few images): a 256-column tile leaves most CUs idle and every workgroup walks the whole K alone —
     // batch 1, block 10-11: 40 us fused against 24 us as two launches — so below one 256-wide tile per CU the block runs
     // on 128-column tiles (twice the workgroups, half the MFMA work per step), i.e. on the unified kernel
+    // opt-in: pointwise products on the bf16 matrix cores from exact operand splits (mbn_f32_dwpw2_x6.hip; pw_emul = 6 | 9)
+    if (g_mbn_tune.pw_emul != 0 && g_mbn_tune.dwpw_variant == 0 &&
+        mbn_launch_f32_dwpw2_x6(ctx, s, (float *)out, (const float *)in, (const float *)wd, (const float *)s2, (const float *)b2,
+                                (const float *)wp, (const float *)s3, (const float *)b3, batch, in_rows, in_cols, out_rows, out_cols,
+                                cin, cout, stride, pad_top, pad_left) == MBN_OK)
+        return sc.finish(MBN_OK);
     const int dv = g_mbn_tune.dwpw_variant;
     const long tiles256 = (((long)batch * out_rows * out_cols + 127) / 128) * (cout / 256);
     const bool small = tiles256 < ctx->num_cus;

@@ -274,11 +274,12 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) __attribute__((amdgpu_w
 // ---- filter pre-split: [N][K] fp32 -> per (n-tile, k-tile) the three planes of BN rows x 64 B in the LDS image order of
 // pw_gemm_xb (rows past N repeat row N-1). One thread per (row, 16-byte chunk): 4 * BN threads per block.
 template <int BN>
-__global__ __launch_bounds__(4 * BN) void split_filter(unsigned *ws, const float *filt, int n, int k)
+__global__ __launch_bounds__(4 * BN) void split_filter(unsigned *ws, const float *filt, int n, int k, int paired)
 {
     const int ntile = blockIdx.x, kt = blockIdx.y, nk = gridDim.y;
     const int row = threadIdx.x >> 2, c = threadIdx.x & 3;
-    const int gn = min(ntile * BN + row, n - 1);
+    // paired: image row `row` holds output channel mbn_pair_channel(row) (mbn_epilogue.h: 8-byte epilogue stores of the fused blocks)
+    const int gn = min(ntile * BN + (paired ? mbn_pair_channel(row) : row), n - 1);
     const float *src = filt + (long)gn * k + kt * KT + c * 8;
     u4 H, M, L;
     split8(*reinterpret_cast<const f4 *>(src), *reinterpret_cast<const f4 *>(src + 4), H, M, L);
@@ -513,27 +514,13 @@ int launch_xb(XArgs &a, const mbn_call &c)
     a.mt = (int)((a.m + BM - 1) / BM);
     a.nt = (a.n + BN - 1) / BN;
     const int nk = a.k / KT;
-    const size_t need = (size_t)a.nt * nk * 3 * BN * PW * 4;
-    if (need >= 0xFFFFFFFFull) return MBN_EUNSUPPORTED;
-    // workspace per filter pointer (two sub-batch streams run different layers at the same time; the same layer's image is
-    // rewritten with identical bytes by every launch, so the filter may change between calls like any other argument)
-    void *ws = nullptr;
-    {
-        std::lock_guard<std::mutex> g(c.ctx->mu);
-        auto it = c.ctx->emul_ws.find((uintptr_t)a.filt);
-        if (it != c.ctx->emul_ws.end() && it->second.second >= need) ws = it->second.first;
-        else {
-            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-            (void)hipStreamIsCapturing(c.stream, &cs);
-            if (cs != hipStreamCaptureStatusNone) return MBN_EUNSUPPORTED;     // no allocation inside a capture: the default kernels answer
-            if (it != c.ctx->emul_ws.end()) { (void)hipDeviceSynchronize(); (void)hipFree(it->second.first); c.ctx->emul_ws.erase(it); }
-            if (hipMalloc(&ws, need) != hipSuccess) return MBN_EUNSUPPORTED;
-            c.ctx->emul_ws[(uintptr_t)a.filt] = std::make_pair(ws, need);
-        }
-    }
-    a.bws = (const unsigned *)ws;
-    a.bws_bytes = (unsigned)need;
-    hipLaunchKernelGGL((split_filter<BN>), dim3(a.nt, nk), dim3(4 * BN), 0, c.stream, (unsigned *)ws, a.filt, a.n, a.k);
+    (void)nk;
+    const unsigned *img = nullptr;
+    unsigned img_bytes = 0;
+    const int rc = mbn_pw_emul_filter_image(c.ctx, c.stream, a.filt, a.n, a.k, BN, 0, &img, &img_bytes);
+    if (rc != MBN_OK) return rc;
+    a.bws = img;
+    a.bws_bytes = img_bytes;
     const int lds_bytes = (3 * BM * PW + 2 * 3 * BN * PW + 4 * BN) * 4;
     int per_cu = 160 * 1024 / lds_bytes;
     if (per_cu > OCC * 4 / (NT / 64)) per_cu = OCC * 4 / (NT / 64);
@@ -595,6 +582,41 @@ int launch_np(XArgs &a, hipStream_t s, int num_cus, int tile)
 }
 
 }   // namespace
+
+// The pre-split filter image of pw_gemm_xb and dwpw2_x6: [n-tile][k-tile][plane][bn rows][64 B] (rows past n repeat row n-1;
+// paired: rows in mbn_pair_channel order), written on `stream` by split_filter into a workspace owned by the context. One
+// workspace per (filter pointer, layout): two sub-batch streams run different layers at the same time, and the same layer's
+// image is rewritten with identical bytes by every launch — the filter may change between calls like any other argument.
+// MBN_EUNSUPPORTED when the workspace would have to be allocated inside a stream capture.
+int mbn_pw_emul_filter_image(mbn_context *ctx, hipStream_t stream, const float *filt, int n, int k, int bn, int paired,
+                             const unsigned **img, unsigned *bytes)
+{
+    if ((bn != 64 && bn != 128 && bn != 256) || k < KT || (k % KT) != 0 || n <= 0) return MBN_EUNSUPPORTED;
+    const int nt = (n + bn - 1) / bn, nk = k / KT;
+    const size_t need = (size_t)nt * nk * 3 * bn * PW * 4;
+    if (need >= 0xFFFFFFFFull) return MBN_EUNSUPPORTED;
+    void *ws = nullptr;
+    {
+        std::lock_guard<std::mutex> g(ctx->mu);
+        const std::pair<uintptr_t, int> key((uintptr_t)filt, bn * 2 + (paired ? 1 : 0));
+        auto it = ctx->emul_ws.find(key);
+        if (it != ctx->emul_ws.end() && it->second.second >= need) ws = it->second.first;
+        else {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            (void)hipStreamIsCapturing(stream, &cs);
+            if (cs != hipStreamCaptureStatusNone) return MBN_EUNSUPPORTED;
+            if (it != ctx->emul_ws.end()) { (void)hipDeviceSynchronize(); (void)hipFree(it->second.first); ctx->emul_ws.erase(it); }
+            if (hipMalloc(&ws, need) != hipSuccess) return MBN_EUNSUPPORTED;
+            ctx->emul_ws[key] = std::make_pair(ws, need);
+        }
+    }
+    if (bn == 64) hipLaunchKernelGGL((split_filter<64>), dim3(nt, nk), dim3(256), 0, stream, (unsigned *)ws, filt, n, k, paired);
+    else if (bn == 128) hipLaunchKernelGGL((split_filter<128>), dim3(nt, nk), dim3(512), 0, stream, (unsigned *)ws, filt, n, k, paired);
+    else hipLaunchKernelGGL((split_filter<256>), dim3(nt, nk), dim3(1024), 0, stream, (unsigned *)ws, filt, n, k, paired);
+    *img = (const unsigned *)ws;
+    *bytes = (unsigned)need;
+    return MBN_OK;
+}
 
 // MBN_OK if launched; MBN_EUNSUPPORTED if the mode is off or the shape is outside this kernel's envelope.
 int mbn_launch_f32_pw_emul(const mbn_call &c, float *out, const float *in, const float *filt, long m, int cin, int op_size)

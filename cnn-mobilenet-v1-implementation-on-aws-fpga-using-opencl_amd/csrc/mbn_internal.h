@@ -32,7 +32,7 @@ struct mbn_context {
     size_t marks_used = 0;
     void *lit_ws = nullptr;                      // LITERAL pointwise on v_dot4: packed int8 filter + per-channel weight sums + flag
     size_t lit_ws_bytes = 0;
-    std::map<uintptr_t, std::pair<void *, size_t>> emul_ws;   // pw_emul: pre-split filter images, by filter pointer (mbn_f32_pw_x6.hip)
+    std::map<std::pair<uintptr_t, int>, std::pair<void *, size_t>> emul_ws;   // pw_emul: pre-split filter images, by filter pointer (mbn_f32_pw_x6.hip)
     std::mutex mu;
     std::map<uintptr_t, size_t> allocs;          // buffers handed out by mbn_alloc: base address -> bytes (ordered: mbn_span_check
                                                  // finds the allocation that CONTAINS an interior pointer)
@@ -106,6 +106,11 @@ int mbn_launch_f32_pointwise(const mbn_call &c, void *out, const void *in, const
                              int op_size);
 int mbn_launch_f32_pw_splitk(const mbn_call &c, float *out, const float *in, const float *filt, long m, int cin, int op_size);
 int mbn_launch_f32_pw_emul(const mbn_call &c, float *out, const float *in, const float *filt, long m, int cin, int op_size);
+int mbn_pw_emul_filter_image(mbn_context *ctx, hipStream_t stream, const float *filt, int n, int k, int bn, int paired,
+                             const unsigned **img, unsigned *bytes);
+int mbn_launch_f32_dwpw2_x6(mbn_context *ctx, hipStream_t stream, float *out, const float *in, const float *wd, const float *s2,
+                            const float *b2, const float *wp, const float *s3, const float *b3, int batch, int in_rows, int in_cols,
+                            int out_rows, int out_cols, int cin, int cout, int stride, int pad_top, int pad_left);
 int mbn_launch_bf16_pw_ring(const mbn_call &c, void *out, const void *in, const void *filt, long m, int cin, int op_size);
 int mbn_launch_f32_pool(const mbn_call &c, void *out, const void *in, int rows, int cols, int fs, int channels);
 // floor(v / d) == umulhi(v, *m) >> *s for every v < 2^31 (d >= 2); d == 1 gives *m = 0 (callers skip the multiply)

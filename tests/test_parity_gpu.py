@@ -802,6 +802,69 @@ def test_f32_dwpw_fused(pkg, orc, ctx, shape):
         b.free()
 
 
+DWPW_EMUL_SHAPES = DWPW_SHAPES[:4] + [(3, 14, 32, 128, 1), (5, 12, 96, 128, 2), (1, 2, 32, 256, 1), (2, 14, 512, 512, 1),
+                                       (43, 28, 256, 256, 1), (170, 28, 128, 256, 2),        # enough tiles for the 256-column tile
+                                       (3, 14, 640, 128, 1)]                                  # Cin > 512: falls back to the fp32 kernels
+
+
+@pytest.mark.parametrize("form", [6, 9])
+@pytest.mark.parametrize("shape", DWPW_EMUL_SHAPES)
+def test_f32_dwpw_fused_emul(pkg, orc, ctx, shape, form):
+    """mbn_dwpw_fused under the opt-in pw_emul = 6 | 9 (mbn_f32_dwpw2_x6.hip: depthwise output split into three bf16 planes on its
+    way into LDS, pre-split channel-paired filter image, bf16 MFMAs): against the oracle at the fp32 tolerance and BIT-IDENTICAL
+    to mbn_depthwise + mbn_pointwise under the same pw_emul (same depthwise fma order, same split, same product and chunk order
+    as pw_gemm_xb). Both tile widths, both strides, ragged M, many tiles per workgroup; repeatable."""
+    n, h, cin, cout, stride = shape
+    rng = np.random.default_rng(h * 13 + cin + cout + stride + form)
+    x = rng.uniform(-1, 1, (n, h, h, cin)).astype(np.float32)
+    wd = rng.normal(0, 0.5, (3, 3, cin)).astype(np.float32)
+    wp = rng.normal(0, (2.0 / cin) ** 0.5, (cout, cin)).astype(np.float32)
+    s2, s3 = rng.uniform(0.5, 1.5, cin).astype(np.float32), rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    b2, b3 = rng.normal(0, 0.1, cin).astype(np.float32), rng.normal(0, 0.1, cout).astype(np.float32)
+    oh = (h + stride - 1) // stride
+    pad = max((oh - 1) * stride + 3 - h, 0) // 2
+    big = n * oh * oh > 20000
+    sel = slice(0, 2) if big else slice(0, n)                           # the oracle on the first two images of the big cases
+    mid = orc.f32_depthwise(x[sel], wd, s2, b2, stride, 2, pad_top=pad, pad_left=pad)
+    want = orc.f32_pointwise(mid.reshape(-1, cin), wp, s3, b3, 2).reshape(-1, oh, oh, cout)
+    full = (n, oh, oh, cout)
+    d = [ctx.to_device(a) for a in (x, wd, s2, b2, wp, s3, b3)]
+    nbytes = int(np.prod(full)) * 4
+    d_f, d_m, d_u = ctx.alloc(nbytes + 64), ctx.alloc(n * oh * oh * cin * 4), ctx.alloc(nbytes)
+    try:
+        assert ctx.lib.mbn_tune_set(b"pw_emul", form) == 0
+        assert ctx.lib.mbn_tune_set(b"pw_splitk", 1) == 0
+        ctx.lib.mbn_memset(ctx.h, d_f.ptr, 0xFF, nbytes + 64)
+        rc = ctx.lib.mbn_dwpw_fused(ctx.h, d_f.ptr, d[0].ptr, d[1].ptr, d[2].ptr, d[3].ptr, d[4].ptr, d[5].ptr, d[6].ptr,
+                                    n, h, h, oh, oh, cin, cout, stride, pad, pad, None)
+        assert rc == 0, rc
+        ctx.sync()
+        raw = d_f.download((nbytes // 4 + 16,), np.float32)
+        assert np.all(raw[nbytes // 4:].view(np.uint32) == 0xFFFFFFFF), "stores past the output"
+        fused = raw[:nbytes // 4].reshape(full)
+        assert_close(fused[sel], want, TOL_PW, "dwpw emul %s vs oracle" % (shape,))
+        rc = ctx.lib.mbn_dwpw_fused(ctx.h, d_f.ptr, d[0].ptr, d[1].ptr, d[2].ptr, d[3].ptr, d[4].ptr, d[5].ptr, d[6].ptr,
+                                    n, h, h, oh, oh, cin, cout, stride, pad, pad, None)
+        ctx.sync()
+        assert np.array_equal(fused, d_f.download(full, np.float32)), "not repeatable"
+        ctx.depthwise(d_m.ptr, d[0].ptr, d[1].ptr, oh, oh, 3, stride, cin,
+                      pkg.make_ext(batch=n, act=2, pad_top=pad, pad_left=pad, in_rows=h, in_cols=h, scale=d[2].ptr, shift=d[3].ptr))
+        if cin <= 512:
+            assert ctx.lib.mbn_tune_set(b"pw_tile", 11) == 0          # the split GEMM whatever the tile count
+        ctx.pointwise(d_u.ptr, d_m.ptr, d[4].ptr, n * oh * oh, 1, cin, cout, pkg.make_ext(batch=1, act=2, scale=d[5].ptr, shift=d[6].ptr))
+        ctx.sync()
+        unfused = d_u.download(full, np.float32)
+        if cin <= 512:
+            assert np.array_equal(fused, unfused), "fused emul block differs from depthwise + pointwise(emul) by %g" % np.abs(fused - unfused).max()
+        else:
+            assert_close(fused, unfused, TOL_PW, "fallback block")
+    finally:
+        for k in (b"pw_emul", b"pw_splitk", b"pw_tile"):
+            ctx.lib.mbn_tune_set(k, 0)
+        for b in d + [d_f, d_m, d_u]:
+            b.free()
+
+
 def test_f32_dwpw_fused_envelope(pkg, ctx):
     """Shapes outside the kernel's envelope answer MBN_EUNSUPPORTED (caller falls back to two launches); null -> EINVAL."""
     d = ctx.alloc(1 << 20)
@@ -1601,3 +1664,12 @@ def test_literal_pointwise_on_dot4_is_bit_exact(pkg, orc, ctx, shape):
     ctx.pointwise(d_o.ptr, d_x.ptr, d_f.ptr, rows, cols, cin, oc, pkg.make_ext(dtype=pkg.DT_U8, quirks=1))
     ctx.sync()
     assert np.array_equal(d_o.download(wantc.shape, np.uint8), wantc)
+
+
+def test_graft_entry_smoke_runs():
+    """__graft_entry__.smoke() is what the driver runs on the GPU box before the bench: it must keep passing when dispatch
+    rules change (it asserts which fused kernels are on its path)."""
+    import importlib
+    ge = importlib.import_module("__graft_entry__")
+    ge.smoke()
+

@@ -41,9 +41,15 @@ for first in [int(b) for b in args.blocks.split(",")]:
     e_dw = pkg.make_ext(batch=n, act=2, pad_top=ldw.pad_top, pad_left=ldw.pad_left, in_rows=h, in_cols=h, scale=d[2].ptr, shift=d[3].ptr)
     e_pw = pkg.make_ext(batch=1, act=2, scale=d[5].ptr, shift=d[6].ptr)
 
+    emul = [kv for kv in args.tune if kv.startswith("pw_emul=")]      # an arithmetic form, not a kernel variant: applies to both sides
+
     def unfused():
+        for kv in emul:
+            lib.mbn_tune_set(b"pw_emul", int(kv.split("=")[1]))
         ctx.depthwise(d_m.ptr, d[0].ptr, d[1].ptr, oh, oh, 3, s, cin, e_dw)
         ctx.pointwise(d_u.ptr, d_m.ptr, d[4].ptr, n * oh * oh, 1, cin, cout, e_pw)
+        for kv in emul:
+            lib.mbn_tune_set(b"pw_emul", 0)
 
     def fused():
         for kv in args.tune:
