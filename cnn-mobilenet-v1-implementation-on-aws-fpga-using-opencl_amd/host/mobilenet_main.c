@@ -4,7 +4,7 @@
  *   mobilenet --h5 weights.h5 [--ppm image.ppm] [--batch N] [--res 224] [--alpha 1.0]      fp32 path
  *   mobilenet --synthetic SEED [--alpha A] [--res R] [--batch N]                              fp32, synthetic weights
  *   mobilenet --literal [--weights weights_c.txt] [--image Cat_Image0.ppm] [--ref-args]      the reference's own mode
- *   mobilenet --gpus G --batch N [--steps K --warmup W --streams S] (--h5 F | --synthetic SEED)  N images sharded over G GPUs
+ *   mobilenet --gpus G --batch N [--steps K --warmup W --streams S --pw-emul 6] (--h5 F | --synthetic SEED)  N images sharded over G GPUs
  *   mobilenet --inspect weights.h5                                                             list the datasets of a .h5
  *   mobilenet --convert weights.h5 out.txt                                                     folded blob as text (one %.9g per line)
  *
@@ -289,12 +289,15 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[i], "--gpus") && i + 1 < argc) gpus = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--steps") && i + 1 < argc) steps = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--streams") && i + 1 < argc) g_streams = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--pw-emul") && i + 1 < argc) {          /* opt-in arithmetic form of the pointwise layers (mbn.h: pw_emul) */
+            if (mbn_tune_set("pw_emul", atoi(argv[++i])) != MBN_OK) { fprintf(stderr, "bad --pw-emul\n"); return 2; }
+        }
         else if (!strcmp(argv[i], "--warmup") && i + 1 < argc) warmup = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--literal")) literal = 1;
         else if (!strcmp(argv[i], "--ref-args")) ref_args = 1;
         else {
             fprintf(stderr, "usage: %s [--h5 F | --synthetic SEED | --literal] [--ppm F] [--batch N] [--res R] [--alpha A] "
-                            "[--gpus G [--steps K] [--warmup W] [--streams S]]\n", argv[0]);
+                            "[--gpus G [--steps K] [--warmup W] [--streams S] [--pw-emul 6]]\n", argv[0]);
             return 2;
         }
     }
