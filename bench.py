@@ -362,7 +362,8 @@ def main():
             flops_per_launch = sum(layer_work(plan.layer[i], args.batch, pkg, act_bytes)[0] for i in pw_idx) / len(pw_idx)
             bytes_per_launch = sum(layer_work(plan.layer[i], args.batch, pkg, act_bytes)[1] for i in pw_idx) / len(pw_idx)
             avg_ms = pw["ms"] / len(pw_idx)           # per LAYER (= per launch when --streams 1)
-            traffic, traffic_src = load_traffic([i + 1 for i in pw_idx], "bf16_%gx%d" % (args.alpha, args.res) if bf16 else "f32")
+            traffic, traffic_src = load_traffic([i + 1 for i in pw_idx], "bf16_%gx%d" % (args.alpha, args.res) if bf16 else
+                                                ("f32_pw_emul%d" % args.pw_emul if args.pw_emul else "f32"))
             if bf16:       # ridge ~312 flop/B: every pointwise layer is HBM-bound in bf16
                 out["roofline"] = {
                     "kernel": ("pw_gemm<bf16> (%d pointwise 1x1 conv launches per step)" if dom == "pointwise" else

@@ -309,7 +309,7 @@ __device__ __forceinline__ void dma_pieces(const __amdgpu_buffer_rsrc_t rsrc, un
 // ---- the GEMM with the filter planes streamed by LDS-DMA from the pre-split image (double-buffered: a k-tile ahead) and only
 // the activations split on the way in (single-buffered planes, two barriers per k-tile): half the VALU work and LDS writes of
 // pw_gemm_x, 16 staging VGPRs less.
-template <int BM, int BN, int WM, int WN, int NP, int OCC>
+template <int BM, int BN, int WM, int WN, int NP, int OCC, int NBB = 2, int ASETS = 2>
 __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void pw_gemm_xb(XArgs a)
 {
     constexpr int WAVES_N = BN / WN, NW = (BM / WM) * WAVES_N, NT = 64 * NW;
@@ -320,9 +320,10 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) __attribute__((amdgpu_w
     constexpr int PLANE_A = BM * PW, PLANE_B = BN * PW, IMG_B = 3 * PLANE_B;        // words
     constexpr int NPC = IMG_B / 256 / NW;                                          // 1-KB DMA pieces per wave per k-tile
     static_assert(NPC * NW * 256 == IMG_B, "filter image / waves mismatch");
-    __shared__ __attribute__((aligned(16))) unsigned lds[3 * PLANE_A + 2 * IMG_B + 4 * BN];
+    // NBB = 1: one filter buffer (50 KB per workgroup: three per CU); its DMA is then issued behind the first barrier of the k-tile
+    __shared__ __attribute__((aligned(16))) unsigned lds[3 * PLANE_A + NBB * IMG_B + 4 * BN];
     unsigned *const Bbuf = lds + 3 * PLANE_A;
-    float *const ss_s = reinterpret_cast<float *>(lds + 3 * PLANE_A + 2 * IMG_B);
+    float *const ss_s = reinterpret_cast<float *>(lds + 3 * PLANE_A + NBB * IMG_B);
     const bool ss_lds = a.scale && a.shift;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nwg = a.mt * a.nt;
@@ -391,7 +392,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) __attribute__((amdgpu_w
     if (vb >= nwg) return;
     set_tile(vb, m0, n0);
     stage_load(a_r0, 0);
-    if (nk > 1) stage_load(a_r1, KT);
+    if (ASETS == 2 && nk > 1) stage_load(a_r1, KT);
     dma_b(0, 0);
 
     for (;;) {
@@ -423,6 +424,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) __attribute__((amdgpu_w
                         for (int ni = 0; ni < NI; ni++)
                             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, fa[Prod<NP>::pa[q]][mi]),
                                                                                   __builtin_bit_cast(bf8, fb[Prod<NP>::pb[q]][ni]), acc[mi][ni], 0, 0, 0);
+                if (OCC >= 3) __builtin_amdgcn_sched_barrier(0);   // one step's fragments live at a time (168 VGPRs)
             }
         };
         float *const sc_s = ss_s + (tpar ? 2 * BN : 0), *const sh_s = sc_s + BN;
@@ -433,6 +435,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) __attribute__((amdgpu_w
         }
         tpar ^= 1;
         stage_store(a_r0);
+        if (ASETS == 1 && nk > 1) stage_load(a_r0, KT);       // one register set: the next k-tile's loads go out right behind the split
         __syncthreads();                                      // A planes of k-tile 0 written, filter image 0 landed (vmcnt(0) ahead of the barrier)
         // one k-tile: PEND holds the loads of k-tile kt + 1 (issued a k-tile ago), FRESH receives those of kt + 2. HAS1 / HAS2 =
         // "k-tile kt + 1 / kt + 2 exists": literal constants in the steady state and in the even tail, so that the loop body is
@@ -441,32 +444,37 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) __attribute__((amdgpu_w
 #define XB_KTILE(KTV, PEND, FRESH, HAS1, HAS2)                                                                              \
         {                                                                                                                  \
             const int kt_ = (KTV);                                                                                         \
-            if (HAS1) dma_b(kt_ + 1, (kt_ + 1) & 1);                  /* older than the A loads below: vmcnt(their count) covers it */ \
-            if (HAS2) stage_load(FRESH, (kt_ + 2) * KT);                                                                   \
+            if (NBB == 2 && HAS1) dma_b(kt_ + 1, (kt_ + 1) & 1);      /* older than the A loads below: vmcnt(their count) covers it */ \
+            if (ASETS == 2 && NBB == 2 && HAS2) stage_load(FRESH, (kt_ + 2) * KT);                                         \
             __builtin_amdgcn_sched_barrier(0);                /* loads in flight before the first MFMA */                  \
-            compute(Bbuf + (kt_ & 1) * IMG_B);                                                                             \
-            xb_barrier<-1>();                                 /* everyone has read the A planes of k-tile kt */            \
+            compute(Bbuf + (NBB == 2 ? (kt_ & 1) : 0) * IMG_B);                                                            \
+            xb_barrier<-1>();                                 /* everyone has read the A planes (and the filter image) of k-tile kt */ \
             __builtin_amdgcn_sched_barrier(0);                /* keep the split (and the wait for its loads) behind the MFMAs */ \
+            if (NBB == 1 && HAS1) dma_b(kt_ + 1, 0);                                                                       \
+            if (ASETS == 2 && NBB == 1 && HAS2) stage_load(FRESH, (kt_ + 2) * KT);                                         \
             if (a.prio) __builtin_amdgcn_s_setprio(3);        /* the split is VALU work: not behind the other workgroup's MFMA stream */ \
             if (HAS1) stage_store(PEND);                                                                                   \
             if (a.prio) __builtin_amdgcn_s_setprio(0);                                                                     \
+            if (ASETS == 1 && HAS2) stage_load(PEND, (kt_ + 2) * KT);                                                      \
             if (HAS2) xb_barrier<2 * A_LD>();                 /* A planes of kt + 1 written, filter image kt + 1 landed */ \
             else xb_barrier<0>();                                                                                          \
         }
         int kt = 0;
+#define XB_R1 (ASETS == 2 ? a_r1 : a_r0)
         for (; kt + 3 < nk; kt += 2) {
-            XB_KTILE(kt, a_r1, a_r0, true, true)
-            XB_KTILE(kt + 1, a_r0, a_r1, true, true)
+            XB_KTILE(kt, XB_R1, a_r0, true, true)
+            XB_KTILE(kt + 1, a_r0, XB_R1, true, true)
         }
         if (nk - kt == 2) {
-            XB_KTILE(kt, a_r1, a_r0, true, false)
-            XB_KTILE(kt + 1, a_r0, a_r1, false, false)
+            XB_KTILE(kt, XB_R1, a_r0, true, false)
+            XB_KTILE(kt + 1, a_r0, XB_R1, false, false)
         } else {
             for (; kt < nk; kt += 2) {                        // odd K / 32 (not in the network): at most three k-tiles, run-time conditions
-                XB_KTILE(kt, a_r1, a_r0, kt + 1 < nk, kt + 2 < nk)
-                if (kt + 1 < nk) XB_KTILE(kt + 1, a_r0, a_r1, kt + 2 < nk, kt + 3 < nk)
+                XB_KTILE(kt, XB_R1, a_r0, kt + 1 < nk, kt + 2 < nk)
+                if (kt + 1 < nk) XB_KTILE(kt + 1, a_r0, XB_R1, kt + 2 < nk, kt + 3 < nk)
             }
         }
+#undef XB_R1
 #undef XB_KTILE
 
         const long cm0 = m0;
@@ -476,7 +484,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) __attribute__((amdgpu_w
         if (more) {
             set_tile(nvb, m0, n0);
             stage_load(a_r0, 0);
-            if (nk > 1) stage_load(a_r1, KT);
+            if (ASETS == 2 && nk > 1) stage_load(a_r1, KT);
             dma_b(0, 0);                                      // both filter buffers are free after the loop's last barrier
         }
 
@@ -507,7 +515,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) __attribute__((amdgpu_w
     }
 }
 
-template <int BM, int BN, int WM, int WN, int NP, int OCC>
+template <int BM, int BN, int WM, int WN, int NP, int OCC, int NBB = 2, int ASETS = 2>
 int launch_xb(XArgs &a, const mbn_call &c)
 {
     constexpr int NT = 64 * (BM / WM) * (BN / WN);
@@ -521,7 +529,7 @@ int launch_xb(XArgs &a, const mbn_call &c)
     if (rc != MBN_OK) return rc;
     a.bws = img;
     a.bws_bytes = img_bytes;
-    const int lds_bytes = (3 * BM * PW + 2 * 3 * BN * PW + 4 * BN) * 4;
+    const int lds_bytes = (3 * BM * PW + NBB * 3 * BN * PW + 4 * BN) * 4;
     int per_cu = 160 * 1024 / lds_bytes;
     if (per_cu > OCC * 4 / (NT / 64)) per_cu = OCC * 4 / (NT / 64);
     if (per_cu < 1) per_cu = 1;
@@ -529,7 +537,7 @@ int launch_xb(XArgs &a, const mbn_call &c)
     const long nwg = (long)a.mt * a.nt;
     long grid = (long)c.ctx->num_cus * per_cu;
     if (grid > nwg) grid = nwg;
-    hipLaunchKernelGGL((pw_gemm_xb<BM, BN, WM, WN, NP, OCC>), dim3((unsigned)grid), dim3(NT), 0, c.stream, a);
+    hipLaunchKernelGGL((pw_gemm_xb<BM, BN, WM, WN, NP, OCC, NBB, ASETS>), dim3((unsigned)grid), dim3(NT), 0, c.stream, a);
     return MBN_OK;
 }
 
@@ -542,6 +550,8 @@ int launch_np_b(XArgs &a, const mbn_call &c, int tile)
     case 13: return launch_xb<256, 128, 64, 64, NP, 2>(a, c);     // 8 waves of 64x64, 98 KB
     case 14: return launch_xb<128, 128, 32, 64, NP, 2>(a, c);     // 8 waves of 32x64, 74 KB, 1 workgroup per CU
     case 15: return launch_xb<128, 128, 32, 64, NP, 4>(a, c);     // 8 waves of 32x64, 2 workgroups per CU (128 VGPRs)
+    case 16: return launch_xb<128, 128, 64, 64, NP, 3, 1, 1>(a, c);  // one filter buffer, one A register set, 50 KB: 3 workgroups per CU (168 VGPRs)
+    case 17: return launch_xb<128, 128, 64, 64, NP, 2, 1>(a, c);  // one filter buffer at 2 workgroups per CU (A/B of the buffer alone)
     default: return MBN_EINVAL;
     }
 }
