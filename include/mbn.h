@@ -502,8 +502,12 @@ const char *mbn_version(void);
  *                bf16 x bf16 partial products on v_mfma_f32_32x32x16_bf16 with the fp32 accumulator; fp32 in, fp32 out. The 3 dropped
  *                partial products of 6 are below 2^-24 of the product. Measured error against a float64 product on the network's
  *                layer shapes: equal to or smaller than the fp32 MFMA kernel's (profiles/r02/m_pw_emul.txt); layers 13-27 at
- *                batch 256: 1.49 -> 1.24 ms, whole step +12 %. Applies to pointwise calls with K % 32 == 0 and at least as many
- *                128x128 tiles as CUs; everything else takes the default kernels.
+ *                batch 256: 1.41 -> 1.14 ms; with the fused blocks (mbn_dwpw_fused takes mbn_f32_dwpw2_x6.hip for Cin <= 512) the whole
+ *                step 89 k -> 108-110 k images/s. Applies to pointwise calls with K % 32 == 0 and at least as many 128x128 tiles as
+ *                CUs; everything else takes the default kernels — which form a layer takes therefore depends on the size of the call,
+ *                and forward(n)[:k] == forward(k) holds bit for bit only between calls whose layers take the same forms (fused blocks
+ *                and stand-alone pairs agree bit for bit under the same value). Each filter pointer gets a pre-split image (6 bytes per
+ *                weight) in the context on first use (not inside a hipGraph capture: the unsplit-filter kernel is taken there).
  *   pw_xn        pointwise GEMM tile order: XCD groups along n (0 = by filter size, 1 = single ordering, 2, 4)
  *   dwpw_variant fused block kernel: 0 = shipped choice, 1 = round-1 producer/consumer kernels, 2 = unified-wave kernels,
  *                3 = unified fp32 with the taps read inside the step, 100 + bits = unified with parts switched off */
