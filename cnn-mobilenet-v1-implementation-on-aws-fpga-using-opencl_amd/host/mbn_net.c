@@ -31,6 +31,7 @@ struct mbn_net {
     int fuse_blocks_set;       /* the caller chose a mask; otherwise the default of the current dtype applies */
     int use_graph;             /* mbn_net_set_graph */
     void *graph;               /* instantiated hipGraph of one forward, valid for the key below */
+    int g_emul;                /* pw_emul value the graph was captured under */
     const void *g_images;
     void *g_logits;
     int g_batch, g_last, g_dtype, g_keep;
@@ -479,8 +480,10 @@ static int forward_impl(mbn_net *net, const void *images, void *logits, int batc
     if (ns <= 1) net->fr_images = NULL;                /* a single-stream forward in between: the next multi-stream one forks again */
     if (ns <= 1 && net->use_graph && !layer_ms) {
         /* launch-bound batches: replay the 29 launches as one hipGraph; re-capture when the call's key changes */
+        int emul = 0;
+        (void)mbn_tune_get("pw_emul", &emul);              /* the arithmetic form of the pointwise layers is baked into the capture */
         if (net->graph && (net->g_images != images || net->g_logits != logits || net->g_batch != batch ||
-                           net->g_last != last_layer || net->g_dtype != net->dtype || net->g_keep != net->keep)) {
+                           net->g_last != last_layer || net->g_dtype != net->dtype || net->g_keep != net->keep || net->g_emul != emul)) {
             mbn_sync(net->ctx);
             mbn_graph_destroy(net->ctx, net->graph);
             net->graph = NULL;
@@ -494,7 +497,11 @@ static int forward_impl(mbn_net *net, const void *images, void *logits, int batc
                         int rc = mbn_alloc(net->ctx, bytes, &net->keep_buf[i]);
                         if (rc != MBN_OK) return rc;
                     }
-            int rc = mbn_graph_begin(net->ctx, NULL);
+            /* one eager pass first: kernels that allocate a workspace on first use (the pre-split filter images of pw_emul) must
+             * have done so before the capture, inside which nothing may be allocated */
+            int rc = forward_range(net, images, logits, 0, batch, last_layer, NULL, NULL, 0, NULL, 0);
+            if (rc != MBN_OK) return rc;
+            rc = mbn_graph_begin(net->ctx, NULL);
             if (rc != MBN_OK) return rc;
             rc = forward_range(net, images, logits, 0, batch, last_layer, NULL, NULL, 0, NULL, 0);
             void *g = NULL;
@@ -502,7 +509,7 @@ static int forward_impl(mbn_net *net, const void *images, void *logits, int batc
             if (rc != MBN_OK || rc2 != MBN_OK) { if (g) mbn_graph_destroy(net->ctx, g); return rc != MBN_OK ? rc : rc2; }
             net->graph = g;
             net->g_images = images; net->g_logits = logits; net->g_batch = batch; net->g_last = last_layer;
-            net->g_dtype = net->dtype; net->g_keep = net->keep;
+            net->g_dtype = net->dtype; net->g_keep = net->keep; net->g_emul = emul;
         }
         return mbn_graph_launch(net->ctx, net->graph, NULL);
     }

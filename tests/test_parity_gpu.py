@@ -1666,6 +1666,38 @@ def test_literal_pointwise_on_dot4_is_bit_exact(pkg, orc, ctx, shape):
     assert np.array_equal(d_o.download(wantc.shape, np.uint8), wantc)
 
 
+def test_net_graph_under_pw_emul(pkg, ctx, tmp_path):
+    """mbn_net_set_graph with the opt-in pw_emul: the pre-split filter images are allocated on first use, which may not happen
+    inside a capture — the runner makes one eager pass before it captures, and the graph key holds the pw_emul value. Replayed
+    logits == eager logits bit for bit under pw_emul 6, and switching back to 0 re-captures the default kernels."""
+    n = 64
+    hw, net = _make_net(pkg, ctx, tmp_path, 1.0, 224, 1000, n)
+    imgs = _headline_images(n, 224, 77)
+    d_in, d_out = ctx.to_device(imgs), ctx.alloc(n * 1000 * 4)
+
+    def fwd():
+        net.forward(d_in.ptr, d_out.ptr, n)
+        ctx.sync()
+        return d_out.download((n, 1000), np.float32)
+    base = fwd()
+    try:
+        assert ctx.lib.mbn_tune_set(b"pw_emul", 6) == 0
+        net.set_graph(True)                                  # first forward under the graph: eager pass + capture + replay
+        g1 = fwd()
+        g2 = fwd()
+        net.set_graph(False)
+        eager = fwd()
+        assert np.array_equal(g1, eager) and np.array_equal(g2, eager)
+        assert not np.array_equal(eager, base), "the split kernels were not on the path"
+        net.set_graph(True)
+        fwd()
+        assert ctx.lib.mbn_tune_set(b"pw_emul", 0) == 0
+        assert np.array_equal(fwd(), base), "the graph was not re-captured after pw_emul changed"
+    finally:
+        ctx.lib.mbn_tune_set(b"pw_emul", 0)
+        net.destroy()
+
+
 def test_graft_entry_smoke_runs():
     """__graft_entry__.smoke() is what the driver runs on the GPU box before the bench: it must keep passing when dispatch
     rules change (it asserts which fused kernels are on its path)."""
