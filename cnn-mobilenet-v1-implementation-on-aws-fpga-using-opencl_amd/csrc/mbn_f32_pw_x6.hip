@@ -552,6 +552,9 @@ int launch_np_b(XArgs &a, const mbn_call &c, int tile)
     case 15: return launch_xb<128, 128, 32, 64, NP, 4>(a, c);     // 8 waves of 32x64, 2 workgroups per CU (128 VGPRs)
     case 16: return launch_xb<128, 128, 64, 64, NP, 3, 1, 1>(a, c);  // one filter buffer, one A register set, 50 KB: 3 workgroups per CU (168 VGPRs)
     case 17: return launch_xb<128, 128, 64, 64, NP, 2, 1>(a, c);  // one filter buffer at 2 workgroups per CU (A/B of the buffer alone)
+    case 18: return launch_xb<64, 128, 32, 64, NP, 3, 1, 1>(a, c);   // 64-row tiles (finer tail), 4 waves of 32x64, 38 KB: 3 workgroups per CU
+    case 19: return launch_xb<64, 128, 32, 64, NP, 4, 1, 1>(a, c);   // the same at 4 workgroups per CU (128 VGPRs)
+    case 20: return launch_xb<64, 128, 32, 64, NP, 2, 2, 2>(a, c);   // the same with two filter buffers and two A register sets, 2 per CU
     default: return MBN_EINVAL;
     }
 }

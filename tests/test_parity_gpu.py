@@ -1170,7 +1170,7 @@ def _emul_reset(ctx):
 
 
 @pytest.mark.parametrize("form", [6, 9])
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 11, 12, 13, 14, 15, 16, 17])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20])
 def test_f32_pointwise_emul_split_is_exact(pkg, ctx, form, tile):
     """mbn_f32_pw_x6.hip (opt-in, tune pw_emul = 6 | 9): every fp32 operand is split into three bf16 values that carry all 24
     bits. Proof on the device, for every tile instantiation: with one operand a (signed) power of two per row, the output is a
