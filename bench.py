@@ -319,7 +319,7 @@ def main():
                "steps": 10, "warmup": 3,
                "max_rel_diff_to_default_logits": float(np.abs(alt_logits.astype(np.float64) - logits).max() / max(float(np.abs(logits).max()), 1e-6)),
                "what": "mbn_tune_set(\"pw_emul\", 6): the pointwise layers 13-27 on mbn_f32_pw_x6.hip and the pointwise halves of the "
-                       "fused blocks 4-11 on mbn_f32_dwpw2_x6.hip - fp32 in/out, every "
+                       "fused blocks 4-11 on mbn_f32_dwpw2_x6.hip, the pointwise phase of the fused stem likewise - fp32 in/out, every "
                        "operand split exactly into three bf16 values, 6 bf16 MFMA partial products per fp32 product (the dropped "
                        "three are < 2^-24 of it), fp32 accumulate; measured error against float64 <= the fp32 MFMA kernel's "
                        "(profiles/r02/m_pw_emul.txt). Opt-in: `value` above is the fp32-MFMA path"}
@@ -420,7 +420,7 @@ def main():
             out["config"]["pw_emul"] = args.pw_emul
             out["config"]["arithmetic"] = ("pointwise layers 13-27 and the pointwise halves of the fused blocks 4-11: fp32 operands split exactly "
                                            "into three bf16 values, %d bf16 MFMA partial products per product, fp32 accumulate "
-                                           "(mbn_f32_pw_x6.hip, mbn_f32_dwpw2_x6.hip); stem, depthwise, pool, FC unchanged" % args.pw_emul)
+                                           "(mbn_f32_pw_x6.hip, mbn_f32_dwpw2_x6.hip) and the pointwise phase of the fused stem; conv1, depthwise, pool, FC unchanged" % args.pw_emul)
             if "roofline" in out and out["roofline"].get("bound") == "mfma":
                 r = out["roofline"]
                 r["kernel"] = "pw_gemm_x (%d bf16 partial products per fp32 product) " % args.pw_emul + r["kernel"]

@@ -129,6 +129,32 @@ __device__ __forceinline__ void patch_store(float *in_s, int tid, const f2 (&pf)
 // separate launches would store them — the pointwise filter is the bf16 copy, and the result is stored as bf16.
 __device__ __forceinline__ float rbf(float v) { return (float)(__bf16)v; }
 __device__ __forceinline__ f4 rbf4(f4 v) { return f4{ rbf(v.x), rbf(v.y), rbf(v.z), rbf(v.w) }; }
+// exact three-way bf16 split of fp32 values (mbn_f32_pw_x6.hip: h = bf16(x), m = bf16(x - h), l = x - h - m), packed two per word
+__device__ __forceinline__ void x6_split2(float x0, float x1, unsigned &h, unsigned &m, unsigned &l)
+{
+    typedef float f2e __attribute__((ext_vector_type(2)));
+    typedef __bf16 b2e __attribute__((ext_vector_type(2)));
+    const f2e v = f2e{ x0, x1 };
+    const b2e hh = __builtin_convertvector(v, b2e);
+    const f2e r = v - __builtin_convertvector(hh, f2e);
+    const b2e mm = __builtin_convertvector(r, b2e);
+    const f2e lo = r - __builtin_convertvector(mm, f2e);
+    h = __builtin_bit_cast(unsigned, hh);
+    m = __builtin_bit_cast(unsigned, mm);
+    l = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, b2e));
+}
+__device__ __forceinline__ void x6_split4(f4 v, unsigned (&h)[2], unsigned (&m)[2], unsigned (&l)[2])
+{
+    x6_split2(v.x, v.y, h[0], m[0], l[0]);
+    x6_split2(v.z, v.w, h[1], m[1], l[1]);
+}
+__device__ __forceinline__ void x6_split8(f4 v0, f4 v1, unsigned (&h)[4], unsigned (&m)[4], unsigned (&l)[4])
+{
+    x6_split2(v0.x, v0.y, h[0], m[0], l[0]);
+    x6_split2(v0.z, v0.w, h[1], m[1], l[1]);
+    x6_split2(v1.x, v1.y, h[2], m[2], l[2]);
+    x6_split2(v1.z, v1.w, h[3], m[3], l[3]);
+}
 
 // WPE = workgroups per CU (= waves per SIMD). The alpha = 1 forms need 59.6 KB (fp32) / 48.7 KB (bf16: A/B tiles in bf16) of LDS
 // and 246 / 232 VGPRs: two. With the nine depthwise tap vectors re-read from LDS per tile instead of living in 36 VGPRs for the
@@ -136,10 +162,15 @@ __device__ __forceinline__ f4 rbf4(f4 v) { return f4{ rbf(v.x), rbf(v.y), rbf(v.
 // 33.7 KB): more workgroups put one's conv1 phase (VALU) under the others' barriers and stores. Measured (batch 512,
 // profiles/r02/j_stem_occupancy.txt): alpha = 0.5 bf16 0.196 -> 0.153 ms, fp32 0.221 -> 0.173 ms with four; alpha = 1 bf16:
 // see the launcher.
-template <int C1, int C3, bool BF, int WPE, bool MC = false>
+// X6 = 6 | 9 (fp32 mode only, opt-in: mbn_tune_set("pw_emul", ...)): phase D forms its fp32 products from the exact three-way bf16
+// split of both operands (mbn_f32_pw_x6.hip): the depthwise output is split on its way into LDS (three bf16 planes), the filter once
+// per workgroup, and C1/16 x 6 (9) v_mfma_f32_32x32x16_bf16 per column block replace C1/2 fp32 MFMAs of twice the duration.
+template <int C1, int C3, bool BF, int WPE, bool MC = false, int X6 = 0>
 __global__ __launch_bounds__(256, WPE) void stem_fused_f32(StemArgs a)
 {
     static_assert(!MC || BF, "conv1 on the bf16 MFMA: bf16 mode");
+    static_assert(X6 == 0 || (!BF && (X6 == 6 || X6 == 9)), "split products: fp32 mode, 6 or 9 of them");
+    constexpr int APL = TH * TW * C1 / 2, BPL = C3 * C1 / 2;       // X6: floats per bf16 plane of the A / B tile
     constexpr int MH = C1 / 16;                    // MC: 16-channel halves (2 / 1)
     constexpr bool WDL = WPE >= 3;
     constexpr int Q1 = C1 / 4;                     // channel quads per pixel (8 / 4)
@@ -152,8 +183,8 @@ __global__ __launch_bounds__(256, WPE) void stem_fused_f32(StemArgs a)
     __shared__ __attribute__((aligned(16))) float in_s[PR * PROW + PROWPAD]; //  9.4 KB
     __shared__ __attribute__((aligned(16))) float w1_s[27 * C1];          //  3.4 KB
     __shared__ __attribute__((aligned(16))) float c1_s[CR * CC * C1];     // 22.5 KB
-    __shared__ __attribute__((aligned(16))) float a_s[TH * TW * C1 / (BF ? 2 : 1)];   // 16 KB (fp32, C1 = 32) ... 4 KB (bf16, C1 = 16)
-    __shared__ __attribute__((aligned(16))) float b_s[C3 * C1 / (BF ? 2 : 1)];        //  8 KB ... 1 KB
+    __shared__ __attribute__((aligned(16))) float a_s[X6 ? 3 * APL : TH * TW * C1 / (BF ? 2 : 1)];   // 16 KB (fp32, C1 = 32) ... 4 KB (bf16, C1 = 16); X6: three bf16 planes, 24 KB
+    __shared__ __attribute__((aligned(16))) float b_s[X6 ? 3 * BPL : C3 * C1 / (BF ? 2 : 1)];        //  8 KB ... 1 KB; X6: 12 KB
     __shared__ __attribute__((aligned(16))) float sb_s[4 * C1];           // s1 | b1 | s2 | b2
     __shared__ __attribute__((aligned(16))) float wd_s[WDL ? 9 * C1 : 4]; // depthwise taps [ky][kx][C1] (WDL)
 
@@ -170,6 +201,18 @@ __global__ __launch_bounds__(256, WPE) void stem_fused_f32(StemArgs a)
             const int row = tid / SL, slot = tid % SL, ch = NI == 2 ? 2 * (row & 31) + (row >> 5) : row;
             *reinterpret_cast<f4 *>(b_s + swzb<C1>(row, slot)) =
                 *reinterpret_cast<const f4 *>(reinterpret_cast<const __bf16 *>(a.wp) + ch * C1 + slot * 8);
+        }
+    } else if constexpr (X6 != 0) {
+        constexpr int SL = C1 / 8;                                        // 16-byte slots per plane row (4 / 2)
+        if (tid < C3 * SL) {                                              // 8 consecutive k of one filter row -> the three planes
+            const int row = tid / SL, slot = tid % SL;
+            const float *src = a.wp + row * C1 + slot * 8;
+            unsigned hw[4], mw[4], lw[4];
+            x6_split8(*reinterpret_cast<const f4 *>(src), *reinterpret_cast<const f4 *>(src + 4), hw, mw, lw);
+            typedef unsigned u4e __attribute__((ext_vector_type(4)));
+            *reinterpret_cast<u4e *>(b_s + swzb<C1>(row, slot)) = u4e{ hw[0], hw[1], hw[2], hw[3] };
+            *reinterpret_cast<u4e *>(b_s + BPL + swzb<C1>(row, slot)) = u4e{ mw[0], mw[1], mw[2], mw[3] };
+            *reinterpret_cast<u4e *>(b_s + 2 * BPL + swzb<C1>(row, slot)) = u4e{ lw[0], lw[1], lw[2], lw[3] };
         }
     } else
     for (int i = tid; i < C3 * Q1; i += 256) {                            // pointwise filter [C3][C1] -> swizzled B tile
@@ -368,6 +411,14 @@ __global__ __launch_bounds__(256, WPE) void stem_fused_f32(StemArgs a)
                 if (BF) {                                                 // the layer output, rounded to bf16 (RNE): 8 bytes per lane
                     const int row = cy * TW + cx + p;
                     *reinterpret_cast<bf4 *>(a_s + swzb<C1>(row, c4 >> 1) + 2 * (c4 & 1)) = bf4{ (__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w };
+                } else if constexpr (X6 != 0) {                           // exact split of the fp32 value: 8 bytes per lane and plane
+                    const int o = swzb<C1>(cy * TW + cx + p, c4 >> 1) + 2 * (c4 & 1);
+                    unsigned hw[2], mw[2], lw[2];
+                    x6_split4(v, hw, mw, lw);
+                    typedef unsigned u2e __attribute__((ext_vector_type(2)));
+                    *reinterpret_cast<u2e *>(a_s + o) = u2e{ hw[0], hw[1] };
+                    *reinterpret_cast<u2e *>(a_s + APL + o) = u2e{ mw[0], mw[1] };
+                    *reinterpret_cast<u2e *>(a_s + 2 * APL + o) = u2e{ lw[0], lw[1] };
                 } else *reinterpret_cast<f4 *>(a_s + swz<C1>(cy * TW + cx + p, c4)) = v;
             }
         }
@@ -413,6 +464,27 @@ __global__ __launch_bounds__(256, WPE) void stem_fused_f32(StemArgs a)
                 }
             }
         } else {
+        if constexpr (X6 != 0) {
+            // product list of mbn_f32_pw_x6.hip (plane of A, plane of B; 0 = h, 1 = m, 2 = l), smallest terms first
+            constexpr int pa9[9] = { 2, 2, 1, 2, 0, 1, 1, 0, 0 }, pb9[9] = { 2, 1, 2, 0, 2, 1, 0, 1, 0 };
+            constexpr int pa6[6] = { 2, 0, 1, 1, 0, 0 }, pb6[6] = { 0, 2, 1, 0, 1, 0 };
+#pragma unroll
+            for (int ks = 0; ks < C1 / 16; ks++) {
+                f4 av[3], bv[3][NI];
+#pragma unroll
+                for (int pl = 0; pl < 3; pl++) {
+                    av[pl] = *reinterpret_cast<const f4 *>(a_s + pl * APL + swzb<C1>(wave * 32 + li, 2 * ks + lh));
+#pragma unroll
+                    for (int ni = 0; ni < NI; ni++) bv[pl][ni] = *reinterpret_cast<const f4 *>(b_s + pl * BPL + swzb<C1>(ni * 32 + li, 2 * ks + lh));
+                }
+#pragma unroll
+                for (int q = 0; q < X6; q++)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ni++)
+                        acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, av[X6 == 6 ? pa6[q % 6] : pa9[q]]),
+                                                                          __builtin_bit_cast(bf8, bv[X6 == 6 ? pb6[q % 6] : pb9[q]][ni]), acc[ni], 0, 0, 0);
+            }
+        } else
 #pragma unroll
         for (int g = 0; g < KG; g++) {
             const int chunk = 2 * g + lh;
@@ -485,6 +557,8 @@ int mbn_launch_f32_stem(mbn_context *ctx, hipStream_t stream, float *out, const 
         if (bf16 && wpe_bf == 3 && g_mbn_tune.conv_variant != 2) hipLaunchKernelGGL((stem_fused_f32<32, 64, true, 3, true>), g, b, 0, stream, a);   // conv1 on the bf16 MFMA (conv_variant=2: VALU form, A/B)
         else if (bf16 && wpe_bf == 3) hipLaunchKernelGGL((stem_fused_f32<32, 64, true, 3>), g, b, 0, stream, a);
         else if (bf16) hipLaunchKernelGGL((stem_fused_f32<32, 64, true, 2>), g, b, 0, stream, a);
+        else if (g_mbn_tune.pw_emul == 6) hipLaunchKernelGGL((stem_fused_f32<32, 64, false, 2, false, 6>), g, b, 0, stream, a);   // opt-in split products in phase D
+        else if (g_mbn_tune.pw_emul == 9) hipLaunchKernelGGL((stem_fused_f32<32, 64, false, 2, false, 9>), g, b, 0, stream, a);
         else hipLaunchKernelGGL((stem_fused_f32<32, 64, false, 2>), g, b, 0, stream, a);
     } else {
         if (bf16 && g_mbn_tune.conv_variant != 2) {            // MFMA conv1 + buffer-store epilogue: 92 VGPRs, 28.6 KB of LDS: five workgroups per CU (0.1163 -> 0.1108 ms)
@@ -493,6 +567,8 @@ int mbn_launch_f32_stem(mbn_context *ctx, hipStream_t stream, float *out, const 
             hipLaunchKernelGGL((stem_fused_f32<16, 32, true, 5, true>), dim3((unsigned)g5), b, 0, stream, a);
         }
         else if (bf16) hipLaunchKernelGGL((stem_fused_f32<16, 32, true, 4>), g, b, 0, stream, a);
+        else if (g_mbn_tune.pw_emul == 6) hipLaunchKernelGGL((stem_fused_f32<16, 32, false, 4, false, 6>), g, b, 0, stream, a);
+        else if (g_mbn_tune.pw_emul == 9) hipLaunchKernelGGL((stem_fused_f32<16, 32, false, 4, false, 9>), g, b, 0, stream, a);
         else hipLaunchKernelGGL((stem_fused_f32<16, 32, false, 4>), g, b, 0, stream, a);
     }
     return MBN_OK;

@@ -502,8 +502,8 @@ const char *mbn_version(void);
  *                bf16 x bf16 partial products on v_mfma_f32_32x32x16_bf16 with the fp32 accumulator; fp32 in, fp32 out. The 3 dropped
  *                partial products of 6 are below 2^-24 of the product. Measured error against a float64 product on the network's
  *                layer shapes: equal to or smaller than the fp32 MFMA kernel's (profiles/r02/m_pw_emul.txt); layers 13-27 at
- *                batch 256: 1.41 -> 1.14 ms; with the fused blocks (mbn_dwpw_fused takes mbn_f32_dwpw2_x6.hip for Cin <= 512) the whole
- *                step 89 k -> 108-110 k images/s. Applies to pointwise calls with K % 32 == 0 and at least as many 128x128 tiles as
+ *                batch 256: 1.41 -> 1.14 ms; with the fused blocks (mbn_dwpw_fused takes mbn_f32_dwpw2_x6.hip for Cin <= 512) and the
+ *                pointwise phase of mbn_stem_fused the whole step 89 k -> 109-110 k images/s. Applies to pointwise calls with K % 32 == 0 and at least as many 128x128 tiles as
  *                CUs; everything else takes the default kernels — which form a layer takes therefore depends on the size of the call,
  *                and forward(n)[:k] == forward(k) holds bit for bit only between calls whose layers take the same forms (fused blocks
  *                and stand-alone pairs agree bit for bit under the same value). Each filter pointer gets a pre-split image (6 bytes per

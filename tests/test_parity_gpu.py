@@ -735,6 +735,42 @@ def test_fused_stem_equals_three_layers_and_oracle(pkg, orc, ctx, tmp_path, alph
     net.destroy()
 
 
+@pytest.mark.parametrize("form", [6, 9])
+@pytest.mark.parametrize("alpha,res,n", [(1.0, 224, 2), (1.0, 96, 3), (0.5, 160, 2), (0.5, 64, 3)])
+def test_fused_stem_pw_emul(pkg, orc, ctx, tmp_path, alpha, res, n, form):
+    """The fused stem under the opt-in pw_emul = 6 | 9: its pointwise phase forms the products from the exact bf16 split of the
+    depthwise output and of the filter (mbn_f32_stem.hip, X6). Against the oracle at the fp32 tolerance; at alpha = 1 (K = 32)
+    bit-identical to conv1 + depthwise + mbn_pointwise under the same pw_emul (same split, same product order); at alpha = 0.5
+    (K = 16, outside the split GEMM's envelope) the separate layers run the fp32 MFMA kernel: fp32 tolerance."""
+    hw, net = _make_net(pkg, ctx, tmp_path, alpha, res, 20, n)
+    c3 = hw.plan.layer[2].out_ch
+    imgs = np.random.default_rng(res + form).uniform(-1, 1, (n, res, res, 3)).astype(np.float32)
+    h = res // 2
+    d_in, d_a, d_b = ctx.to_device(imgs), ctx.alloc(n * h * h * c3 * 4), ctx.alloc(n * h * h * c3 * 4)
+    net.forward(d_in.ptr, d_b.ptr, n, 3)
+    ctx.sync()
+    base = d_b.download((n, h, h, c3), np.float32)
+    try:
+        assert ctx.lib.mbn_tune_set(b"pw_emul", form) == 0
+        net.forward(d_in.ptr, d_a.ptr, n, 3)                 # fused, split products
+        net.set_fuse_stem(False)
+        assert ctx.lib.mbn_tune_set(b"pw_tile", 7) == 0       # the split GEMM for the narrow layer 3 whatever the tile count
+        net.forward(d_in.ptr, d_b.ptr, n, 3)                 # conv1, dw2, pw3 as separate launches
+        ctx.sync()
+    finally:
+        ctx.lib.mbn_tune_set(b"pw_emul", 0)
+        ctx.lib.mbn_tune_set(b"pw_tile", 0)
+    fused, unfused = d_a.download((n, h, h, c3), np.float32), d_b.download((n, h, h, c3), np.float32)
+    assert not np.array_equal(fused, base), "the split form was not on the path"
+    want, _ = orc.net_forward(orc.plan_build(alpha, res, 20), hw.blob, imgs, last_layer=3, threads=orc.num_threads())
+    assert_close(fused, want, TOL_PW, "fused stem (pw_emul %d) vs oracle" % form)
+    if alpha == 1.0:
+        assert np.array_equal(fused, unfused)
+    else:
+        assert_close(fused, unfused, TOL_PW, "fused stem (pw_emul) vs separate layers")
+    net.destroy()
+
+
 def test_fused_stem_unsupported_shapes_fall_back(pkg, ctx, tmp_path):
     """Widths other than alpha = 1 (32 -> 64) and alpha = 0.5 (16 -> 32): mbn_stem_fused answers MBN_EUNSUPPORTED and the
     runner issues the 3 calls (alpha = 0.25: conv1 has 8 channels)."""
