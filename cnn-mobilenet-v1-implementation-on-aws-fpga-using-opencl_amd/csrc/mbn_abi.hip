@@ -68,6 +68,7 @@ static std::atomic<int> *tune_slot(const char *key)
     if (!strcmp(key, "pw_ring")) return &g_mbn_tune.pw_ring;
     if (!strcmp(key, "pw_splitk")) return &g_mbn_tune.pw_splitk;
     if (!strcmp(key, "pw_emul")) return &g_mbn_tune.pw_emul;
+    if (!strcmp(key, "pw_emul_static")) return &g_mbn_tune.pw_emul_static;
     if (!strcmp(key, "lit_dot")) return &g_mbn_tune.lit_dot;
     return nullptr;
 }
@@ -134,7 +135,7 @@ int mbn_shutdown(mbn_context *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     for (auto &kv : ctx->allocs) (void)hipFree((void *)kv.first);
     if (ctx->lit_ws) (void)hipFree(ctx->lit_ws);
-    for (auto &kv : ctx->emul_ws) (void)hipFree(kv.second.first);
+    for (auto &kv : ctx->emul_ws) (void)hipFree(kv.second.p);
     ctx->allocs.clear();
     for (hipEvent_t e : ctx->pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->marks) (void)hipEventDestroy(e);
@@ -276,7 +277,11 @@ int mbn_free(mbn_context *ctx, void *dptr)
         std::lock_guard<std::mutex> lk(ctx->mu);
         auto it = ctx->allocs.find((uintptr_t)dptr);
         if (it == ctx->allocs.end()) return MBN_EINVAL;   // not ours: caller-owned memory is never freed here
+        const size_t freed = it->second;
         ctx->allocs.erase(it);
+        const uintptr_t lo = (uintptr_t)dptr, hi = lo + freed;     // pre-split images of filters inside the freed buffer are stale from now on
+        for (auto &kv : ctx->emul_ws)
+            if (kv.first.first < hi && kv.first.first + kv.second.src_bytes > lo) kv.second.built = false;
     }
     (void)hipSetDevice(ctx->device);
     MBN_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -289,6 +294,7 @@ int mbn_upload(mbn_context *ctx, void *dst, const void *src, size_t bytes)
     if (!ctx || !dst || !src) return MBN_EINVAL;
     if (bytes == 0) return MBN_OK;
     MBN_SPANS(ctx, { dst, (double)bytes, "upload destination" });
+    mbn_pw_emul_invalidate(ctx, dst, bytes);
     (void)hipSetDevice(ctx->device);
     MBN_HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
     MBN_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // blocking like CL_TRUE, MobileNet.c:350
@@ -311,6 +317,7 @@ int mbn_memset(mbn_context *ctx, void *dst, int byte, size_t bytes)
     if (!ctx || !dst) return MBN_EINVAL;
     if (bytes == 0) return MBN_OK;
     MBN_SPANS(ctx, { dst, (double)bytes, "memset destination" });
+    mbn_pw_emul_invalidate(ctx, dst, bytes);
     (void)hipSetDevice(ctx->device);
     MBN_HIP_TRY(ctx, hipMemsetAsync(dst, byte, bytes, ctx->stream));
     return MBN_OK;

@@ -13,6 +13,13 @@
 
 #include "mbn.h"
 
+struct mbn_emul_img {
+    void *p = nullptr;           // the image (device)
+    size_t bytes = 0;            // its size
+    size_t src_bytes = 0;        // size of the fp32 filter it was split from (for invalidation by mbn_upload / mbn_memset / mbn_free)
+    bool built = false;          // pw_emul_static: the image holds the split of the current filter contents
+};
+
 struct mbn_context {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -32,7 +39,7 @@ struct mbn_context {
     size_t marks_used = 0;
     void *lit_ws = nullptr;                      // LITERAL pointwise on v_dot4: packed int8 filter + per-channel weight sums + flag
     size_t lit_ws_bytes = 0;
-    std::map<std::pair<uintptr_t, int>, std::pair<void *, size_t>> emul_ws;   // pw_emul: pre-split filter images, by filter pointer (mbn_f32_pw_x6.hip)
+    std::map<std::pair<uintptr_t, int>, mbn_emul_img> emul_ws;   // pw_emul: pre-split filter images, by (filter pointer, layout) (mbn_f32_pw_x6.hip)
     std::mutex mu;
     std::map<uintptr_t, size_t> allocs;          // buffers handed out by mbn_alloc: base address -> bytes (ordered: mbn_span_check
                                                  // finds the allocation that CONTAINS an interior pointer)
@@ -64,6 +71,7 @@ struct mbn_tunables {
     std::atomic<int> pw_ring{0};      // bf16 pointwise: 0 = ring kernel for K = 64, 1 = always pw_gemm, 2 = ring wherever eligible
     std::atomic<int> pw_splitk{0};    // fp32 pointwise in the few-tile regime: 0 = split-K kernel (mbn_f32_pw_splitk.hip), 1 = always pw_gemm, 2 = split-K wherever eligible
     std::atomic<int> pw_emul{0};      // fp32 pointwise on the bf16 matrix cores from exact three-way operand splits (mbn_f32_pw_x6.hip): 0 = off, 6 or 9 products
+    std::atomic<int> pw_emul_static{0}; // pw_emul: 1 = a filter's image is split once and reused until the filter is rewritten through this library
     std::atomic<int> pw_xn{0};        // pointwise GEMM: XCD groups along n (0 = by filter size, 1 = off, 2, 4)
     std::atomic<int> dwpw_variant{0}; // fused block kernel: 0 = shipped choice per shape, 1 = round-1 producer/consumer kernel, 2 = unified-wave kernel,
                                       // 3 = unified with the taps read inside the step, 100 + bits = unified with parts switched off (ablation)
@@ -108,6 +116,7 @@ int mbn_launch_f32_pw_splitk(const mbn_call &c, float *out, const float *in, con
 int mbn_launch_f32_pw_emul(const mbn_call &c, float *out, const float *in, const float *filt, long m, int cin, int op_size);
 int mbn_pw_emul_filter_image(mbn_context *ctx, hipStream_t stream, const float *filt, int n, int k, int bn, int paired,
                              const unsigned **img, unsigned *bytes);
+void mbn_pw_emul_invalidate(mbn_context *ctx, const void *dst, size_t bytes);   // caller holds no lock
 int mbn_launch_f32_dwpw2_x6(mbn_context *ctx, hipStream_t stream, float *out, const float *in, const float *wd, const float *s2,
                             const float *b2, const float *wp, const float *s3, const float *b3, int batch, int in_rows, int in_cols,
                             int out_rows, int out_cols, int cin, int cout, int stride, int pad_top, int pad_left);

@@ -290,7 +290,7 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[i], "--steps") && i + 1 < argc) steps = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--streams") && i + 1 < argc) g_streams = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--pw-emul") && i + 1 < argc) {          /* opt-in arithmetic form of the pointwise layers (mbn.h: pw_emul) */
-            if (mbn_tune_set("pw_emul", atoi(argv[++i])) != MBN_OK) { fprintf(stderr, "bad --pw-emul\n"); return 2; }
+            if (mbn_tune_set("pw_emul", atoi(argv[++i])) != MBN_OK || mbn_tune_set("pw_emul_static", 1) != MBN_OK) { fprintf(stderr, "bad --pw-emul\n"); return 2; }
         }
         else if (!strcmp(argv[i], "--warmup") && i + 1 < argc) warmup = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--literal")) literal = 1;

@@ -508,6 +508,11 @@ const char *mbn_version(void);
  *                and forward(n)[:k] == forward(k) holds bit for bit only between calls whose layers take the same forms (fused blocks
  *                and stand-alone pairs agree bit for bit under the same value). Each filter pointer gets a pre-split image (6 bytes per
  *                weight) in the context on first use (not inside a hipGraph capture: the unsplit-filter kernel is taken there).
+ *   pw_emul_static  with pw_emul: 0 = a filter's pre-split image is rewritten by every call that uses it (the filter may change between
+ *                calls like any other argument); 1 = the caller's promise that filters are only ever written through mbn_upload /
+ *                mbn_memset (or freed through mbn_free): an image is then split once and reused until one of those calls touches its
+ *                filter — 13 launches of ~5 us less per forward of the network. bench.py --pw-emul and mobilenet --pw-emul set it
+ *                (weights are uploaded once there).
  *   pw_xn        pointwise GEMM tile order: XCD groups along n (0 = by filter size, 1 = single ordering, 2, 4)
  *   dwpw_variant fused block kernel: 0 = shipped choice, 1 = round-1 producer/consumer kernels, 2 = unified-wave kernels,
  *                3 = unified fp32 with the taps read inside the step, 100 + bits = unified with parts switched off */

@@ -1303,6 +1303,39 @@ def test_f32_pointwise_emul_accuracy(pkg, orc, ctx, shape):
         _emul_reset(ctx)
 
 
+def test_f32_pointwise_emul_static_images(pkg, ctx):
+    """pw_emul_static = 1: a filter's pre-split image is built once and reused — and rebuilt after the filter was rewritten through
+    mbn_upload (the library sees its own writes). Results equal the per-call-split mode bit for bit, before and after the
+    rewrite; a second context-owned filter at another pointer is unaffected."""
+    m, k, n = 4099, 256, 256
+    rng = np.random.default_rng(5)
+    x = rng.uniform(0, 6, (m, k)).astype(np.float32)
+    f1 = rng.normal(0, 0.1, (n, k)).astype(np.float32)
+    f2 = rng.normal(0, 0.1, (n, k)).astype(np.float32)
+    d_x, d_f, d_o = ctx.to_device(x), ctx.to_device(f1), ctx.alloc(m * n * 4)
+    ext = pkg.make_ext(batch=1, act=0)
+
+    def run():
+        ctx.pointwise(d_o.ptr, d_x.ptr, d_f.ptr, m, 1, k, n, ext)
+        ctx.sync()
+        return d_o.download((m, n), np.float32)
+    try:
+        _emul_modes(ctx, 6, 11)
+        ref1 = run()                                            # per-call split
+        assert ctx.lib.mbn_tune_set(b"pw_emul_static", 1) == 0
+        assert np.array_equal(run(), ref1) and np.array_equal(run(), ref1)     # built, then reused
+        d_f.upload(f2)                                           # mbn_upload: the image of this filter is stale from here
+        got2 = run()
+        assert ctx.lib.mbn_tune_set(b"pw_emul_static", 0) == 0
+        ref2 = run()
+        assert np.array_equal(got2, ref2) and not np.array_equal(ref2, ref1)
+        want = x.astype(np.float64) @ f2.astype(np.float64).T
+        assert_close(ref2, want.astype(np.float32), TOL_PW, "after the filter was rewritten")
+    finally:
+        ctx.lib.mbn_tune_set(b"pw_emul_static", 0)
+        _emul_reset(ctx)
+
+
 def test_headline_fp32_batch256_pw_emul(pkg, orc, ctx, tmp_path):
     """The opt-in split form on the headline configuration (1.0x224 fp32, batch 256, default runner): with pw_emul = 6 the
     stand-alone pointwise layers 13-27 run on mbn_f32_pw_x6.hip; logits of four images against the oracle at the SAME bound
