@@ -114,7 +114,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) __attribute__((amdgpu_w
     const int st_c = tid & 3, st_r = tid >> 2;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int wm_u = (wave_u / WAVES_N) * WM, wn_u = (wave_u % WAVES_N) * WN;
-    const __amdgpu_buffer_rsrc_t orsrc = mbn_make_rsrc(a.out, a.fast_epi ? (unsigned)(a.m * a.n * 4L) : 0u);
+    const __amdgpu_buffer_rsrc_t orsrc = mbn_make_rsrc(a.out, (unsigned)(a.m * a.n * 4L));
 
     const float *a_src[A_LD], *b_src[B_LD];
     f4 a_reg[A_LD][2], b_reg[B_LD][2];
@@ -258,11 +258,13 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) __attribute__((amdgpu_w
                 for (int mi = 0; mi < MI; mi++)
 #pragma unroll
                     for (int r = 0; r < 16; r++) {
-                        const long row = cm0 + wm + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        const unsigned row = (unsigned)cm0 + wm + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                         float v = fmaf(acc[mi][ni][r], sc, sh);
                         if (a.act == MBN_ACT_RELU6) v = fminf(fmaxf(v, 0.f), 6.f);
                         else if (a.act == MBN_ACT_RELU) v = fmaxf(v, 0.f);
-                        if (cok && row < a.m) a.out[row * a.n + col] = v;
+                        // 32-bit offsets through the output's descriptor (the launcher keeps M * N * 4 below 4 GiB): no 64-bit
+                        // per-lane addresses live across the tile loop (they were the kernel's only spills = its scratch segment)
+                        if (cok && row < (unsigned)a.m) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), orsrc, (row * (unsigned)a.n + (unsigned)col) * 4u, 0, 0);
                     }
             }
         }
@@ -333,7 +335,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) __attribute__((amdgpu_w
     const int st_c = tid & 3, st_r = tid >> 2;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int wm_u = (wave_u / WAVES_N) * WM, wn_u = (wave_u % WAVES_N) * WN;
-    const __amdgpu_buffer_rsrc_t orsrc = mbn_make_rsrc(a.out, a.fast_epi ? (unsigned)(a.m * a.n * 4L) : 0u);
+    const __amdgpu_buffer_rsrc_t orsrc = mbn_make_rsrc(a.out, (unsigned)(a.m * a.n * 4L));
     const __amdgpu_buffer_rsrc_t brsrc = mbn_make_rsrc(a.bws, a.bws_bytes);
 
     const float *a_src[A_LD];
@@ -502,11 +504,13 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) __attribute__((amdgpu_w
                 for (int mi = 0; mi < MI; mi++)
 #pragma unroll
                     for (int r = 0; r < 16; r++) {
-                        const long row = cm0 + wm + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        const unsigned row = (unsigned)cm0 + wm + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                         float v = fmaf(acc[mi][ni][r], sc, sh);
                         if (a.act == MBN_ACT_RELU6) v = fminf(fmaxf(v, 0.f), 6.f);
                         else if (a.act == MBN_ACT_RELU) v = fmaxf(v, 0.f);
-                        if (cok && row < a.m) a.out[row * a.n + col] = v;
+                        // 32-bit offsets through the output's descriptor (the launcher keeps M * N * 4 below 4 GiB): no 64-bit
+                        // per-lane addresses live across the tile loop (they were the kernel's only spills = its scratch segment)
+                        if (cok && row < (unsigned)a.m) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), orsrc, (row * (unsigned)a.n + (unsigned)col) * 4u, 0, 0);
                     }
             }
         }
@@ -680,7 +684,8 @@ int mbn_launch_f32_pw_emul(const mbn_call &c, float *out, const float *in, const
     XArgs a;
     a.out = out; a.in = in; a.filt = filt; a.scale = c.scale; a.shift = c.shift;
     a.m = m; a.k = cin; a.n = op_size; a.act = c.act; a.mt = a.nt = 0;
-    a.fast_epi = (double)m * op_size * 4.0 < 4294967296.0 ? 1 : 0;
+    if ((double)m * op_size * 4.0 >= 4294967296.0) return MBN_EUNSUPPORTED;      // buffer stores with 32-bit offsets: the default kernels take larger outputs
+    a.fast_epi = 1;
     a.bws = nullptr; a.bws_bytes = 0;
     a.prio = (g_mbn_tune.conv_variant & 16) ? 0 : 1;          // A/B hook: conv_variant bit 4 = no raised priority over the split
     const int cus = c.ctx->num_cus;
@@ -692,7 +697,8 @@ int mbn_launch_f32_pw_emul(const mbn_call &c, float *out, const float *in, const
         // splitting it per tile, profiles/r02/m_pw_emul.txt); without a workspace (first use inside a graph capture) and for
         // narrow outputs: both operands split on the way in
         if (op_size >= 128 && (np == 6 || np == 9)) {
-            const int rc = np == 9 ? launch_np_b<9>(a, c, 11) : launch_np_b<6>(a, c, 11);
+            const int t = (g_mbn_tune.conv_variant & 32) ? 17 : 11;          // A/B hook: conv_variant bit 5 = one filter buffer
+            const int rc = np == 9 ? launch_np_b<9>(a, c, t) : launch_np_b<6>(a, c, t);
             if (rc == MBN_OK) return rc;
         }
         tile = op_size >= 128 ? 6 : 7;

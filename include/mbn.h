@@ -488,7 +488,8 @@ const char *mbn_version(void);
  *   misc         workgroups per CU of the persistent GEMM grid (1000 = one tile per workgroup); in the split-K kernel 16 / 32 =
  *                force the 16x16 / 32x32 workgroup tile
  *   pw_stage     1 = stage GEMM operands through registers instead of direct-to-LDS loads
- *   conv_variant 1 = generic conv1 kernel; 2 = bf16 fused stem with conv1 on the VALU instead of the bf16 MFMA; 8 = GEMM without the software-pipelined k-loop; 9 = GEMM with the general epilogue
+ *   conv_variant 1 = generic conv1 kernel; 2 = bf16 fused stem with conv1 on the VALU instead of the bf16 MFMA; 8 = GEMM without the software-pipelined k-loop; 9 = GEMM with the general epilogue;
+ *                16 / 32 (with pw_emul): split GEMM without the raised wave priority over the split / with one filter buffer
  *   dw_variant   depthwise: bits 0-1 = output columns per lane, bit 4 = lanes across all channels, bit 5 = bf16 with
  *                4-channel lanes, bit 7 = no raised wave priority
  *   dw_nseg      depthwise: row segments per image
