@@ -509,6 +509,9 @@ const char *mbn_version(void);
  *                and forward(n)[:k] == forward(k) holds bit for bit only between calls whose layers take the same forms (fused blocks
  *                and stand-alone pairs agree bit for bit under the same value). Each filter pointer gets a pre-split image (6 bytes per
  *                weight) in the context on first use (not inside a hipGraph capture: the unsplit-filter kernel is taken there).
+ *                Operand range: the split is exact for 2^-110 <= |x| < 2^127 (measured, profiles/r02/m_pw_emul.txt (19)); in fp32's top
+ *                binade h = bf16(x) can round to infinity, below 2^-110 the matrix cores flush the bf16 denormals of the low planes
+ *                (2e-6 relative at 2^-115). Post-ReLU6 activations and BN-folded weights are far inside.
  *   pw_emul_static  with pw_emul: 0 = a filter's pre-split image is rewritten by every call that uses it (the filter may change between
  *                calls like any other argument); 1 = the caller's promise that filters are only ever written through mbn_upload /
  *                mbn_memset (or freed through mbn_free): an image is then split once and reused until one of those calls touches its

@@ -54,7 +54,37 @@ def main():
                 e = np.abs(got - ref) / unit
                 rel = np.abs(got - ref).max() / np.abs(ref).max()
             print("%-20s %-10s %12.3f %12.4f %12.3e" % ("%d,%d,%d" % (m, k, n), name, e.max(), np.sqrt((e ** 2).mean()), rel))
+    range_probe(pkg, lib, ctx)
     ctx.close() if hasattr(ctx, "close") else None
+
+
+def range_probe(pkg, lib, ctx):
+    """Operand range of the exact split: x * 1.0 through the pw_emul = 6 kernel for x with random 24-bit significands in one binade.
+    bf16 has fp32's exponent range, but rounding up in the top binade overflows (h = inf) and the matrix cores flush bf16
+    denormals, so the l plane (2^-17 x) loses bits below 2^-110."""
+    m, k, n = 256, 64, 128
+    rng = np.random.default_rng(1)
+    lib.mbn_tune_set(b"pw_splitk", 1); lib.mbn_tune_set(b"pw_emul", 6); lib.mbn_tune_set(b"pw_tile", 11)
+    ext = pkg.make_ext(batch=1, act=0)
+    d_o = ctx.alloc(m * n * 4)
+    print("\nbinade of the operand: exactness of x * 1.0 (pw_emul 6)")
+    for e in (1, 60, 120, 126, 127, -60, -100, -110, -115, -120, -126):
+        bits = rng.integers(0, 1 << 23, (m, k), dtype=np.uint32) | (np.uint32(127 + e) << 23)
+        x = bits.view(np.float32)
+        f = np.zeros((n, k), np.float32)
+        kk = (np.arange(n) * 7) % k
+        f[np.arange(n), kk] = 1.0
+        d_x, d_f = ctx.to_device(x), ctx.to_device(f)
+        ctx.pointwise(d_o.ptr, d_x.ptr, d_f.ptr, m, 1, k, n, ext)
+        ctx.sync()
+        got, want = d_o.download((m, n), np.float32), x[:, kk]
+        bad = got.view(np.uint32) != want.view(np.uint32)
+        with np.errstate(all="ignore"):
+            rel = np.abs((got.astype(np.float64) - want.astype(np.float64)) / want.astype(np.float64))
+        print("2^%4d: exact %-5s mismatches %5d / %d  max rel err %.3e  finite %s" % (e, not bad.any(), bad.sum(), bad.size, np.nanmax(rel), np.isfinite(got).all()))
+        d_x.free(); d_f.free()
+    for key in (b"pw_splitk", b"pw_emul", b"pw_tile"):
+        lib.mbn_tune_set(key, 0)
 
 
 if __name__ == "__main__":
