@@ -29,9 +29,14 @@
 // no workspace (narrow outputs; first use inside a hipGraph capture, where nothing may be allocated).
 //
 // Measured (profiles/r02/m_pw_emul.txt, batch 256): 512 -> 512 at 14x14 0.195 ms (pw_gemm<float>) -> 0.151-0.160; the step
-// 85-88 k -> 95-102 k images/s. The matrix pipe is busy 47 % of the kernel (SQ_VALU_MFMA_BUSY_CYCLES), the clock holds
-// 2.05 GHz (GRBM_GUI_ACTIVE; 2.09 under pw_gemm<float>): the rest is the two barriers per k-tile at two waves per SIMD —
-// three 2-byte planes per operand make the 128x128 tile 74 KB of LDS, so only two workgroups fit a CU.
+// 87-89 k -> 110-114 k images/s with the fused blocks and the stem on the same form. The matrix pipe is busy 47 % of the kernel (SQ_VALU_MFMA_BUSY_CYCLES), the clock holds
+// 2.05 GHz (GRBM_GUI_ACTIVE; 2.09 under pw_gemm<float>). Three 2-byte planes per operand make the 128x128 tile 74 KB of LDS: two
+// workgroups (two waves per SIMD) per CU, and 1568 tiles on 512 slots end in a 6 %-full fourth round (7 tile times per CU against
+// 6.125). Neither the in-GEMM split nor the fragment-read latency is the gap: an all-DMA, single-barrier, software-pipelined form
+// of the loop measured 10 % faster as a kernel and slower with its separate split pass (same file, (13)); 64-row tiles and three
+// workgroups per CU do not fit the register file or lose on the 7x7 layers ((11), (14)).
+// The split is exact for 2^-110 <= |x| < 2^127 (bf16 has fp32's exponent range; h can round to infinity in the top binade, the
+// matrix cores flush the bf16 denormals of the low planes below 2^-110): (19).
 #include "mbn_internal.h"
 #include "mbn_epilogue.h"
 
