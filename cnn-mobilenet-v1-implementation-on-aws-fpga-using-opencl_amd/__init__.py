@@ -17,7 +17,9 @@ import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(PKG_DIR)
-LIB_PATH = os.path.join(PKG_DIR, "libmbn.so")
+# MBN_LAB=1 in the environment selects the lab build (every A/B variant and mbn_tune_set knob: `make lab`); tools/*.py set it,
+# bench.py and the tests run the shipped library unless the caller exports it
+LIB_PATH = os.path.join(PKG_DIR, "libmbn_lab.so" if os.environ.get("MBN_LAB") == "1" else "libmbn.so")
 HOST_LIB_PATH = os.path.join(PKG_DIR, "libmbn_host.so")
 HEADER = os.path.join(REPO_ROOT, "include", "mbn.h")
 
@@ -62,8 +64,9 @@ class Weights(C.Structure):
 
 
 def build(force: bool = False) -> None:
-    """Compile the HIP kernels for gfx950 + the C host (make; hipcc cross-compiles without a GPU)."""
-    args = ["make", "-C", PKG_DIR, "-j8"]
+    """Compile the HIP kernels for gfx950 + the C host (make; hipcc cross-compiles without a GPU): the shipped library and
+    the lab build beside it (`all lab`)."""
+    args = ["make", "-C", PKG_DIR, "-j8", "all", "lab"]
     if force:
         subprocess.check_call(["make", "-C", PKG_DIR, "clean"], stdout=subprocess.DEVNULL)
     subprocess.check_call(args, stdout=subprocess.DEVNULL)
@@ -140,6 +143,7 @@ def load():
         lib.mbn_profile_begin.argtypes = [vp, ci]
         lib.mbn_profile_end.argtypes = [vp, C.POINTER(C.c_float), ci, C.POINTER(ci)]
         lib.mbn_profile_pause.argtypes = [vp, ci]
+        lib.mbn_profile_null.argtypes = [vp, ci, vp]
         lib.mbn_mark.argtypes = [vp, vp]
         lib.mbn_dist_init.argtypes = [ci, C.POINTER(ci), C.POINTER(vp)]
         lib.mbn_dist_size.argtypes = [vp, C.POINTER(ci)]
@@ -169,6 +173,8 @@ def load():
         lib.mbn_net_fused_layers.argtypes = [vp, ci, C.POINTER(ci)]
         lib.mbn_net_set_fuse_blocks.argtypes = [vp, C.c_uint]
         lib.mbn_net_get_fuse_blocks.argtypes = [vp, C.POINTER(C.c_uint)]
+        lib.mbn_net_reset_fuse_blocks.argtypes = [vp]
+        lib.mbn_forget.argtypes = [vp, vp, C.c_size_t]
         lib.mbn_net_classify.argtypes = [vp, vp, ci, ci, vp, vp]
         lib.mbn_net_launches.argtypes = [vp, ci, ci, C.POINTER(ci), C.POINTER(ci), ci, C.POINTER(ci)]
         lib.mbn_stem_fused.argtypes = [vp] + [vp] * 11 + [ci, ci, ci, ci, vp]
@@ -324,6 +330,14 @@ class Context:
         _chk(self.lib.mbn_profile_end(self.h, ms, capacity, C.byref(n)), self.last_error())
         return [ms[i] for i in range(n.value)]
 
+    def profile_null_us(self, with_kernel: bool, n: int = 200) -> float:
+        """Median reading (microseconds) of an event pair recorded around nothing / around an empty kernel (mbn_profile_null)."""
+        self.profile_begin(n)
+        for _ in range(n):
+            _chk(self.lib.mbn_profile_null(self.h, int(with_kernel), None))
+        ms = sorted(self.profile_end(n))
+        return 1000.0 * ms[len(ms) // 2]
+
     def mark(self, stream=None):
         _chk(self.lib.mbn_mark(self.h, stream))
 
@@ -428,6 +442,9 @@ class Net:
 
     def set_fuse_blocks(self, mask):
         _chk(self.ctx.lib.mbn_net_set_fuse_blocks(self.h, int(mask)))
+
+    def reset_fuse_blocks(self):
+        _chk(self.ctx.lib.mbn_net_reset_fuse_blocks(self.h))
 
     def get_fuse_blocks(self) -> int:
         m = C.c_uint()

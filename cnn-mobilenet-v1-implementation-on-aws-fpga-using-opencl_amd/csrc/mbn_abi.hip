@@ -49,42 +49,75 @@ int span_check(mbn_context *ctx, const Span *sp, int n)
 inline double esz_in(const mbn_call &c) { return c.dtype == MBN_DT_BF16 && !(c.io_flags & MBN_IO_IN_F32) ? 2.0 : 4.0; }
 inline double esz_out(const mbn_call &c) { return c.dtype == MBN_DT_BF16 && !(c.io_flags & MBN_IO_OUT_F32) ? 2.0 : 4.0; }
 
+// Library-owned images derived from [lo, hi) (the pre-split filter images of pw_emul): taken out of the map under the lock,
+// released by the caller once the device is idle (they may be in use on any of the net runner's sub-batch streams).
+std::vector<void *> take_derived(mbn_context *ctx, uintptr_t lo, uintptr_t hi)
+{
+    std::vector<void *> gone;
+    for (auto it = ctx->emul_ws.begin(); it != ctx->emul_ws.end();) {
+        if (it->first.first < hi && it->first.first + it->second.src_bytes > lo) {
+            gone.push_back(it->second.p);
+            it = ctx->emul_ws.erase(it);
+        } else ++it;
+    }
+    return gone;
+}
+
 }   // namespace
 
 extern "C" {
 
-static std::atomic<int> *tune_slot(const char *key)
+static std::atomic<int> *tune_slot(const char *key, bool *lab_only)
 {
+    *lab_only = false;
     if (!key) return nullptr;
-    if (!strcmp(key, "dw_variant")) return &g_mbn_tune.dw_variant;
-    if (!strcmp(key, "dw_nseg")) return &g_mbn_tune.dw_nseg;
     if (!strcmp(key, "pw_tile")) return &g_mbn_tune.pw_tile;
-    if (!strcmp(key, "pw_stage")) return &g_mbn_tune.pw_stage;
-    if (!strcmp(key, "conv_variant")) return &g_mbn_tune.conv_variant;
-    if (!strcmp(key, "misc")) return &g_mbn_tune.misc;
     if (!strcmp(key, "net_stagger")) return &g_mbn_tune.net_stagger;
-    if (!strcmp(key, "dwpw_variant")) return &g_mbn_tune.dwpw_variant;
-    if (!strcmp(key, "pw_xn")) return &g_mbn_tune.pw_xn;
-    if (!strcmp(key, "pw_ring")) return &g_mbn_tune.pw_ring;
     if (!strcmp(key, "pw_splitk")) return &g_mbn_tune.pw_splitk;
     if (!strcmp(key, "pw_emul")) return &g_mbn_tune.pw_emul;
     if (!strcmp(key, "pw_emul_static")) return &g_mbn_tune.pw_emul_static;
     if (!strcmp(key, "lit_dot")) return &g_mbn_tune.lit_dot;
+    static const char *const lab_keys[] = { "dw_variant", "dw_nseg", "pw_stage", "conv_variant", "misc", "pw_ring", "pw_xn", "dwpw_variant",
+                                            "exp0", "exp1", "exp2" };
+    for (const char *k : lab_keys)
+        if (!strcmp(key, k)) *lab_only = true;
+#ifdef MBN_LAB
+    if (!strcmp(key, "dw_variant")) return &g_mbn_tune.dw_variant;
+    if (!strcmp(key, "dw_nseg")) return &g_mbn_tune.dw_nseg;
+    if (!strcmp(key, "pw_stage")) return &g_mbn_tune.pw_stage;
+    if (!strcmp(key, "conv_variant")) return &g_mbn_tune.conv_variant;
+    if (!strcmp(key, "misc")) return &g_mbn_tune.misc;
+    if (!strcmp(key, "pw_ring")) return &g_mbn_tune.pw_ring;
+    if (!strcmp(key, "pw_xn")) return &g_mbn_tune.pw_xn;
+    if (!strcmp(key, "dwpw_variant")) return &g_mbn_tune.dwpw_variant;
+    if (!strcmp(key, "exp0")) return &g_mbn_tune.exp0;
+    if (!strcmp(key, "exp1")) return &g_mbn_tune.exp1;
+    if (!strcmp(key, "exp2")) return &g_mbn_tune.exp2;
+#endif
     return nullptr;
 }
 
+int mbn_lab_build(void) { return MBN_LAB_BUILD; }
+
 int mbn_tune_set(const char *key, int value)
 {
-    std::atomic<int> *p = tune_slot(key);
-    if (!p) return MBN_ENOTFOUND;
+    bool lab_only;
+    std::atomic<int> *p = tune_slot(key, &lab_only);
+    if (!p) return lab_only ? MBN_EUNSUPPORTED : MBN_ENOTFOUND;      // a lab knob in the shipped library
     p->store(value, std::memory_order_relaxed);
     return MBN_OK;
 }
 
 int mbn_tune_get(const char *key, int *value)
 {
-    std::atomic<int> *p = tune_slot(key);
-    if (!p || !value) return p ? MBN_EINVAL : MBN_ENOTFOUND;
+    bool lab_only;
+    std::atomic<int> *p = tune_slot(key, &lab_only);
+    if (!value) return MBN_EINVAL;
+    if (!p) {
+        if (!lab_only) return MBN_ENOTFOUND;
+        *value = 0;                                                   // what the shipped library behaves like
+        return MBN_OK;
+    }
     *value = p->load(std::memory_order_relaxed);
     return MBN_OK;
 }
@@ -273,19 +306,36 @@ int mbn_free(mbn_context *ctx, void *dptr)
 {
     if (!ctx) return MBN_EINVAL;
     if (!dptr) return MBN_OK;
+    std::vector<void *> gone;
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
         auto it = ctx->allocs.find((uintptr_t)dptr);
         if (it == ctx->allocs.end()) return MBN_EINVAL;   // not ours: caller-owned memory is never freed here
         const size_t freed = it->second;
         ctx->allocs.erase(it);
-        const uintptr_t lo = (uintptr_t)dptr, hi = lo + freed;     // pre-split images of filters inside the freed buffer are stale from now on
-        for (auto &kv : ctx->emul_ws)
-            if (kv.first.first < hi && kv.first.first + kv.second.src_bytes > lo) kv.second.built = false;
+        gone = take_derived(ctx, (uintptr_t)dptr, (uintptr_t)dptr + freed);     // images of filters inside the freed buffer (they leaked)
     }
     (void)hipSetDevice(ctx->device);
-    MBN_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (!gone.empty()) MBN_HIP_TRY(ctx, hipDeviceSynchronize());
+    else MBN_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (void *p : gone) (void)hipFree(p);
     MBN_HIP_TRY(ctx, hipFree(dptr));
+    return MBN_OK;
+}
+
+int mbn_forget(mbn_context *ctx, const void *dptr, size_t bytes)
+{
+    if (!ctx) return MBN_EINVAL;
+    if (!dptr || bytes == 0) return MBN_OK;
+    std::vector<void *> gone;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        gone = take_derived(ctx, (uintptr_t)dptr, (uintptr_t)dptr + bytes);
+    }
+    if (gone.empty()) return MBN_OK;
+    (void)hipSetDevice(ctx->device);
+    MBN_HIP_TRY(ctx, hipDeviceSynchronize());
+    for (void *p : gone) (void)hipFree(p);
     return MBN_OK;
 }
 
@@ -453,6 +503,8 @@ struct Scope {   // hipEvent pair around one layer call when profiling is on (Mo
     }
 };
 
+__global__ void mbn_null_kernel() {}
+
 int resolve(mbn_context *ctx, const mbn_layer_ext *ext, mbn_call *c, int *dtype)
 {
     if (!ctx) return MBN_EINVAL;
@@ -498,6 +550,15 @@ int resolve(mbn_context *ctx, const mbn_layer_ext *ext, mbn_call *c, int *dtype)
 }   // namespace
 
 extern "C" {
+
+int mbn_profile_null(mbn_context *ctx, int with_kernel, void *stream)
+{
+    if (!ctx) return MBN_EINVAL;
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    Scope sc(ctx, s);
+    if (with_kernel) hipLaunchKernelGGL(mbn_null_kernel, dim3(1), dim3(64), 0, s);
+    return sc.finish(MBN_OK);
+}
 
 int mbn_convolute(mbn_context *ctx, void *output, const void *inp_r, const void *inp_g, const void *inp_b,
                   const void *filter_k, int rows, int cols, int filtersize, int stride, int op_size,
@@ -754,13 +815,16 @@ int mbn_dwpw_fused_bf16(mbn_context *ctx, void *out, const void *in, const void 
               { out, 2.0 * batch * out_rows * out_cols * cout, "dwpw output" }, { wd, 36.0 * cin, "dwpw depthwise filter" },
               { wp_bf16, 2.0 * cin * cout, "dwpw pointwise filter" });
     Scope sc(ctx, s);
-    if (g_mbn_tune.dwpw_variant != 1)      // unified-wave kernel (mbn_bf16_dwpw2.hip); 1 = the round-1 producer/consumer kernel (A/B hook)
-        return sc.finish(mbn_launch_bf16_dwpw2(ctx, s, out, in, (const float *)wd, (const float *)s2, (const float *)b2, wp_bf16,
-                                               (const float *)s3, (const float *)b3, batch, in_rows, in_cols, out_rows, out_cols,
-                                               cin, cout, stride, pad_top, pad_left));
-    return sc.finish(mbn_launch_bf16_dwpw(ctx, s, out, in, (const float *)wd, (const float *)s2, (const float *)b2, wp_bf16,
-                                          (const float *)s3, (const float *)b3, batch, in_rows, in_cols, out_rows, out_cols,
-                                          cin, cout, stride, pad_top, pad_left));
+#ifdef MBN_LAB
+    if (g_mbn_tune.dwpw_variant == 1)      // the round-1 producer/consumer kernel (A/B hook; mbn_bf16_dwpw.hip's kernels are lab-only)
+        return sc.finish(mbn_launch_bf16_dwpw(ctx, s, out, in, (const float *)wd, (const float *)s2, (const float *)b2, wp_bf16,
+                                              (const float *)s3, (const float *)b3, batch, in_rows, in_cols, out_rows, out_cols,
+                                              cin, cout, stride, pad_top, pad_left));
+#endif
+    // unified-wave kernel (mbn_bf16_dwpw2.hip)
+    return sc.finish(mbn_launch_bf16_dwpw2(ctx, s, out, in, (const float *)wd, (const float *)s2, (const float *)b2, wp_bf16,
+                                           (const float *)s3, (const float *)b3, batch, in_rows, in_cols, out_rows, out_cols,
+                                           cin, cout, stride, pad_top, pad_left));
 }
 
 int mbn_convert_f32_to_bf16(mbn_context *ctx, void *dst_bf16, const void *src_f32, size_t count, void *stream)

@@ -316,8 +316,10 @@ void launch2(DwPw2Args &a, hipStream_t s, int num_cus)
     const long nwg = (long)a.mt * a.nt;
     long grid = num_cus;
     if (grid > nwg) grid = nwg;
-    if (a.dbg) hipLaunchKernelGGL((dwpw2_bf16<S, BN, true>), dim3((unsigned)grid), dim3(NT), 0, s, a);
-    else hipLaunchKernelGGL((dwpw2_bf16<S, BN, false>), dim3((unsigned)grid), dim3(NT), 0, s, a);
+#ifdef MBN_LAB
+    if (a.dbg) { hipLaunchKernelGGL((dwpw2_bf16<S, BN, true>), dim3((unsigned)grid), dim3(NT), 0, s, a); return; }
+#endif
+    hipLaunchKernelGGL((dwpw2_bf16<S, BN, false>), dim3((unsigned)grid), dim3(NT), 0, s, a);
 }
 
 }   // namespace

@@ -267,7 +267,11 @@ int mbn_launch_bf16_pw_ring(const mbn_call &c, void *out, const void *in, const 
     if (nwg > 0x7fffffffL) return MBN_EUNSUPPORTED;
     long grid = c.ctx->num_cus;                            // 136 / 152 KB of LDS: one workgroup per CU
     if (grid > nwg) grid = nwg;
-    if (big) hipLaunchKernelGGL((pw_ring_bf16<256, 2>), dim3((unsigned)grid), dim3(NT), 0, c.stream, a);
-    else hipLaunchKernelGGL((pw_ring_bf16<128, 3>), dim3((unsigned)grid), dim3(NT), 0, c.stream, a);
+#ifdef MBN_LAB
+    if (big) { hipLaunchKernelGGL((pw_ring_bf16<256, 2>), dim3((unsigned)grid), dim3(NT), 0, c.stream, a); return MBN_OK; }      // pw_ring = 2 only
+#else
+    if (big) return MBN_EUNSUPPORTED;
+#endif
+    hipLaunchKernelGGL((pw_ring_bf16<128, 3>), dim3((unsigned)grid), dim3(NT), 0, c.stream, a);
     return MBN_OK;
 }

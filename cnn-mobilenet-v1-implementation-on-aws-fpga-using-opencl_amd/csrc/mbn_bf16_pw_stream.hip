@@ -1,0 +1,310 @@
+// mbn_bf16_pw_stream.hip — the 1x1 pointwise conv of the network's bf16 mode (kernel.cl:94-114 `pointwise`;
+// out = relu6(scale * (in . filt^T) + shift), in [M][K] bf16, filt [N][K] bf16, out [M][N] bf16, fp32 accumulate on
+// v_mfma_f32_32x32x16_bf16) as a GEMM whose operand stream never drains: TWO 8-wave workgroups per CU, each with a ring
+// of THREE activation slots and TWO filter slots in LDS fed by buffer_load ... lds, counted s_waitcnt vmcnt(N) in front of
+// a raw s_barrier, and the (tile, k-tile) sequence flattened across the persistent workgroup's tiles.
+//
+// Why (round 3; counters in profiles/r03/a_pmc_bf16_gemm.txt). pw_gemm<bf16> — two LDS buffers, `issue k+1 -> MFMA k ->
+// vmcnt(0) -> barrier` — left the waves parked in s_waitcnt / s_barrier for 53 % of their cycles on the 512 -> 512 layers with
+// the matrix pipe 42 % busy, the LDS 32 % busy, no bank conflicts and TA back-pressure at 2 %: every k-tile waited out a
+// full HBM round trip with one k-tile (16 KB of activations per workgroup) in flight — 0.38 of the HBM rate two rounds
+// running. Round 2's ring kernel (mbn_bf16_pw_ring.hip) had three k-tiles in flight but needed 128 KB of LDS, i.e. ONE
+// workgroup per CU: two waves per SIMD cannot cover the LDS-DMA issue, the fragment latency and the barrier, and it lost
+// from K = 256 up. This kernel keeps the tiled kernel's occupancy (2 x 8 waves = 4 waves per SIMD) AND has two activation
+// k-tiles in flight per workgroup: the activations are the operand that comes from HBM, so they get the third slot; the
+// filter (<= 2 MB, L2-resident, re-read by every m-tile) needs one k-tile of look-ahead only.
+//   LDS: 3 x 16 KB (A: 128 rows x 128 B) + 2 x 16 KB (B: 128 rows x 128 B) = 80 KB = exactly half a CU's LDS; scale/shift
+//   do not fit beside it, so a lane loads its four values per tile into registers at the head of the tile's last k-step,
+//   AHEAD of that step's LDS-DMA (waiting for them then leaves the younger DMA in flight: in-order vmcnt).
+// Step i of the flattened sequence (k-tile i lives in A slot i % 3, B slot i % 2):
+//   s_waitcnt vmcnt(N) ; s_barrier      k-tile i has landed for every wave; every wave is done reading k-tile i-1
+//   LDS-DMA  B(i+1) -> B slot (i+1)%2   (vacated by k-tile i-1), then A(i+2) -> A slot (i+2)%3 (vacated by k-tile i-1)
+//   8 MFMAs per wave on k-tile i (fragments of group g+1 requested before the MFMAs of group g)
+//   [last k-step of a tile: epilogue, 16 channel-paired 4-byte stores per lane]
+// N = what was issued after B(i): the 2 pieces of A(i+1), plus the 16 stores if step i-1 ended a tile.
+// Tile 128 x 128, waves 4 (m) x 2 (n) of 32 x 64; LDS image, source-side XOR swizzle, fragment reads, XCD-aware tile order
+// and the channel-paired epilogue are those of pw_gemm<__bf16> (mbn_f32_pw.hip), so the two kernels return the same bits.
+// Envelope: K a multiple of 64, N a multiple of 128, BN + ReLU6 epilogue, tensors < 4 GiB; everything else stays on pw_gemm.
+#include "mbn_internal.h"
+#include "mbn_epilogue.h"
+
+#include <type_traits>
+
+namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2e __attribute__((ext_vector_type(2)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf2e __attribute__((ext_vector_type(2)));
+typedef mbn_f16v f16v;
+
+constexpr int BM = 128, BN = 128, BKE = 64, BKF = 32;      // k-tile: 64 bf16 = 128-byte rows = 32 LDS words
+constexpr int NT = 512;
+constexpr int WM = 32, WN = 64, NI = 2, WAVES_N = BN / WN;
+constexpr int ASLOTS = 3, BSLOTS = 2;
+constexpr int AF = BM * BKF, BF_ = BN * BKF;               // floats per A / B slot (16 KB each)
+constexpr int LDP = 2;                                     // 16-byte pieces per lane per operand per k-tile
+constexpr int NST = 16;                                    // store instructions per lane per epilogue
+constexpr unsigned OOB = 0xF0000000u;                      // a buffer offset past every tensor in the envelope (< 3.75 GiB): the load is dropped
+
+struct StreamArgs {
+    __bf16 *out;
+    const __bf16 *in, *filt;
+    const float *scale, *shift;
+    long m;
+    int k, n, mt, nt;
+};
+
+__device__ __forceinline__ int swz(int row, int chunk) { return (row << 5) + (((chunk ^ (row >> 1)) & 7) << 2); }
+__device__ __forceinline__ int xcd_remap(int vb, int nwg)
+{
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = vb & 7;
+    return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (vb >> 3);
+}
+
+// all but the VM_LEFT youngest vector-memory operations of this wave are done, its LDS reads are done, then s_barrier
+// (asm: nothing is moved across it; __syncthreads() would drain vmcnt(0) while an LDS-DMA is pending)
+template <int VM_LEFT, bool BAR = true>
+__device__ __forceinline__ void stream_barrier()
+{
+    if (BAR) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(VM_LEFT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(VM_LEFT) : "memory");
+}
+
+__device__ __forceinline__ void dma2(__amdgpu_buffer_rsrc_t rsrc, float *slot, const unsigned (&voff)[LDP], int soff, int wave_u)
+{
+#pragma unroll
+    for (int p = 0; p < LDP; p++)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(slot + (p * (NT / 8) + wave_u * 8) * BKF),
+                                                 16, voff[p], soff, 0, 0);
+}
+
+// ABL (lab build only; 0 in the shipped kernel): ablation bits for timing — results are wrong with any of them set.
+//   1 = no LDS-DMA in the steps (the ring keeps what the prologue loaded), 2 = no fragment reads (one set read before the loop),
+//   4 = no MFMAs, 8 = no barriers (the counted waits stay), 16 = no epilogue stores
+template <int ABL>
+__global__ __launch_bounds__(NT, 4) void pw_stream_bf16(StreamArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float lds[ASLOTS * AF + BSLOTS * BF_];      // 81 920 bytes: two workgroups per CU
+    float *const Bring = lds + ASLOTS * AF;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = (wave_u / WAVES_N) * WM, wn = (wave_u % WAVES_N) * WN;
+    const int li = lane & 31, lh = lane >> 5;
+    const int nk = a.k / BKE, nwg = a.mt * a.nt;
+    if ((int)blockIdx.x >= nwg) return;
+    const int ntile = (nwg - 1 - (int)blockIdx.x) / (int)gridDim.x + 1;      // tiles of this workgroup
+
+    const __amdgpu_buffer_rsrc_t arsrc = mbn_make_rsrc(a.in, (unsigned)(a.m * a.k * 2));
+    const __amdgpu_buffer_rsrc_t brsrc = mbn_make_rsrc(a.filt, (unsigned)((long)a.n * a.k * 2));
+    const __amdgpu_buffer_rsrc_t orsrc = mbn_make_rsrc(a.out, (unsigned)(a.m * a.n * 2));
+    const __amdgpu_buffer_rsrc_t scrsrc = mbn_make_rsrc(a.scale, (unsigned)a.n * 4u);
+    const __amdgpu_buffer_rsrc_t shrsrc = mbn_make_rsrc(a.shift, (unsigned)a.n * 4u);
+
+    const int st_ch = tid & 7;
+    int fr_a[4], fr_b[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        fr_a[g] = swz(wm + li, 2 * g + lh);
+        fr_b[g] = swz(wn + li, 2 * g + lh);
+    }
+
+    // ---- issue cursors: the filter runs one k-tile ahead of the compute cursor, the activations two
+    unsigned a_vo[LDP], b_vo[LDP];
+    int a_vb = blockIdx.x, a_kt = 0, a_slot = 0;
+    int b_vb = blockIdx.x, b_kt = 0, b_slot = 0;
+    // Past the end of the workgroup's sequence the cursors keep issuing — with out-of-range offsets, which the buffer unit drops —
+    // so that EVERY step issues exactly 2 + 2 LDS-DMA operations: the counted waits are then compile-time constants, for the
+    // barriers here and for the compiler's own wait on the scale/shift loads (with conditional issue it fell back to vmcnt(0) there,
+    // i.e. drained the ring once per tile).
+    auto set_a_tile = [&](int vb) __attribute__((always_inline)) {
+        if (vb >= nwg) {
+#pragma unroll
+            for (int p = 0; p < LDP; p++) a_vo[p] = OOB;
+            return;
+        }
+        const long m0 = (long)(xcd_remap(vb, nwg) / a.nt) * BM;
+#pragma unroll
+        for (int p = 0; p < LDP; p++) {
+            const int row = (p * NT + tid) >> 3;
+            long gm = m0 + row;
+            if (gm >= a.m) gm = a.m - 1;                                 // rows past M are computed but never stored
+            a_vo[p] = ((unsigned)gm * (unsigned)a.k + (unsigned)(((st_ch ^ (row >> 1)) & 7) * 8)) * 2u;
+        }
+    };
+    auto set_b_tile = [&](int vb) __attribute__((always_inline)) {
+        if (vb >= nwg) {
+#pragma unroll
+            for (int p = 0; p < LDP; p++) b_vo[p] = OOB;
+            return;
+        }
+        const int n0 = (xcd_remap(vb, nwg) % a.nt) * BN;
+#pragma unroll
+        for (int p = 0; p < LDP; p++) {
+            const int row = (p * NT + tid) >> 3;
+            const int gn = n0 + mbn_pair_channel(row);                   // channel-paired column blocks (mbn_epilogue.h)
+            b_vo[p] = ((unsigned)gn * (unsigned)a.k + (unsigned)(((st_ch ^ (row >> 1)) & 7) * 8)) * 2u;
+        }
+    };
+    auto issue_a = [&]() __attribute__((always_inline)) {
+        dma2(arsrc, lds + a_slot * AF, a_vo, a_kt * BKE * 2, wave_u);
+        if (++a_slot == ASLOTS) a_slot = 0;
+        if (++a_kt == nk) {
+            a_kt = 0;
+            a_vb += gridDim.x;
+            set_a_tile(a_vb);
+        }
+    };
+    auto issue_b = [&]() __attribute__((always_inline)) {
+        dma2(brsrc, Bring + b_slot * BF_, b_vo, b_kt * BKE * 2, wave_u);
+        b_slot ^= 1;
+        if (++b_kt == nk) {
+            b_kt = 0;
+            b_vb += gridDim.x;
+            set_b_tile(b_vb);
+        }
+    };
+    set_a_tile(a_vb);
+    set_b_tile(b_vb);
+    // prologue: B(0), A(0), A(1) — in this order, so that "everything up to B(i)" is one counted wait from the first step on
+    issue_b();
+    issue_a();
+    issue_a();
+
+    f16v acc[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[ni][r] = 0.f;
+    int cvb = blockIdx.x, cas = 0, cbs = 0;
+    f4 fa_fix = f4{ 0.f, 0.f, 0.f, 0.f };
+    if (ABL & 2) { stream_barrier<0>(); fa_fix = *reinterpret_cast<const f4 *>(lds + fr_a[0]); }
+    bool prev_end = false;                         // step i-1 ended a tile: its 16 stores were issued after A(i+1)
+    // One step. LAST (compile time) = the tile's last k-step: scale/shift loads ahead of the DMA, epilogue behind the MFMAs. The
+    // sequence is written as tiles x (nk-1 plain steps + one LAST step) so that the scale/shift registers are defined and
+    // consumed inside one straight-line region: as loop-carried values of a single flattened loop the compiler's counter model
+    // put s_waitcnt vmcnt(0) in front of every redefinition of them, i.e. drained the ring in every step (seen in the ISA).
+    auto step = [&](auto last_tag) __attribute__((always_inline)) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        // younger than B(i) at this point: A(i+1) (issued behind B(i) in step i-1 / the prologue), then step i-1's stores
+        if (ABL & 1) stream_barrier<0, !(ABL & 8)>();
+        else if (prev_end && !(ABL & 16)) stream_barrier<LDP + NST, !(ABL & 8)>();
+        else stream_barrier<LDP, !(ABL & 8)>();
+        f2e sc, sh;
+        int n0 = 0;
+        unsigned m0 = 0;
+        if constexpr (LAST) {                                            // ahead of this step's DMA: see the header
+            const int lid = xcd_remap(cvb, nwg);
+            n0 = (lid % a.nt) * BN;
+            m0 = (unsigned)(lid / a.nt) * BM;
+            const unsigned co = (unsigned)(n0 + wn + 2 * li) * 4u;
+            sc = __builtin_bit_cast(f2e, __builtin_amdgcn_raw_buffer_load_b64(scrsrc, co, 0, 0));
+            sh = __builtin_bit_cast(f2e, __builtin_amdgcn_raw_buffer_load_b64(shrsrc, co, 0, 0));
+        }
+        if (!(ABL & 1)) {
+            issue_b();                                                   // B(i+1)
+            issue_a();                                                   // A(i+2)
+        }
+        const float *As = lds + cas * AF, *Bs = Bring + cbs * BF_;
+        if (++cas == ASLOTS) cas = 0;
+        cbs ^= 1;
+        f4 fa[2], fb[2][NI];
+        if (ABL & 2) {
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                fa[q] = fa_fix;
+#pragma unroll
+                for (int ni = 0; ni < NI; ni++) fb[q][ni] = fa_fix;
+            }
+        } else {
+        fa[0] = *reinterpret_cast<const f4 *>(As + fr_a[0]);
+#pragma unroll
+        for (int ni = 0; ni < NI; ni++) fb[0][ni] = *reinterpret_cast<const f4 *>(Bs + fr_b[0] + ni * 32 * BKF);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            if (g < 3 && !(ABL & 2)) {
+                fa[(g + 1) & 1] = *reinterpret_cast<const f4 *>(As + fr_a[g + 1]);
+#pragma unroll
+                for (int ni = 0; ni < NI; ni++) fb[(g + 1) & 1][ni] = *reinterpret_cast<const f4 *>(Bs + fr_b[g + 1] + ni * 32 * BKF);
+            }
+            if (ABL & 4) {
+                asm volatile("" ::"v"(fa[g & 1]), "v"(fb[g & 1][0]), "v"(fb[g & 1][1]));      // keep the reads alive
+            } else {
+#pragma unroll
+            for (int ni = 0; ni < NI; ni++)
+                acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, fa[g & 1]), __builtin_bit_cast(bf8, fb[g & 1][ni]),
+                                                                  acc[ni], 0, 0, 0);
+            }
+        }
+        prev_end = LAST;
+        if constexpr (LAST) {
+            // channel-paired epilogue of mbn_store_relu6_bf16_pair with the lane's scale/shift in registers; rows past M are
+            // dropped by the descriptor's range check (the whole offset goes through the VGPR then)
+            const bool inside = (long)m0 + BM <= a.m;
+            const unsigned lane_off = ((unsigned)(4 * lh) * (unsigned)a.n + (unsigned)(2 * li)) * 2u;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const unsigned ro = m0 + wm + (r & 3) + 8 * (r >> 2);
+                const float v0 = fminf(fmaxf(fmaf(acc[0][r], sc.x, sh.x), 0.f), 6.f);
+                const float v1 = fminf(fmaxf(fmaf(acc[1][r], sc.y, sh.y), 0.f), 6.f);
+                const unsigned v = __builtin_bit_cast(unsigned, bf2e{ (__bf16)v0, (__bf16)v1 });
+                const unsigned soff = (ro * (unsigned)a.n + (unsigned)(n0 + wn)) * 2u;
+                if (ABL & 16) asm volatile("" ::"v"(v));
+                else if (inside) __builtin_amdgcn_raw_buffer_store_b32(v, orsrc, lane_off, soff, 0);
+                else __builtin_amdgcn_raw_buffer_store_b32(v, orsrc, lane_off + soff, 0, 0);
+            }
+#pragma unroll
+            for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[ni][r] = 0.f;
+            cvb += gridDim.x;
+        }
+    };
+    for (int t = 0; t < ntile; t++) {
+        for (int kt = 0; kt + 1 < nk; kt++) step(std::false_type{});
+        step(std::true_type{});
+    }
+}
+
+}   // namespace
+
+// MBN_OK when launched; MBN_EUNSUPPORTED when the shape is outside this kernel's envelope (the caller uses pw_gemm).
+int mbn_launch_bf16_pw_stream(const mbn_call &c, void *out, const void *in, const void *filt, long m, int cin, int op_size)
+{
+    if (c.dtype != MBN_DT_BF16 || (c.io_flags & (MBN_IO_OUT_F32 | MBN_IO_IN_F32)) || c.act != MBN_ACT_RELU6 || !c.scale || !c.shift)
+        return MBN_EUNSUPPORTED;
+    if (cin < BKE || (cin % BKE) != 0 || op_size < BN || (op_size % BN) != 0 || m < 4 * BM) return MBN_EUNSUPPORTED;
+    if (((uintptr_t)in % 16) != 0 || ((uintptr_t)filt % 16) != 0 || ((uintptr_t)out % 4) != 0 || ((uintptr_t)c.scale % 8) != 0 ||
+        ((uintptr_t)c.shift % 8) != 0)
+        return MBN_EUNSUPPORTED;
+    if ((double)m * cin * 2 >= (double)OOB || (double)m * op_size * 2 >= 4294967296.0 || (double)op_size * cin * 2 >= (double)OOB)
+        return MBN_EUNSUPPORTED;
+    StreamArgs a;
+    a.out = (__bf16 *)out; a.in = (const __bf16 *)in; a.filt = (const __bf16 *)filt; a.scale = c.scale; a.shift = c.shift;
+    a.m = m; a.k = cin; a.n = op_size;
+    a.mt = (int)((m + BM - 1) / BM);
+    a.nt = op_size / BN;
+    const long nwg = (long)a.mt * a.nt;
+    if (nwg > 0x7fffffffL) return MBN_EUNSUPPORTED;
+    long grid = 2L * c.ctx->num_cus;                       // 80 KB of LDS: two workgroups per CU
+    if (g_mbn_tune.exp0 > 0) grid = (long)g_mbn_tune.exp0 * c.ctx->num_cus;      // lab: workgroups per CU of the persistent grid
+    if (grid > nwg) grid = nwg;
+#ifdef MBN_LAB
+    switch (g_mbn_tune.exp1) {                                 // ablations (timing only)
+    case 1: hipLaunchKernelGGL(pw_stream_bf16<1>, dim3((unsigned)grid), dim3(NT), 0, c.stream, a); return MBN_OK;
+    case 2: hipLaunchKernelGGL(pw_stream_bf16<2>, dim3((unsigned)grid), dim3(NT), 0, c.stream, a); return MBN_OK;
+    case 3: hipLaunchKernelGGL(pw_stream_bf16<3>, dim3((unsigned)grid), dim3(NT), 0, c.stream, a); return MBN_OK;
+    case 4: hipLaunchKernelGGL(pw_stream_bf16<4>, dim3((unsigned)grid), dim3(NT), 0, c.stream, a); return MBN_OK;
+    case 8: hipLaunchKernelGGL(pw_stream_bf16<8>, dim3((unsigned)grid), dim3(NT), 0, c.stream, a); return MBN_OK;
+    case 16: hipLaunchKernelGGL(pw_stream_bf16<16>, dim3((unsigned)grid), dim3(NT), 0, c.stream, a); return MBN_OK;
+    case 6: hipLaunchKernelGGL(pw_stream_bf16<6>, dim3((unsigned)grid), dim3(NT), 0, c.stream, a); return MBN_OK;
+    case 7: hipLaunchKernelGGL(pw_stream_bf16<7>, dim3((unsigned)grid), dim3(NT), 0, c.stream, a); return MBN_OK;
+    case 5: hipLaunchKernelGGL(pw_stream_bf16<5>, dim3((unsigned)grid), dim3(NT), 0, c.stream, a); return MBN_OK;
+    default: break;
+    }
+#endif
+    hipLaunchKernelGGL(pw_stream_bf16<0>, dim3((unsigned)grid), dim3(NT), 0, c.stream, a);
+    return MBN_OK;
+}

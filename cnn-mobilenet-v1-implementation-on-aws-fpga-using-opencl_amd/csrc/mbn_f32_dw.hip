@@ -336,13 +336,15 @@ int launch_dw(const mbn_call &c, DwArgs &a, int rows, int cols, int fs, int stri
         a.nseg = (rows + a.seg_rows - 1) / a.seg_rows;
         a.total = row_lanes * a.nseg;
         dim3 grid((unsigned)((a.total + 255) / 256));
-        if (stride == 1) {
-            if (tw8 == 2) hipLaunchKernelGGL((dw3x3_nhwc_bf16x8<1, 2>), grid, dim3(256), 0, c.stream, a);
-            else hipLaunchKernelGGL((dw3x3_nhwc_bf16x8<1, 1>), grid, dim3(256), 0, c.stream, a);
-        } else {
-            if (tw8 == 2) hipLaunchKernelGGL((dw3x3_nhwc_bf16x8<2, 2>), grid, dim3(256), 0, c.stream, a);
+#ifdef MBN_LAB
+        if (tw8 == 1) {
+            if (stride == 1) hipLaunchKernelGGL((dw3x3_nhwc_bf16x8<1, 1>), grid, dim3(256), 0, c.stream, a);
             else hipLaunchKernelGGL((dw3x3_nhwc_bf16x8<2, 1>), grid, dim3(256), 0, c.stream, a);
+            return MBN_OK;
         }
+#endif
+        if (stride == 1) hipLaunchKernelGGL((dw3x3_nhwc_bf16x8<1, 2>), grid, dim3(256), 0, c.stream, a);
+        else hipLaunchKernelGGL((dw3x3_nhwc_bf16x8<2, 2>), grid, dim3(256), 0, c.stream, a);
         return MBN_OK;
     }
     int tw = (var & 3) ? (var & 3) : 2;
@@ -378,13 +380,15 @@ int launch_dw(const mbn_call &c, DwArgs &a, int rows, int cols, int fs, int stri
     a.nseg = (rows + a.seg_rows - 1) / a.seg_rows;
     a.total = row_lanes * a.nseg;
     dim3 grid((unsigned)((a.total + 255) / 256));
-    if (stride == 1) {
-        if (tw == 1) hipLaunchKernelGGL((dw3x3_nhwc<1, 1, T>), grid, dim3(256), 0, c.stream, a);
-        else hipLaunchKernelGGL((dw3x3_nhwc<1, 2, T>), grid, dim3(256), 0, c.stream, a);
-    } else {
-        if (tw == 1) hipLaunchKernelGGL((dw3x3_nhwc<2, 1, T>), grid, dim3(256), 0, c.stream, a);
-        else hipLaunchKernelGGL((dw3x3_nhwc<2, 2, T>), grid, dim3(256), 0, c.stream, a);
+#ifdef MBN_LAB
+    if (tw == 1) {
+        if (stride == 1) hipLaunchKernelGGL((dw3x3_nhwc<1, 1, T>), grid, dim3(256), 0, c.stream, a);
+        else hipLaunchKernelGGL((dw3x3_nhwc<2, 1, T>), grid, dim3(256), 0, c.stream, a);
+        return MBN_OK;
     }
+#endif
+    if (stride == 1) hipLaunchKernelGGL((dw3x3_nhwc<1, 2, T>), grid, dim3(256), 0, c.stream, a);
+    else hipLaunchKernelGGL((dw3x3_nhwc<2, 2, T>), grid, dim3(256), 0, c.stream, a);
     return MBN_OK;
 }
 

@@ -358,11 +358,16 @@ void launch2(DwPw2Args &a, hipStream_t s, int num_cus, bool pre)
     const long nwg = (long)a.mt * a.nt;
     long grid = num_cus;
     if (grid > nwg) grid = nwg;
+#ifdef MBN_LAB                                                       // ablation / stamp builds and the taps-inside-the-step form: dwpw_variant
     if (a.dbg) {
         if (pre) hipLaunchKernelGGL((dwpw2_f32<S, BN, true, true>), dim3((unsigned)grid), dim3(NT), 0, s, a);
         else hipLaunchKernelGGL((dwpw2_f32<S, BN, false, true>), dim3((unsigned)grid), dim3(NT), 0, s, a);
-    } else if (pre) hipLaunchKernelGGL((dwpw2_f32<S, BN, true, false>), dim3((unsigned)grid), dim3(NT), 0, s, a);
-    else hipLaunchKernelGGL((dwpw2_f32<S, BN, false, false>), dim3((unsigned)grid), dim3(NT), 0, s, a);
+        return;
+    }
+    if (!pre) { hipLaunchKernelGGL((dwpw2_f32<S, BN, false, false>), dim3((unsigned)grid), dim3(NT), 0, s, a); return; }
+#endif
+    (void)pre;
+    hipLaunchKernelGGL((dwpw2_f32<S, BN, true, false>), dim3((unsigned)grid), dim3(NT), 0, s, a);
 }
 
 }   // namespace

@@ -511,7 +511,9 @@ void launch_cfg(PwArgs &a, hipStream_t s, int num_cus)
         else hipLaunchKernelGGL((pw_gemm<T, BM, BN, WM, WN, 1, false, false>), grid, block, 0, s, a);
     } else {
         if (glds) hipLaunchKernelGGL((pw_gemm<T, BM, BN, WM, WN, 2, true, true>), grid, block, 0, s, a);
-        else if (kfull) hipLaunchKernelGGL((pw_gemm<T, BM, BN, WM, WN, 2, true, false>), grid, block, 0, s, a);
+#ifdef MBN_LAB
+        else if (kfull) hipLaunchKernelGGL((pw_gemm<T, BM, BN, WM, WN, 2, true, false>), grid, block, 0, s, a);      // pw_stage = 1 only
+#endif
         else hipLaunchKernelGGL((pw_gemm<T, BM, BN, WM, WN, 2, false, false>), grid, block, 0, s, a);
     }
 }
@@ -541,10 +543,9 @@ int mbn_launch_f32_pointwise(const mbn_call &c, void *out, const void *in, const
         else hipLaunchKernelGGL(pw_generic<float>, grid, dim3(256), 0, c.stream, a);
         return MBN_OK;
     }
-    // bf16: the streaming ring kernel (mbn_bf16_pw_ring.hip) for K = 64, where the tiled GEMM has a single k-tile and no
-    // LDS-DMA pipeline at all (layer 5 at batch 512: 0.179 -> 0.117 ms); measured equal at K = 128 and 25-40 % SLOWER from
-    // K = 256 up (one 8-wave workgroup per CU hides the per-k-tile LDS-DMA issue cost and fragment latency worse than two
-    // 8-wave workgroups of the tiled kernel: profiles/r02/d_bf16_ring_gemm.txt). pw_ring: 1 = never, 2 = wherever eligible.
+    // bf16: the streaming kernel (mbn_bf16_pw_stream.hip: 3 activation + 2 filter LDS slots per workgroup, two workgroups per CU,
+    // counted vmcnt) wherever the shape is inside its envelope. Lab knob pw_ring: 1 = never (the tiled pw_gemm<bf16>), 2 = round 2's
+    // one-workgroup-per-CU ring kernel wherever eligible, 3 = round 2's dispatch (that ring kernel for K = 64 only), 4 = this kernel wherever eligible.
     const int ring_mode = g_mbn_tune.pw_ring;
     // opt-in: fp32 products on the bf16 matrix cores from exact operand splits (mbn_f32_pw_x6.hip; pw_emul = 6 | 9)
     if (!bf && g_mbn_tune.pw_emul != 0 && mbn_launch_f32_pw_emul(c, (float *)out, (const float *)in, (const float *)filt, m, cin, op_size) == MBN_OK)
@@ -552,14 +553,26 @@ int mbn_launch_f32_pointwise(const mbn_call &c, void *out, const void *in, const
     // fp32, few tiles (batch 1..4): K split over the waves of a 16x16-tile workgroup (mbn_f32_pw_splitk.hip)
     if (!bf && g_mbn_tune.pw_tile == 0 && mbn_launch_f32_pw_splitk(c, (float *)out, (const float *)in, (const float *)filt, m, cin, op_size) == MBN_OK)
         return MBN_OK;
-    if (bf && ring_mode != 1 && (ring_mode == 2 || cin == 64) && g_mbn_tune.pw_tile == 0 &&
+    // measured per layer at batch 512 (profiles/r03/b_bf16_stream_gemm.txt, same call, against pw_gemm<bf16>): K = 64 0.179 -> 0.116 ms,
+    // K = 128 0.080 -> 0.076, K = 256 with N = 256 0.114 -> 0.100; K = 256 with N = 512 and every K >= 512 layer 0-5 % SLOWER (there the
+    // L2 -> LDS operand stream of a 128 x 128 tile, not the look-ahead, is the limit: ablation in the same file) -> pw_gemm keeps those.
+    // pw_ring = 4 (lab): the streaming kernel wherever eligible.
+    if (bf && (ring_mode == 4 || (ring_mode == 0 && (cin <= 128 || (cin <= 256 && op_size <= 256)))) && g_mbn_tune.pw_tile == 0 &&
+        mbn_launch_bf16_pw_stream(c, out, in, filt, m, cin, op_size) == MBN_OK)
+        return MBN_OK;
+#ifdef MBN_LAB
+    if (bf && ring_mode >= 2 && (ring_mode == 2 || cin == 64) && g_mbn_tune.pw_tile == 0 &&
         mbn_launch_bf16_pw_ring(c, out, in, filt, m, cin, op_size) == MBN_OK)
         return MBN_OK;
+#endif
     // Tile choice measured per layer on MI355X in fp32 with the software-pipelined loop (tools/layer_bench.py --tune
     // pw_tile=1..8, profiles/r01/e_gemm_tile_sweep_pipelined.txt): 64x64 tiles at 4 workgroups per CU are best from
     // K = 512 up and for K = 256 with wide outputs (133 TFLOP/s = 85 % of the fp32 matrix peak on the 512 -> 512 layers),
     // 8 waves of 32x64 on a 128x128 tile win slightly for K <= 256, <128,64> in between; small grids take 64x64 too.
     int tile = g_mbn_tune.pw_tile;
+    // a forced shape this kernel does not have in this build (the value may be meant for the pw_emul kernels, which fell through to
+    // here because the layer is outside their envelope): the per-layer rule decides
+    if (!MBN_LAB_BUILD && tile != 2 && tile != 3 && tile != 5) tile = 0;
     if (tile == 0) {
         const long big_tiles = ((m + 127) / 128) * ((op_size + 63) / 64);
         if (big_tiles < 2L * c.ctx->num_cus || op_size <= 64 || m <= 16384) tile = 3;   // 7x7 layers: finer tiles balance better
@@ -574,25 +587,30 @@ int mbn_launch_f32_pointwise(const mbn_call &c, void *out, const void *in, const
             if (op_size >= 128) launch_cfg<__bf16, 64, 128, 32, 64>(a, c.stream, cus);   // 4 waves of 32x64: even NI, channel-paired 4-byte stores
             else launch_cfg<__bf16, 64, 64, 32, 32>(a, c.stream, cus);                  // narrow outputs (alpha < 1 early layers): a 128-column tile would idle
             break;
+        case 5: launch_cfg<__bf16, 128, 128, 32, 64>(a, c.stream, cus); break;
+        case 2: launch_cfg<__bf16, 128, 64, 64, 32>(a, c.stream, cus); break;
+#ifdef MBN_LAB                                                                   // shapes of the tile sweep (profiles/r02/d_bf16_ring_gemm.txt: 5 wins everywhere)
         case 1: launch_cfg<__bf16, 128, 128, 64, 64>(a, c.stream, cus); break;   // 4 waves of 64x64
         case 4: launch_cfg<__bf16, 256, 128, 64, 64>(a, c.stream, cus); break;   // 8 waves of 64x64, 96 KB
-        case 5: launch_cfg<__bf16, 128, 128, 32, 64>(a, c.stream, cus); break;
         case 7: launch_cfg<__bf16, 128, 64, 32, 32>(a, c.stream, cus); break;    // 8 waves of 32x32, 48 KB LDS: 3 WG = 24 waves per CU
         case 8: launch_cfg<__bf16, 64, 128, 32, 32>(a, c.stream, cus); break;
-        default: launch_cfg<__bf16, 128, 64, 64, 32>(a, c.stream, cus); break;
+#endif
+        default: return MBN_EUNSUPPORTED;
         }
         return MBN_OK;
     }
     switch (tile) {
-    case 1: launch_cfg<float, 128, 128, 64, 64>(a, c.stream, cus); break;   // 4 waves, 64 KB LDS, 2 WG/CU
     case 2: launch_cfg<float, 128, 64, 64, 32>(a, c.stream, cus); break;    // 4 waves, 48 KB LDS, 3 WG/CU
     case 3: launch_cfg<float, 64, 64, 32, 32>(a, c.stream, cus); break;     // 4 waves, small problems
-    case 4: launch_cfg<float, 256, 128, 64, 64>(a, c.stream, cus); break;   // 8 waves, 96 KB LDS, 1 WG/CU
     case 5: launch_cfg<float, 128, 128, 32, 64>(a, c.stream, cus); break;   // 8 waves of 32x64, 2 WG/CU
+#ifdef MBN_LAB                                                              // shapes of the tile sweep (profiles/r01/e_gemm_tile_sweep_pipelined.txt)
+    case 1: launch_cfg<float, 128, 128, 64, 64>(a, c.stream, cus); break;   // 4 waves, 64 KB LDS, 2 WG/CU
+    case 4: launch_cfg<float, 256, 128, 64, 64>(a, c.stream, cus); break;   // 8 waves, 96 KB LDS, 1 WG/CU
     case 6: launch_cfg<float, 128, 256, 64, 64>(a, c.stream, cus); break;   // 8 waves, 96 KB LDS
     case 7: launch_cfg<float, 64, 128, 32, 64>(a, c.stream, cus); break;    // 4 waves, 48 KB LDS, 3 WG/CU
     case 8: launch_cfg<float, 128, 64, 32, 64>(a, c.stream, cus); break;    // 4 waves of 32x64
-    default: return MBN_EINVAL;
+#endif
+    default: return MBN_EUNSUPPORTED;
     }
     return MBN_OK;
 }

@@ -129,7 +129,7 @@ int mbn_launch_f32_pw_splitk(const mbn_call &c, float *out, const float *in, con
     // images — so every batch of 1..4 images takes the same kernel for a given layer, and S below depends on K alone:
     // forward(n)[:k] == forward(k) stays bit-exact within 1..4 images as it is within 5 and more.
     // Rule: pw_gemm's 64x64 tiles of a 4-image call would cover less than half of the CUs.
-    if (mode != 2) {
+    if (mode != 2 && mode != 16 && mode != 32) {            // 2 / 16 / 32: wherever the shape allows (16, 32: with that workgroup tile forced — tests)
         if (c.batch < 1 || c.batch > 4 || m % c.batch) return MBN_EUNSUPPORTED;
         const long m4 = m / c.batch * 4;
         if (((m4 + 63) / 64) * ((op_size + 63) / 64) * 2 > c.ctx->num_cus) return MBN_EUNSUPPORTED;
@@ -138,7 +138,7 @@ int mbn_launch_f32_pw_splitk(const mbn_call &c, float *out, const float *in, con
     const int S = (cin >= 1024 && cin % 256 == 0) ? 16 : (cin >= 512 && cin % 128 == 0) ? 8 : 4;
     // tile: 16x16 while that gives at most ~2 workgroups per CU, 32x32 beyond (same sums; halves the L2 traffic of the
     // operand re-reads, which is what bounds the 3-4 image calls: 512 -> 512 at 4 images 18 -> 10 us)
-    const int tb = g_mbn_tune.misc == 16 ? 1 : g_mbn_tune.misc == 32 ? 2 : (((m + 15) / 16) * ((op_size + 15) / 16) > 2L * c.ctx->num_cus ? 2 : 1);
+    const int tb = mode == 16 ? 1 : mode == 32 ? 2 : (((m + 15) / 16) * ((op_size + 15) / 16) > 2L * c.ctx->num_cus ? 2 : 1);
     const long mt = (m + 16 * tb - 1) / (16 * tb), nt = (op_size + 16 * tb - 1) / (16 * tb);
     if (mt * nt > 1L << 20) return MBN_EUNSUPPORTED;
     SkArgs a;

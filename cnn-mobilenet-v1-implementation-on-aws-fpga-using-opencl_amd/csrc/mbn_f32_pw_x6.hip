@@ -554,7 +554,8 @@ template <int NP>
 int launch_np_b(XArgs &a, const mbn_call &c, int tile)
 {
     switch (tile) {
-    case 11: return launch_xb<128, 128, 64, 64, NP, 2>(a, c);     // 4 waves of 64x64, 74 KB: 2 workgroups per CU
+    case 11: return launch_xb<128, 128, 64, 64, NP, 2>(a, c);     // 4 waves of 64x64, 74 KB: 2 workgroups per CU — the one shape the dispatch takes
+#ifdef MBN_LAB                                                     // the shapes of profiles/r02/m_pw_emul.txt (10)-(18): slower, 12 of them spill
     case 12: return launch_xb<128, 64, 64, 32, NP, 3>(a, c);      // 4 waves of 64x32, 49 KB: 3 workgroups per CU
     case 13: return launch_xb<256, 128, 64, 64, NP, 2>(a, c);     // 8 waves of 64x64, 98 KB
     case 14: return launch_xb<128, 128, 32, 64, NP, 2>(a, c);     // 8 waves of 32x64, 74 KB, 1 workgroup per CU
@@ -564,7 +565,8 @@ int launch_np_b(XArgs &a, const mbn_call &c, int tile)
     case 18: return launch_xb<64, 128, 32, 64, NP, 3, 1, 1>(a, c);   // 64-row tiles (finer tail), 4 waves of 32x64, 38 KB: 3 workgroups per CU
     case 19: return launch_xb<64, 128, 32, 64, NP, 4, 1, 1>(a, c);   // the same at 4 workgroups per CU (128 VGPRs)
     case 20: return launch_xb<64, 128, 32, 64, NP, 2, 2, 2>(a, c);   // the same with two filter buffers and two A register sets, 2 per CU
-    default: return MBN_EINVAL;
+#endif
+    default: return MBN_EUNSUPPORTED;
     }
 }
 
@@ -589,16 +591,18 @@ template <int NP>
 int launch_np(XArgs &a, hipStream_t s, int num_cus, int tile)
 {
     switch (tile) {
+    case 6: launch_x<128, 128, 64, 64, NP, 1, 2>(a, s, num_cus); break;     // single buffer, 50 KB: 3 workgroups per CU — the dispatch's form without a filter image
+    case 7: launch_x<128, 64, 64, 32, NP, 1, 3>(a, s, num_cus); break;      // single buffer, 37 KB: 4 workgroups per CU — narrow outputs
+#ifdef MBN_LAB
     case 1: launch_x<128, 128, 64, 64, NP, 2, 1>(a, s, num_cus); break;     // 4 waves of 64x64, 98 KB
     case 2: launch_x<128, 64, 64, 32, NP, 2, 2>(a, s, num_cus); break;      // 4 waves of 64x32, 73 KB: 2 workgroups per CU
     case 3: launch_x<64, 64, 32, 32, NP, 2, 3>(a, s, num_cus); break;       // 4 waves of 32x32, 49 KB: 3 workgroups per CU
     case 4: launch_x<256, 128, 64, 64, NP, 2, 2>(a, s, num_cus); break;     // 8 waves of 64x64, 146 KB
     case 5: launch_x<128, 128, 32, 64, NP, 2, 2>(a, s, num_cus); break;     // 8 waves of 32x64, 98 KB
-    case 6: launch_x<128, 128, 64, 64, NP, 1, 2>(a, s, num_cus); break;     // single buffer, 50 KB: 3 workgroups per CU
-    case 7: launch_x<128, 64, 64, 32, NP, 1, 3>(a, s, num_cus); break;      // single buffer, 37 KB: 4 workgroups per CU
     case 8: launch_x<256, 128, 64, 64, NP, 1, 2>(a, s, num_cus); break;     // 8 waves, single buffer, 74 KB
     case 9: launch_x<128, 128, 64, 64, NP, 1, 3>(a, s, num_cus); break;     // single buffer, 3 workgroups per CU (168 VGPRs)
-    default: return MBN_EINVAL;
+#endif
+    default: return MBN_EUNSUPPORTED;
     }
     return MBN_OK;
 }
@@ -637,7 +641,12 @@ int mbn_pw_emul_filter_image(mbn_context *ctx, hipStream_t stream, const float *
         auto it = ctx->emul_ws.find(key);
         if (it != ctx->emul_ws.end() && it->second.bytes >= need) {
             ws = it->second.p;
-            if (is_static && it->second.built && it->second.src_bytes == (size_t)n * k * 4) {      // split once, reused (pw_emul_static)
+            // Inside a stream capture `built` is ignored and the split is always recorded as a node of the graph: a graph that baked in
+            // "already split" would keep replaying GEMMs on the old image after mbn_upload rewrote the filter (the graph's key
+            // does not change with the weights). Costs the 13 split launches per replay, in graph mode only.
+            hipStreamCaptureStatus cs0 = hipStreamCaptureStatusNone;
+            if (is_static) (void)hipStreamIsCapturing(stream, &cs0);
+            if (is_static && cs0 == hipStreamCaptureStatusNone && it->second.built && it->second.src_bytes == (size_t)n * k * 4) {      // split once, reused (pw_emul_static)
                 *img = (const unsigned *)ws;
                 *bytes = (unsigned)need;
                 return MBN_OK;
@@ -682,7 +691,11 @@ int mbn_launch_f32_pw_emul(const mbn_call &c, float *out, const float *in, const
 {
     const int np = g_mbn_tune.pw_emul;
     if (np == 0 || c.dtype != MBN_DT_F32) return MBN_EUNSUPPORTED;
-    if (np != 1 && np != 3 && np != 6 && np != 9) return MBN_EUNSUPPORTED;
+#ifdef MBN_LAB
+    if (np != 1 && np != 3 && np != 6 && np != 9) return MBN_EUNSUPPORTED;      // 3 / 1 products: only for the error table of tools/pw_emul_check.py
+#else
+    if (np != 6 && np != 9) return MBN_EUNSUPPORTED;
+#endif
     if (cin < KT || (cin % KT) != 0 || m <= 0) return MBN_EUNSUPPORTED;
     if (((uintptr_t)in % 16) || ((uintptr_t)filt % 16)) return MBN_EUNSUPPORTED;
     if ((long)((m + 63) / 64) * ((op_size + 63) / 64) > 0x7fffffffL) return MBN_EUNSUPPORTED;
@@ -716,7 +729,10 @@ int mbn_launch_f32_pw_emul(const mbn_call &c, float *out, const float *in, const
     switch (np) {
     case 9: return launch_np<9>(a, c.stream, cus, tile);
     case 6: return launch_np<6>(a, c.stream, cus, tile);
+#ifdef MBN_LAB
     case 3: return launch_np<3>(a, c.stream, cus, tile);
-    default: return launch_np<1>(a, c.stream, cus, tile);
+    case 1: return launch_np<1>(a, c.stream, cus, tile);
+#endif
+    default: return MBN_EUNSUPPORTED;
     }
 }

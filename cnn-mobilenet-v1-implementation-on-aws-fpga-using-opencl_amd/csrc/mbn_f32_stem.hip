@@ -554,19 +554,25 @@ int mbn_launch_f32_stem(mbn_context *ctx, hipStream_t stream, float *out, const 
     if (grid > (long)a.ntiles) grid = (long)a.ntiles;
     const dim3 g((unsigned)grid), b(256);
     if (c1 == 32) {
-        if (bf16 && wpe_bf == 3 && g_mbn_tune.conv_variant != 2) hipLaunchKernelGGL((stem_fused_f32<32, 64, true, 3, true>), g, b, 0, stream, a);   // conv1 on the bf16 MFMA (conv_variant=2: VALU form, A/B)
-        else if (bf16 && wpe_bf == 3) hipLaunchKernelGGL((stem_fused_f32<32, 64, true, 3>), g, b, 0, stream, a);
-        else if (bf16) hipLaunchKernelGGL((stem_fused_f32<32, 64, true, 2>), g, b, 0, stream, a);
+#ifdef MBN_LAB
+        if (bf16 && wpe_bf == 3 && g_mbn_tune.conv_variant == 2) hipLaunchKernelGGL((stem_fused_f32<32, 64, true, 3>), g, b, 0, stream, a);     // conv1 on the VALU (A/B)
+        else if (bf16 && wpe_bf != 3) hipLaunchKernelGGL((stem_fused_f32<32, 64, true, 2>), g, b, 0, stream, a);                                // two workgroups per CU (A/B)
+        else
+#endif
+        if (bf16) hipLaunchKernelGGL((stem_fused_f32<32, 64, true, 3, true>), g, b, 0, stream, a);   // conv1 on the bf16 MFMA, three workgroups per CU
         else if (g_mbn_tune.pw_emul == 6) hipLaunchKernelGGL((stem_fused_f32<32, 64, false, 2, false, 6>), g, b, 0, stream, a);   // opt-in split products in phase D
         else if (g_mbn_tune.pw_emul == 9) hipLaunchKernelGGL((stem_fused_f32<32, 64, false, 2, false, 9>), g, b, 0, stream, a);
         else hipLaunchKernelGGL((stem_fused_f32<32, 64, false, 2>), g, b, 0, stream, a);
     } else {
-        if (bf16 && g_mbn_tune.conv_variant != 2) {            // MFMA conv1 + buffer-store epilogue: 92 VGPRs, 28.6 KB of LDS: five workgroups per CU (0.1163 -> 0.1108 ms)
+#ifdef MBN_LAB
+        if (bf16 && g_mbn_tune.conv_variant == 2) hipLaunchKernelGGL((stem_fused_f32<16, 32, true, 4>), g, b, 0, stream, a);     // conv1 on the VALU (A/B)
+        else
+#endif
+        if (bf16) {            // MFMA conv1 + buffer-store epilogue: 92 VGPRs, 28.6 KB of LDS: five workgroups per CU (0.1163 -> 0.1108 ms)
             long g5 = (long)ctx->num_cus * 5;
             if (g5 > (long)a.ntiles) g5 = (long)a.ntiles;
             hipLaunchKernelGGL((stem_fused_f32<16, 32, true, 5, true>), dim3((unsigned)g5), b, 0, stream, a);
         }
-        else if (bf16) hipLaunchKernelGGL((stem_fused_f32<16, 32, true, 4>), g, b, 0, stream, a);
         else if (g_mbn_tune.pw_emul == 6) hipLaunchKernelGGL((stem_fused_f32<16, 32, false, 4, false, 6>), g, b, 0, stream, a);
         else if (g_mbn_tune.pw_emul == 9) hipLaunchKernelGGL((stem_fused_f32<16, 32, false, 4, false, 9>), g, b, 0, stream, a);
         else hipLaunchKernelGGL((stem_fused_f32<16, 32, false, 4>), g, b, 0, stream, a);

@@ -57,25 +57,41 @@ static inline int mbn_record_hip_error(mbn_context *ctx, hipError_t e, const cha
         if (_e != hipSuccess) return mbn_record_hip_error((ctx), _e, #expr);      \
     } while (0)
 
-// Process-wide tuning knobs (mbn_tune_set). 0 = shipped default everywhere.
-// Relaxed atomics: the knobs are read on every launch by whichever host thread drives a context (one thread per GPU is
-// the documented model, mbn.h) while another thread may call mbn_tune_set — no torn or racy reads, no ordering implied.
+// Process-wide switches (mbn_tune_set). 0 = shipped default everywhere.
+// Two kinds. PRODUCT switches select between code paths that every build contains (the opt-in pw_emul arithmetic, the
+// split-K and LITERAL dot4 regimes a test must be able to force, the sub-batch stagger, a forced GEMM tile among the compiled
+// ones): relaxed atomics, read once per launch on the host. LAB knobs are A/B hooks of the experiments recorded in
+// profiles/LOG.md: they exist only in the lab build (make lab -> libmbn_lab.so, -DMBN_LAB); in the shipped library they are
+// compile-time zeros, so every branch on them folds away, the template instantiations only they reach are not compiled,
+// and mbn_tune_set answers MBN_EUNSUPPORTED for their keys.
+#ifdef MBN_LAB
+#define MBN_LAB_KNOB(name) std::atomic<int> name{0}
+#define MBN_LAB_BUILD 1
+#else
+#define MBN_LAB_KNOB(name) static constexpr int name = 0
+#define MBN_LAB_BUILD 0
+#endif
 struct mbn_tunables {
-    std::atomic<int> dw_variant{0};   // depthwise kernel variant
-    std::atomic<int> dw_nseg{0};      // force row segments per image (0 = heuristic)
-    std::atomic<int> pw_tile{0};      // pointwise tile config override
-    std::atomic<int> pw_stage{0};     // 1 = register staging instead of direct-to-LDS loads
-    std::atomic<int> conv_variant{0}; // conv1 kernel variant
-    std::atomic<int> misc{0};
+    // ---- product switches
+    std::atomic<int> pw_tile{0};      // pointwise GEMM: force a tile shape (0 = per-layer rule); a shape this build does not contain -> MBN_EUNSUPPORTED
     std::atomic<int> lit_dot{0};      // LITERAL pointwise: 0 = v_dot4 path where eligible, 1 = always the scalar kernel
-    std::atomic<int> pw_ring{0};      // bf16 pointwise: 0 = ring kernel for K = 64, 1 = always pw_gemm, 2 = ring wherever eligible
     std::atomic<int> pw_splitk{0};    // fp32 pointwise in the few-tile regime: 0 = split-K kernel (mbn_f32_pw_splitk.hip), 1 = always pw_gemm, 2 = split-K wherever eligible
     std::atomic<int> pw_emul{0};      // fp32 pointwise on the bf16 matrix cores from exact three-way operand splits (mbn_f32_pw_x6.hip): 0 = off, 6 or 9 products
     std::atomic<int> pw_emul_static{0}; // pw_emul: 1 = a filter's image is split once and reused until the filter is rewritten through this library
-    std::atomic<int> pw_xn{0};        // pointwise GEMM: XCD groups along n (0 = by filter size, 1 = off, 2, 4)
-    std::atomic<int> dwpw_variant{0}; // fused block kernel: 0 = shipped choice per shape, 1 = round-1 producer/consumer kernel, 2 = unified-wave kernel,
-                                      // 3 = unified with the taps read inside the step, 100 + bits = unified with parts switched off (ablation)
     std::atomic<int> net_stagger{2};  // layers by which consecutive sub-batch streams are staggered (mbn_net_set_streams)
+    // ---- lab knobs
+    MBN_LAB_KNOB(dw_variant);         // depthwise kernel variant
+    MBN_LAB_KNOB(dw_nseg);            // force row segments per image (0 = heuristic)
+    MBN_LAB_KNOB(pw_stage);           // 1 = register staging instead of direct-to-LDS loads
+    MBN_LAB_KNOB(conv_variant);       // conv1 / stem / GEMM-epilogue variants
+    MBN_LAB_KNOB(misc);
+    MBN_LAB_KNOB(pw_ring);            // bf16 pointwise: 0 = ring kernel for K = 64, 1 = always pw_gemm, 2 = ring wherever eligible
+    MBN_LAB_KNOB(pw_xn);              // pointwise GEMM: XCD groups along n (0 = by filter size, 1 = off, 2, 4)
+    MBN_LAB_KNOB(dwpw_variant);       // fused block kernel: 0 = shipped choice per shape, 1 = round-1 producer/consumer kernel, 2 = unified-wave kernel,
+                                      // 3 = unified with the taps read inside the step, 100 + bits = unified with parts switched off (ablation)
+    MBN_LAB_KNOB(exp0);               // scratch knobs of the experiment at hand (kernel files say what they mean where they read them)
+    MBN_LAB_KNOB(exp1);
+    MBN_LAB_KNOB(exp2);
 };
 extern mbn_tunables g_mbn_tune;
 
@@ -120,7 +136,8 @@ void mbn_pw_emul_invalidate(mbn_context *ctx, const void *dst, size_t bytes);   
 int mbn_launch_f32_dwpw2_x6(mbn_context *ctx, hipStream_t stream, float *out, const float *in, const float *wd, const float *s2,
                             const float *b2, const float *wp, const float *s3, const float *b3, int batch, int in_rows, int in_cols,
                             int out_rows, int out_cols, int cin, int cout, int stride, int pad_top, int pad_left);
-int mbn_launch_bf16_pw_ring(const mbn_call &c, void *out, const void *in, const void *filt, long m, int cin, int op_size);
+int mbn_launch_bf16_pw_ring(const mbn_call &c, void *out, const void *in, const void *filt, long m, int cin, int op_size);      // lab build only
+int mbn_launch_bf16_pw_stream(const mbn_call &c, void *out, const void *in, const void *filt, long m, int cin, int op_size);
 int mbn_launch_f32_pool(const mbn_call &c, void *out, const void *in, int rows, int cols, int fs, int channels);
 // floor(v / d) == umulhi(v, *m) >> *s for every v < 2^31 (d >= 2); d == 1 gives *m = 0 (callers skip the multiply)
 static inline void mbn_udiv_magic(unsigned d, unsigned *m, unsigned *s)

@@ -38,7 +38,7 @@ struct mbn_net {
     int free_running;          /* no fork dependency on the context's stream (mbn_net_set_free_running) */
     const void *fr_images;     /* free-running: the (images, logits, batch, last_layer) of the previous forward; a call that */
     void *fr_logits;           /* differs re-inserts the fork wait, because sub-batch slices of act[] move with the batch */
-    int fr_batch, fr_last;
+    int fr_batch, fr_last, fr_ns, fr_stagger;
     int nstreams;              /* sub-batch pipelining (mbn_net_set_streams); 1 = everything on the context's stream */
     void *streams[8];
     void *bf16_filt[MBN_MAX_LAYERS];   /* bf16 copies of the pointwise / FC filters (bf16 mode) */
@@ -119,6 +119,7 @@ int mbn_net_destroy(mbn_net *net)
     if (net->act[0]) mbn_free(net->ctx, net->act[0]);
     if (net->act[1]) mbn_free(net->ctx, net->act[1]);
     if (net->own_blob && net->dev_blob) mbn_free(net->ctx, net->dev_blob);
+    else if (net->dev_blob) mbn_forget(net->ctx, net->dev_blob, (size_t)net->plan.blob_floats * sizeof(float));   /* images derived from the caller's blob */
     free(net);
     return MBN_OK;
 }
@@ -164,6 +165,7 @@ int mbn_net_set_streams(mbn_net *net, int n)
             if (rc != MBN_OK) return rc;
         }
     net->nstreams = n;
+    net->fr_images = NULL;             /* the next multi-stream forward orders itself behind the previous one's tails again */
     return MBN_OK;
 }
 
@@ -262,9 +264,20 @@ int mbn_net_set_input_u8(mbn_net *net, int enabled)
 int mbn_net_set_fuse_blocks(mbn_net *net, unsigned mask)
 {
     if (!net) return MBN_EINVAL;
-    if (fuse_mask(net) != mask) drop_graph(net);
+    /* an explicit mask also switches off the default-only rules of block_fusable (few tiles in fp32, wide blocks in bf16),
+     * so the launch list can change even when the mask's value does not */
+    if (fuse_mask(net) != mask || !net->fuse_blocks_set) drop_graph(net);
     net->fuse_blocks = mask;
     net->fuse_blocks_set = 1;
+    return MBN_OK;
+}
+
+int mbn_net_reset_fuse_blocks(mbn_net *net)
+{
+    if (!net) return MBN_EINVAL;
+    if (net->fuse_blocks_set) drop_graph(net);
+    net->fuse_blocks_set = 0;
+    net->fuse_blocks = MBN_FUSE_BLOCKS_DEFAULT;
     return MBN_OK;
 }
 
@@ -311,6 +324,7 @@ int mbn_net_set_free_running(mbn_net *net, int enabled)
 {
     if (!net) return MBN_EINVAL;
     net->free_running = enabled != 0;
+    net->fr_images = NULL;
     return MBN_OK;
 }
 
@@ -524,10 +538,11 @@ static int forward_impl(mbn_net *net, const void *images, void *logits, int batc
     int first = 0;
     /* free-running skips the fork only between IDENTICAL consecutive calls: with another batch the sub-batch slices of the
      * ping-pong buffers move, with other images/logits the caller may have queued their producer/consumer on the context's
-     * stream — both need the ordering back */
+     * stream — both need the ordering back; another stream count or stagger moves the slices too */
     const int fork = !net->free_running || net->fr_images != images || net->fr_logits != logits || net->fr_batch != batch ||
-                     net->fr_last != last_layer;
+                     net->fr_last != last_layer || net->fr_ns != ns || net->fr_stagger != stagger;
     net->fr_images = images; net->fr_logits = logits; net->fr_batch = batch; net->fr_last = last_layer;
+    net->fr_ns = ns; net->fr_stagger = stagger;
     if (fork && net->free_running)
         for (int j = 0; j < ns; j++) {                       /* the previous free-running forward's tails, on every sub-stream */
             int rc = mbn_stream_wait(net->ctx, NULL, net->streams[j]);

@@ -165,6 +165,11 @@ int  mbn_free(mbn_context *ctx, void *dptr);
 int  mbn_upload(mbn_context *ctx, void *dst_dev, const void *src_host, size_t bytes);   /* blocking, :350 */
 int  mbn_download(mbn_context *ctx, void *dst_host, const void *src_dev, size_t bytes); /* blocking, :395 */
 int  mbn_memset(mbn_context *ctx, void *dst_dev, int byte, size_t bytes);    /* async on ctx stream */
+/* Tell the library that `bytes` of device memory at `dptr` which the CALLER owns are about to be freed or were rewritten
+ * behind its back: every library-owned image derived from that range (the pre-split filter images of the opt-in pw_emul
+ * form) is released after the device has gone idle. mbn_free does the same for the buffers it hands out; mbn_net_destroy
+ * calls this for a caller-provided parameter blob. */
+int  mbn_forget(mbn_context *ctx, const void *dptr, size_t bytes);
 int  mbn_sync(mbn_context *ctx);                                             /* :390-391 */
 /* Time of the most recent layer call in milliseconds (hipEvent pair recorded around its launch on the
  * stream it ran on; waits for it). Replaces clGetEventProfilingInfo START/END (MobileNet.c:301-305). */
@@ -177,6 +182,11 @@ int  mbn_set_profiling(mbn_context *ctx, int enabled);   /* default 0: no events
 int  mbn_profile_begin(mbn_context *ctx, int capacity);
 int  mbn_profile_end(mbn_context *ctx, float *ms, int ms_capacity, int *count);
 int  mbn_profile_pause(mbn_context *ctx, int paused);   /* 1: stop recording (slots keep their order), 0: resume */
+/* Calibration of the pool: records one event pair exactly as a layer call does, around nothing (with_kernel = 0) or around
+ * an empty one-wave kernel (with_kernel = 1), on `stream` (NULL = the context's stream). What such a pair reads is what
+ * the pair itself adds to every recorded call (bench.py reports it as `event_overhead_us` and subtracts it, so that short
+ * kernels agree with a rocprofv3 kernel trace). */
+int  mbn_profile_null(mbn_context *ctx, int with_kernel, void *stream);
 /* Step markers: mbn_mark queues one timing event on `stream` (NULL = the context's stream) without synchronising;
  * mbn_marks_read waits for the last one and returns the milliseconds between consecutive marks, in order
  * (count = marks - 1), then forgets them. bench.py brackets every timed step with one mark to report the median and
@@ -431,6 +441,9 @@ int  mbn_net_fused_layers(const mbn_net *net, int last_layer, int *count);
 #define MBN_FUSE_BLOCKS_DEFAULT_BF16 0x0FFFFFFEu
 int  mbn_net_set_fuse_blocks(mbn_net *net, unsigned mask);
 int  mbn_net_get_fuse_blocks(const mbn_net *net, unsigned *mask);
+/* Back to the state before any mbn_net_set_fuse_blocks call: the measured default of the current dtype WITH its
+ * default-only rules (few-tile rule in fp32, one-column-tile rule in bf16), which an explicit mask switches off. */
+int  mbn_net_reset_fuse_blocks(mbn_net *net);
 /* The launches the next forward(batch, last_layer) issues per (sub-)batch: launch j covers n_layers[j] layers starting
  * at the 1-based layer first_layer[j] (3 = fused stem, 2 = fused block, 1 = single layer). *count = number of
  * launches; the arrays (may be NULL) receive at most `capacity` entries. */
@@ -481,10 +494,16 @@ int  mbn_shard_range(int total, int world, int rank, int *first, int *count);
 
 const char *mbn_version(void);
 
-/* Tuning hooks, process-wide: select among built kernel variants / launch heuristics for A/B measurements
- * (tools/layer_bench.py, tools/block_bench.py). 0 always means "the shipped default". Unknown key => MBN_ENOTFOUND.
- *   pw_tile      1..8: GEMM tile shape of mbn_pointwise (see mbn_f32_pw.hip); 1 also forces the 128-column tile of
- *                mbn_dwpw_fused(_bf16)
+/* Process-wide switches. 0 always means "the shipped default". Two kinds:
+ *   PRODUCT switches (every build): pw_tile, net_stagger, lit_dot, pw_splitk, pw_emul, pw_emul_static — they select between code
+ *     paths the library always contains (a regime a caller or a test wants to force, the opt-in pw_emul arithmetic).
+ *   LAB knobs (dw_variant, dw_nseg, pw_stage, conv_variant, misc, pw_ring, pw_xn, dwpw_variant, exp0..2): A/B hooks of the
+ *     experiments recorded in profiles/LOG.md. They exist in the lab build only (make lab -> libmbn_lab.so, loaded by the tools with
+ *     MBN_LAB=1); the shipped libmbn.so compiles them to zero together with every kernel instantiation only they can reach, and
+ *     mbn_tune_set answers MBN_EUNSUPPORTED for them (mbn_tune_get: 0). mbn_lab_build() tells which library this is.
+ * Unknown key => MBN_ENOTFOUND.
+ *   pw_tile      force a GEMM tile shape of mbn_pointwise (mbn_f32_pw.hip; with pw_emul: mbn_f32_pw_x6.hip); a shape the build does
+ *                not contain => MBN_EUNSUPPORTED from the call. 1 also forces the 128-column tile of mbn_dwpw_fused(_bf16)
  *   misc         workgroups per CU of the persistent GEMM grid (1000 = one tile per workgroup); in the split-K kernel 16 / 32 =
  *                force the 16x16 / 32x32 workgroup tile
  *   pw_stage     1 = stage GEMM operands through registers instead of direct-to-LDS loads
@@ -497,7 +516,8 @@ const char *mbn_version(void);
  *   lit_dot      LITERAL pointwise: 0 = v_dot4_i32_i8 path where eligible (no carry quirk, filter fits int8), 1 = scalar kernel
  *   pw_ring      bf16 pointwise: 0 = streaming ring kernel for K = 64 (shipped), 1 = always the tiled GEMM, 2 = ring wherever eligible
  *   pw_splitk    fp32 pointwise of 1..4 images in the few-tile regime: 0 = split-K kernel (mbn_f32_pw_splitk.hip), 1 = always the
- *                tiled GEMM, 2 = split-K wherever the shape allows (K >= 128, K % 64 == 0), whatever the batch
+ *                tiled GEMM, 2 = split-K wherever the shape allows (K >= 128, K % 64 == 0), whatever the batch; 16 / 32 = as 2 with
+ *                the 16x16 / 32x32 workgroup tile forced (same bits; tests)
  *   pw_emul      fp32 pointwise, OPT-IN arithmetic form (mbn_f32_pw_x6.hip): 0 = v_mfma_f32_32x32x2_f32 (default); 6 or 9 = every fp32
  *                operand split EXACTLY into three bf16 values (x = h + m + l, 24 bits kept) and the product formed from 6 (or all 9)
  *                bf16 x bf16 partial products on v_mfma_f32_32x32x16_bf16 with the fp32 accumulator; fp32 in, fp32 out. The 3 dropped
@@ -521,6 +541,7 @@ const char *mbn_version(void);
  *   dwpw_variant fused block kernel: 0 = shipped choice, 1 = round-1 producer/consumer kernels, 2 = unified-wave kernels,
  *                3 = unified fp32 with the taps read inside the step, 100 + bits = unified with parts switched off */
 int  mbn_tune_set(const char *key, int value);
+int  mbn_lab_build(void);      /* 1 = built with -DMBN_LAB (all A/B variants and knobs), 0 = the shipped library */
 int  mbn_tune_get(const char *key, int *value);
 
 #ifdef __cplusplus

@@ -1213,6 +1213,8 @@ def test_f32_pointwise_emul_split_is_exact(pkg, ctx, form, tile):
     single product x * 2^e, which the kernel must return BIT FOR BIT for x with random full 24-bit significands — once with the
     activations random (A split: h, m and l all needed) and once with the filter random (B split). Replaces the arithmetic of
     kernel.cl:94-114 for the pointwise call sites MobileNet.c:1218-2576."""
+    if tile not in (6, 7, 11) and not _lab(ctx):
+        pytest.skip("tile %d of the split GEMM is compiled into the lab build only (the dispatch takes 11, 6 and 7)" % tile)
     m, k, n = 517, 96, 200                      # ragged in m and n for every tile shape
     rng = np.random.default_rng(form * 100 + tile)
 
@@ -1540,49 +1542,79 @@ def test_dist_single_gpu_path_and_c_host_gpus_mode(pkg, ctx, tmp_path):
     assert out.returncode != 0 and "mbn_dist_init" in out.stderr
 
 
+def _lab(ctx):
+    return ctx.lib.mbn_lab_build() == 1
+
+
+def _tune_lab(ctx, key, value):
+    """mbn_tune_set of a lab knob: skips the test on the shipped library (MBN_EUNSUPPORTED there by design)."""
+    rc = ctx.lib.mbn_tune_set(key, value)
+    if rc == -8:
+        pytest.skip("lab knob %s: this is the shipped libmbn.so (run with MBN_LAB=1 for the lab build)" % key.decode())
+    assert rc == 0, rc
+
+
 @pytest.mark.parametrize("shape", [(1000, 128, 256), (512, 64, 128), (3 * 3136, 64, 128), (2 * 784 + 5, 256, 256), (50176, 512, 512),
-                                   (8 * 49 * 4, 1024, 1024), (640, 192, 384)])
-def test_bf16_pointwise_ring_kernel(pkg, orc, ctx, shape):
-    """mbn_bf16_pw_ring.hip (4-slot LDS ring, three k-tiles in flight, counted vmcnt waits): against the oracle's bf16
-    emulation, against the tiled pw_gemm<bf16> (tune pw_ring=1) and with exact small integers (operand maps, channel
-    pairing, every slot of the ring: K/64 = 1, 2, 3, 4, 8, 16 k-tiles per tile; ragged last row tile; several tiles per
-    workgroup so the flattened sequence crosses tile boundaries)."""
+                                   (8 * 49 * 4, 1024, 1024), (640, 192, 384), (100352, 512, 512), (25088, 512, 1024), (70001, 320, 640)])
+def test_bf16_pointwise_stream_kernel(pkg, orc, ctx, shape):
+    """mbn_bf16_pw_stream.hip (three activation + two filter LDS slots per workgroup, two workgroups per CU, counted vmcnt waits,
+    flattened (tile, k-tile) sequence, out-of-range dummy DMA past the end): the default bf16 pointwise kernel for K % 64 == 0,
+    N % 128 == 0. Against the oracle's bf16 emulation, and with exact small integers through an asymmetric filter and identity
+    BN (operand maps, channel pairing, every slot of both rings: K/64 = 1, 2, 3, 4, 5, 8, 16 k-tiles per tile; ragged last row
+    tile; one to seven tiles per workgroup so the sequence crosses tile boundaries and ends on every slot phase). With the lab
+    build also bit for bit against the tiled pw_gemm<bf16> (pw_ring = 1) and round 2's ring kernel (pw_ring = 2): all three add
+    the same 64-wide k-groups of exact bf16 products in the same order."""
     m, cin, cout = shape
     rng = np.random.default_rng(m + cin + cout)
     x = orc.bf16_round(rng.uniform(-1, 1, (m, cin)))
     f = orc.bf16_round(rng.normal(0, (2.0 / cin) ** 0.5, (cout, cin)))
     sc, sh = rng.uniform(0.5, 1.5, cout).astype(np.float32), rng.normal(0, 0.1, cout).astype(np.float32)
     d_x, d_f, d_sc, d_sh = _bf16_dev(pkg, ctx, x), _bf16_dev(pkg, ctx, f), ctx.to_device(sc), ctx.to_device(sh)
-    d_o, d_p = ctx.alloc(m * cout * 2), ctx.alloc(m * cout * 2)
+    d_o, d_p = ctx.alloc(m * cout * 2 + 64), ctx.alloc(m * cout * 2)
     ext = pkg.make_ext(dtype=pkg.DT_BF16, act=2, scale=d_sc.ptr, shift=d_sh.ptr)
-    try:
-        assert ctx.lib.mbn_tune_set(b"pw_ring", 2) == 0            # the ring kernel wherever the shape is eligible
-        ctx.pointwise(d_o.ptr, d_x.ptr, d_f.ptr, m, 1, cin, cout, ext)
-        assert ctx.lib.mbn_tune_set(b"pw_ring", 1) == 0            # never
-        ctx.pointwise(d_p.ptr, d_x.ptr, d_f.ptr, m, 1, cin, cout, ext)
-        assert ctx.lib.mbn_tune_set(b"pw_ring", 2) == 0
-    finally:
-        pass
+    ctx.lib.mbn_memset(ctx.h, d_o.ptr, 0xFF, m * cout * 2 + 64)
+    if _lab(ctx):
+        assert ctx.lib.mbn_tune_set(b"pw_ring", 4) == 0      # the streaming kernel on every eligible shape, not only where the dispatch takes it
+    ctx.pointwise(d_o.ptr, d_x.ptr, d_f.ptr, m, 1, cin, cout, ext)
     ctx.sync()
-    got, tiled = _bf16_get(pkg, d_o, (m, cout)), _bf16_get(pkg, d_p, (m, cout))
+    raw = d_o.download((m * cout + 32,), np.uint16)
+    assert np.all(raw[m * cout:] == 0xFFFF), "stores past the output"
+    got = _bf16_get(pkg, d_o, (m, cout))
     if m * cin * cout <= 2e9:
         ref = orc.bf16_round(orc.f32_pointwise(x, f, sc, sh, 2))
-        assert_close(got, ref, TOL_BF16, "ring %s vs oracle" % (shape,))
-    # both kernels add the same 64-wide k-groups of exact bf16 products in the same order: identical bits expected
-    assert np.array_equal(got, tiled), "ring vs tiled GEMM %s: max diff %g" % (shape, np.abs(got - tiled).max())
+        assert_close(got, ref, TOL_BF16, "stream %s vs oracle" % (shape,))
+    else:                                                    # headline-size shapes: the oracle on rows spread over the matrix
+        rows = np.unique(np.concatenate([np.arange(0, 256), np.arange(m - 300, m), rng.integers(0, m, 2000)]))
+        ref = orc.bf16_round(orc.f32_pointwise(x[rows], f, sc, sh, 2))
+        assert_close(got[rows], ref, TOL_BF16, "stream %s vs oracle (sampled rows)" % (shape,))
+    ctx.pointwise(d_o.ptr, d_x.ptr, d_f.ptr, m, 1, cin, cout, ext)
+    ctx.sync()
+    assert np.array_equal(got, _bf16_get(pkg, d_o, (m, cout))), "not repeatable"
+    if _lab(ctx):
+        try:
+            for mode in (1, 2):
+                assert ctx.lib.mbn_tune_set(b"pw_ring", mode) == 0
+                ctx.pointwise(d_p.ptr, d_x.ptr, d_f.ptr, m, 1, cin, cout, ext)
+                ctx.sync()
+                other = _bf16_get(pkg, d_p, (m, cout))
+                assert np.array_equal(got, other), "stream vs pw_ring=%d %s: max diff %g" % (mode, shape, np.abs(got - other).max())
+        finally:
+            ctx.lib.mbn_tune_set(b"pw_ring", 4)
     # exact integers with an asymmetric filter and identity BN: any slot / operand / channel-pair mix-up shows
     xi = rng.integers(-3, 4, (m, cin)).astype(np.float32)
     fi = rng.integers(-2, 3, (cout, cin)).astype(np.float32)
     fi[:, 0] = np.arange(cout) % 5
     one, zero = ctx.to_device(np.ones(cout, np.float32)), ctx.to_device(np.zeros(cout, np.float32))
     d_x.upload(pkg.f32_to_bf16_bits(xi)); d_f.upload(pkg.f32_to_bf16_bits(fi))
-    try:
-        ctx.pointwise(d_o.ptr, d_x.ptr, d_f.ptr, m, 1, cin, cout, pkg.make_ext(dtype=pkg.DT_BF16, act=2, scale=one.ptr, shift=zero.ptr))
-    finally:
-        ctx.lib.mbn_tune_set(b"pw_ring", 0)
+    ctx.pointwise(d_o.ptr, d_x.ptr, d_f.ptr, m, 1, cin, cout, pkg.make_ext(dtype=pkg.DT_BF16, act=2, scale=one.ptr, shift=zero.ptr))
     ctx.sync()
-    want = np.clip(xi[:4096].astype(np.float64) @ fi.astype(np.float64).T, 0, 6)
-    assert np.array_equal(_bf16_get(pkg, d_o, (m, cout))[:4096].astype(np.float64), orc.bf16_round(want.astype(np.float32)).astype(np.float64))
+    goti = _bf16_get(pkg, d_o, (m, cout))
+    for lo in (0, max(0, m - 4096)):                         # the first and the last rows (the tail of every workgroup's sequence)
+        want = np.clip(xi[lo:lo + 4096].astype(np.float64) @ fi.astype(np.float64).T, 0, 6)
+        assert np.array_equal(goti[lo:lo + 4096].astype(np.float64), orc.bf16_round(want.astype(np.float32)).astype(np.float64))
+    ctx.lib.mbn_tune_set(b"pw_ring", 0)
+    for b in (d_x, d_f, d_sc, d_sh, d_o, d_p, one, zero):
+        b.free()
 
 
 @pytest.mark.parametrize("shape", [(196, 512, 512, 1), (49, 1024, 1024, 1), (4 * 196, 256, 512, 4), (3 * 49 , 512, 1024, 3), (1, 1024, 1000, 1),
@@ -1613,11 +1645,10 @@ def test_f32_pointwise_splitk_kernel(pkg, orc, ctx, shape):
         ctx.sync()
         assert np.array_equal(got, d_o.download(want.shape, np.float32)), "not repeatable"
         for tw in (16, 32):                                        # both workgroup tiles: same split, same k map -> same bits
-            assert ctx.lib.mbn_tune_set(b"misc", tw) == 0
+            assert ctx.lib.mbn_tune_set(b"pw_splitk", tw) == 0
             ctx.pointwise(d_p.ptr, d_x.ptr, d_f.ptr, m // batch, 1, cin, cout, ext)
             ctx.sync()
             assert np.array_equal(got, d_p.download(want.shape, np.float32)), "tile %d differs" % tw
-        assert ctx.lib.mbn_tune_set(b"misc", 0) == 0
         assert ctx.lib.mbn_tune_set(b"pw_splitk", 1) == 0          # never
         ctx.pointwise(d_p.ptr, d_x.ptr, d_f.ptr, m // batch, 1, cin, cout, ext)
         ctx.sync()
@@ -1645,13 +1676,12 @@ def test_f32_pointwise_splitk_kernel(pkg, orc, ctx, shape):
         wi = xi.astype(np.float64) @ fi.astype(np.float64).T + bias
         assert np.array_equal(d_o.download(want.shape, np.float32).astype(np.float64), wi)
         for tw in (16, 32):
-            assert ctx.lib.mbn_tune_set(b"misc", tw) == 0
+            assert ctx.lib.mbn_tune_set(b"pw_splitk", tw) == 0          # wherever eligible, with the 16x16 / 32x32 workgroup tile forced
             ctx.pointwise(d_o.ptr, d_x.ptr, d_f.ptr, m // batch, 1, cin, cout, pkg.make_ext(batch=batch, act=0, shift=d_sh.ptr))
             ctx.sync()
             assert np.array_equal(d_o.download(want.shape, np.float32).astype(np.float64), wi), "tile %d" % tw
     finally:
         ctx.lib.mbn_tune_set(b"pw_splitk", 0)
-        ctx.lib.mbn_tune_set(b"misc", 0)
     for b in (d_x, d_f, d_sc, d_sh, d_o, d_p):
         b.free()
 
@@ -1765,6 +1795,87 @@ def test_net_graph_under_pw_emul(pkg, ctx, tmp_path):
     finally:
         ctx.lib.mbn_tune_set(b"pw_emul", 0)
         net.destroy()
+
+
+def test_net_graph_pw_emul_static_follows_weight_upload(pkg, ctx, tmp_path):
+    """hipGraph + pw_emul 6 + pw_emul_static 1, then new weights through mbn_upload. The eager pass before
+    the capture marks every filter image 'built'; a capture that baked that in would replay GEMMs on the old images for ever
+    (the graph key does not change with the weights). Inside a capture the split is now always recorded as a graph node:
+    replayed logits after the upload == eager logits with the new weights, bit for bit, and differ from the old ones."""
+    n = 64                                                      # layer 15 at 64 images: 392 tiles of 128 x 128, on the split GEMM
+    hw, net = _make_net(pkg, ctx, tmp_path, 1.0, 224, 1000, n)
+    imgs = _headline_images(n, 224, 78)
+    d_in, d_out = ctx.to_device(imgs), ctx.alloc(n * 1000 * 4)
+
+    def fwd():
+        net.forward(d_in.ptr, d_out.ptr, n)
+        ctx.sync()
+        return d_out.download((n, 1000), np.float32)
+    try:
+        assert ctx.lib.mbn_tune_set(b"pw_emul", 6) == 0
+        assert ctx.lib.mbn_tune_set(b"pw_emul_static", 1) == 0
+        net.set_graph(True)
+        old = fwd()
+        assert np.array_equal(fwd(), old)
+        blob2 = hw.blob.copy()
+        for li in (6, 14):                                      # pointwise filters of layer 7 (inside fused block 6-7) and layer 15 (stand-alone)
+            l = hw.plan.layer[li]
+            blob2[l.w_offset:l.w_offset + l.w_count] *= np.float32(0.5)
+        net._dev_blob.upload(blob2)                             # mbn_upload: same pointers, new contents
+        replay = fwd()
+        net.set_graph(False)
+        eager = fwd()
+        assert np.array_equal(replay, eager), "the graph replayed the pre-upload filter images"
+        assert not np.array_equal(replay, old)
+    finally:
+        ctx.lib.mbn_tune_set(b"pw_emul", 0)
+        ctx.lib.mbn_tune_set(b"pw_emul_static", 0)
+        net.destroy()
+
+
+def test_net_reset_fuse_blocks_and_stream_change_between_free_running_forwards(pkg, ctx, tmp_path):
+    """(1) set(get()) makes the mask explicit, which switches the few-tile rule off — the launch list changes and
+    mbn_net_reset_fuse_blocks brings the default rules back; (2) changing the stream count between two otherwise identical
+    free-running forwards re-inserts the fork (the sub-batch slices move): logits stay bit-identical to the single-stream ones."""
+    n = 24
+    hw, net = _make_net(pkg, ctx, tmp_path, 1.0, 224, 1000, n)
+    imgs = _headline_images(n, 224, 79)
+    d_in, d_out = ctx.to_device(imgs), ctx.alloc(n * 1000 * 4)
+    default_launches = net.launches(4)
+    net.set_fuse_blocks(net.get_fuse_blocks())
+    assert net.launches(4) != default_launches                  # explicit mask: blocks fused even at 4 images
+    net.reset_fuse_blocks()
+    assert net.launches(4) == default_launches
+
+    def fwd():
+        net.forward(d_in.ptr, d_out.ptr, n)
+        ctx.sync()
+        return d_out.download((n, 1000), np.float32)
+    base = fwd()
+    for ns in (2, 4, 3, 2):
+        net.set_streams(ns, free_running=True)
+        assert np.array_equal(fwd(), base) and np.array_equal(fwd(), base), ns
+    net.destroy()
+
+
+def test_bench_multi_rank_branch_on_one_gpu(pkg):
+    """bench.py's N > 1 branch (it referenced an undefined name) run for real: two ranks on gloo sharing
+    this box's one GPU. The line must carry n_gpus = 2, the whole-job value, and a passing parity_check of rank 0's shard."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29617", os.path.join(pkg.REPO_ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo",
+           "--device-override", "0", "--steps", "5", "--warmup", "1", "--batch", "16", "--alpha", "0.5", "--res", "96"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 32 and out["value"] > 0
+    assert out["parity_check"]["ok"] and out["parity_check"]["images"] == 8
+    assert "cpu_baseline" not in out and "configs_alt" not in out
+    assert out["profiled_steps"] == 5 and out["event_overhead_us"]["empty_pair"] >= 0
 
 
 def test_graft_entry_smoke_runs():

@@ -4,6 +4,7 @@
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("MBN_LAB", "1")      # the lab build: every A/B variant and mbn_tune_set knob (make lab)
 sys.path.insert(0, ROOT)
 from mbn_amd import import_package
 pkg = import_package(); lib = pkg.load(); ctx = pkg.Context(0)

@@ -12,6 +12,7 @@ import sys
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("MBN_LAB", "1")      # the lab build: every A/B variant and mbn_tune_set knob (make lab)
 sys.path.insert(0, ROOT)
 from mbn_amd import import_package  # noqa: E402
 

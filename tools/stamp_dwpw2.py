@@ -5,6 +5,7 @@ E = epilogue (only where a tile ended). usage: stamp_dwpw2.py [--block 6] [--bat
 import argparse, ctypes as C, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("MBN_LAB", "1")      # the lab build: every A/B variant and mbn_tune_set knob (make lab)
 sys.path.insert(0, ROOT)
 from mbn_amd import import_package
 ap = argparse.ArgumentParser(); ap.add_argument("--block", type=int, default=6); ap.add_argument("--batch", type=int, default=256)

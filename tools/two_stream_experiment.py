@@ -11,6 +11,7 @@ if os.environ.get("WITH_TORCH"):
     import torch  # noqa: F401  (loads torch's bundled HIP runtime first)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("MBN_LAB", "1")      # the lab build: every A/B variant and mbn_tune_set knob (make lab)
 sys.path.insert(0, ROOT)
 from mbn_amd import import_package  # noqa: E402
 
