@@ -26,7 +26,7 @@ HEADER = os.path.join(REPO_ROOT, "include", "mbn.h")
 OK, EINVAL, ENOMEM, EDEVICE, EIO, EFORMAT, ENOTFOUND, ESHAPE, EUNSUPPORTED, ENODEVICE = 0, -1, -2, -3, -4, -5, -6, -7, -8, -9
 DT_U8, DT_F32, DT_BF16 = 0, 1, 2
 LAYOUT_NCHW_PLANAR, LAYOUT_NHWC = 0, 1
-IO_IN_F32, IO_OUT_F32, IO_IN_U8 = 1, 2, 4
+IO_IN_F32, IO_OUT_F32, IO_IN_U8, IO_FILT_PACKED = 1, 2, 4, 8
 ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
 Q_CARRY_SUM, Q_DW_PLANE0, Q_LITERAL_INDEX, Q_POOL_DIV49 = 1, 2, 4, 8
 QUIRKS_NONE, QUIRKS_KERNEL_CL = 0, 0xF
@@ -162,6 +162,9 @@ def load():
         lib.mbn_softmax_f32.argtypes = [vp, vp, vp, vp, ci, ci, vp]
         lib.mbn_normalize_u8_to_f32.argtypes = [vp, vp, vp, C.c_size_t, C.c_float, C.c_float, vp]
         lib.mbn_convert_f32_to_bf16.argtypes = [vp, vp, vp, C.c_size_t, vp]
+        lib.mbn_packed_filter_offset.restype = C.c_size_t
+        lib.mbn_packed_filter_offset.argtypes = [ci, ci]
+        lib.mbn_pack_filter_bf16.argtypes = [vp, vp, ci, ci, vp]
         lib.mbn_convert_bf16_to_f32.argtypes = [vp, vp, vp, C.c_size_t, vp]
         lib.mbn_net_set_dtype.argtypes = [vp, ci]
         lib.mbn_tune_set.argtypes = [C.c_char_p, ci]
@@ -254,6 +257,20 @@ def f32_to_bf16_bits(x: np.ndarray) -> np.ndarray:
     """float32 -> bf16 bit patterns, round to nearest even (host-side helper for tests)."""
     u = np.ascontiguousarray(x, np.float32).view(np.uint32).astype(np.uint64)
     return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+
+
+def packed_filter_dev(ctx, filt_f32: np.ndarray):
+    """Device buffer holding a bf16 pointwise filter [cout][cin] followed by its packed image (mbn_pack_filter_bf16), for calls with
+    IO_FILT_PACKED; when the shape has no packed form the buffer holds the plain filter only. Returns (buffer, io_flag)."""
+    cout, cin = filt_f32.shape
+    off = ctx.lib.mbn_packed_filter_offset(cout, cin)
+    bits = f32_to_bf16_bits(filt_f32)
+    buf = ctx.alloc(off + bits.nbytes if off else bits.nbytes)
+    buf.upload(bits)
+    if off:
+        _chk(ctx.lib.mbn_pack_filter_bf16(ctx.h, buf.ptr, cout, cin, None), ctx.last_error())
+        ctx.sync()
+    return buf, (IO_FILT_PACKED if off else 0)
 
 
 class DeviceBuffer:

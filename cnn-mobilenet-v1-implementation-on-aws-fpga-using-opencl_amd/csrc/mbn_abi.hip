@@ -522,7 +522,7 @@ int resolve(mbn_context *ctx, const mbn_layer_ext *ext, mbn_call *c, int *dtype)
     if (ext->dtype != MBN_DT_U8 && ext->dtype != MBN_DT_F32 && ext->dtype != MBN_DT_BF16) return MBN_EINVAL;
     if (ext->dtype == MBN_DT_U8 && ext->layout != MBN_LAYOUT_NCHW_PLANAR) return MBN_EUNSUPPORTED;
     if (ext->dtype != MBN_DT_U8 && ext->layout != MBN_LAYOUT_NHWC) return MBN_EUNSUPPORTED;
-    if (ext->io_flags & ~(MBN_IO_IN_F32 | MBN_IO_OUT_F32 | MBN_IO_IN_U8)) return MBN_EINVAL;
+    if (ext->io_flags & ~(MBN_IO_IN_F32 | MBN_IO_OUT_F32 | MBN_IO_IN_U8 | MBN_IO_FILT_PACKED)) return MBN_EINVAL;
     c->dtype = ext->dtype;
     // IN_F32 / OUT_F32 only mean something in bf16 mode; IN_U8 (raw image into convolute) applies to fp32 and bf16
     c->io_flags = ext->dtype == MBN_DT_BF16 ? ext->io_flags : (ext->io_flags & MBN_IO_IN_U8);
@@ -638,7 +638,9 @@ int mbn_pointwise(mbn_context *ctx, void *output, const void *inp_image, const v
         const double px = (double)c.batch * rows * cols, lit = dtype == MBN_DT_U8;
         MBN_SPANS(ctx, { inp_image, (lit ? 1.0 : esz_in(c)) * px * filtersize, "pointwise input" },
                   { output, (lit ? 1.0 : esz_out(c)) * px * op_size, "pointwise output" },
-                  { filter_k, (dtype == MBN_DT_BF16 ? 2.0 : 4.0) * op_size * filtersize, "pointwise filter" },
+                  { filter_k, (dtype == MBN_DT_BF16 ? 2.0 : 4.0) * op_size * filtersize +
+                                  ((dtype == MBN_DT_BF16 && (c.io_flags & MBN_IO_FILT_PACKED)) ? (double)mbn_packed_filter_offset(op_size, filtersize) : 0.0),
+                    "pointwise filter" },
                   { c.scale, 4.0 * op_size, "pointwise scale" }, { c.shift, 4.0 * op_size, "pointwise shift" });
     }
     Scope sc(ctx, c.stream);
@@ -835,6 +837,28 @@ int mbn_convert_f32_to_bf16(mbn_context *ctx, void *dst_bf16, const void *src_f3
     MBN_SPANS(ctx, { src_f32, 4.0 * count, "convert source" }, { dst_bf16, 2.0 * count, "convert destination" });
     Scope sc(ctx, s);
     return sc.finish(mbn_launch_convert(ctx, s, dst_bf16, src_f32, count, 1));
+}
+
+size_t mbn_packed_filter_offset(int cout, int cin)
+{
+    if (cout <= 0 || cin <= 0 || (cout % 256) != 0 || (cin % 64) != 0) return 0;
+    return ((size_t)cout * cin * 2 + 255) & ~(size_t)255;
+}
+
+int mbn_pack_filter_bf16(mbn_context *ctx, void *filter_buf, int cout, int cin, void *stream)
+{
+    if (!ctx || !filter_buf) return MBN_EINVAL;
+    const size_t off = mbn_packed_filter_offset(cout, cin);
+    if (off == 0) return MBN_EUNSUPPORTED;
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    MBN_SPANS(ctx, { filter_buf, (double)off + 2.0 * cout * cin, "packed filter buffer" });
+#ifdef MBN_LAB
+    Scope sc(ctx, s);
+    return sc.finish(mbn_launch_pack_filter_bf16(ctx, s, (char *)filter_buf + off, filter_buf, cout, cin));
+#else
+    (void)s;
+    return MBN_EUNSUPPORTED;           // the kernel that reads packed images is not part of the shipped library (see mbn.h)
+#endif
 }
 
 int mbn_convert_bf16_to_f32(mbn_context *ctx, void *dst_f32, const void *src_bf16, size_t count, void *stream)

@@ -131,6 +131,115 @@ __global__ __launch_bounds__(256) void dw3x3_nhwc(DwArgs a)
     }
 }
 
+// ---- round 3 (LAB ONLY: measured 9-20 % SLOWER at stride 1, equal at stride 2): the same column march with BRANCH-FREE loads and
+// a row of look-ahead. What it shows: the guarded loads of dw3x3_nhwc are not what holds the kernel at 0.80-0.84 of the copy
+// control (profiles/r03/c_depthwise_copy_control.txt) — issuing the same requests back to back, or twice as many of them, is
+// slower, and so was a third form (own columns only, halo columns from the neighbouring lanes by ds_bpermute; removed).
+// dw3x3_nhwc above guards every load with (row inside && column inside) — in the ISA that is an exec-masked branch per load
+// (65 branches in the stride-1 kernel) with the compiler's s_waitcnt vmcnt(0) behind each row, so a wave has ONE input row
+// (4 x 16 B per lane) in flight and nothing else. Here the loads go through a buffer descriptor: a tap outside the image
+// carries an out-of-range offset and the hardware returns 0, so a row is NC loads back to back, and (PF = 1) the row of
+// output row oy+1 is requested before output row oy is computed: two rows in flight per wave at +16 VGPRs.
+// Same taps, same fma order as dw3x3_nhwc: bit-identical. The offset of a tap is (row part) + (column part) with NO select per
+// load — a conditional offset came out of the compiler as a branch per load with s_waitcnt vmcnt(0) inside (15-30 % slower than
+// the guarded loads): an invalid row or column part is 2^30, the input tensor must be smaller than that (1 GiB), so any sum with
+// an invalid part is out of range and none wraps.
+constexpr unsigned DW_OOB = 0x40000000u;
+
+template <int STRIDE, int TW, typename T, int PF>
+__global__ __launch_bounds__(256) void dw3x3_nhwc_b(DwArgs a)
+{
+    constexpr int NC = TW * STRIDE + 2;
+    constexpr unsigned ES = sizeof(T);
+    if (a.prio) __builtin_amdgcn_s_setprio(3);
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.total) return;
+    const int cl = (int)(t % a.cw);
+    long q = t / a.cw;
+    const int lc = (int)(q % a.lcols);
+    q /= a.lcols;
+    const int slab = (int)(q % a.nslab);
+    q /= a.nslab;
+    const int seg = (int)(q % a.nseg);
+    const int n = (int)(q / a.nseg);
+    const int c = (slab * a.cw + cl) << 2;
+    const int ox0 = lc * TW;
+
+    f4 w[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) w[k] = ld4(a.filt + (long)k * a.ch + c);
+    const f4 sc = a.scale ? ld4(a.scale + c) : f4{ 1.f, 1.f, 1.f, 1.f };
+    const f4 sh = a.shift ? ld4(a.shift + c) : f4{ 0.f, 0.f, 0.f, 0.f };
+
+    const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.in), 0,
+                                                                        (unsigned)((long)a.batch * a.in_rows * a.in_cols * a.ch * ES), 0x00020000);
+    T *op = reinterpret_cast<T *>(a.out) + (((long)n * a.rows) * a.cols + ox0) * a.ch + c;
+    const int oy0 = seg * a.seg_rows;
+    const int oy1 = min(oy0 + a.seg_rows, a.rows);
+    const int ix0 = ox0 * STRIDE - a.pad_left;
+    // byte offset of (n, row 0, column ix0 + j, channel c), or out of range for columns outside the image
+    unsigned coff[NC];
+#pragma unroll
+    for (int j = 0; j < NC; j++) {
+        const int ix = ix0 + j;
+        coff[j] = (ix >= 0 && ix < a.in_cols) ? (unsigned)((((long)n * a.in_rows) * a.in_cols + ix) * a.ch + c) * ES : DW_OOB;
+    }
+    const unsigned rstride = (unsigned)a.in_cols * (unsigned)a.ch * ES;
+    auto load_row_b = [&](int iy, f4 (&r)[NC]) __attribute__((always_inline)) {
+        const unsigned ro = (unsigned)iy < (unsigned)a.in_rows ? (unsigned)iy * rstride : DW_OOB;
+#pragma unroll
+        for (int j = 0; j < NC; j++) {
+            const unsigned off = ro + coff[j];
+            if constexpr (sizeof(T) == 4) r[j] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(irs, off, 0, 0));
+            else {
+                typedef unsigned u2v __attribute__((ext_vector_type(2)));
+                const u2v p = __builtin_bit_cast(u2v, __builtin_amdgcn_raw_buffer_load_b64(irs, off, 0, 0));
+                r[j] = f4{ __builtin_bit_cast(float, p.x << 16), __builtin_bit_cast(float, p.x & 0xffff0000u),
+                           __builtin_bit_cast(float, p.y << 16), __builtin_bit_cast(float, p.y & 0xffff0000u) };
+            }
+        }
+    };
+
+    f4 r0[NC], r1[NC], r2[NC], nx[NC], nx2[NC];
+    int iy = oy0 * STRIDE - a.pad_top;
+    load_row_b(iy, r0);
+    if (STRIDE == 1) load_row_b(iy + 1, r1);
+    if (PF) {                                        // the new row(s) of the first output row
+        if (STRIDE == 2) load_row_b(iy + 1, nx2);
+        load_row_b(iy + 2, nx);
+    }
+    for (int oy = oy0; oy < oy1; oy++) {
+        iy = oy * STRIDE - a.pad_top;
+        if (PF) {
+#pragma unroll
+            for (int j = 0; j < NC; j++) { r2[j] = nx[j]; if (STRIDE == 2) r1[j] = nx2[j]; }
+            // the next output row's new input rows, requested before this row's arithmetic (past the segment: one dropped row)
+            const int iyn = (oy + 1) * STRIDE - a.pad_top;
+            const bool more = oy + 1 < oy1;
+            if (STRIDE == 2) load_row_b(more ? iyn + 1 : -1, nx2);
+            load_row_b(more ? iyn + 2 : -1, nx);
+        } else {
+            if (STRIDE == 2) load_row_b(iy + 1, r1);
+            load_row_b(iy + 2, r2);
+        }
+#pragma unroll
+        for (int p = 0; p < TW; p++) {
+            const int j = p * STRIDE;
+            f4 acc = f4{ 0.f, 0.f, 0.f, 0.f };
+            acc = fma4(r0[j], w[0], acc); acc = fma4(r0[j + 1], w[1], acc); acc = fma4(r0[j + 2], w[2], acc);
+            acc = fma4(r1[j], w[3], acc); acc = fma4(r1[j + 1], w[4], acc); acc = fma4(r1[j + 2], w[5], acc);
+            acc = fma4(r2[j], w[6], acc); acc = fma4(r2[j + 1], w[7], acc); acc = fma4(r2[j + 2], w[8], acc);
+            acc = act4(fma4(acc, sc, sh), a.act);
+            if (TW == 1 || ox0 + p < a.cols) st4(op + ((long)oy * a.cols + p) * a.ch, acc);
+        }
+#pragma unroll
+        for (int j = 0; j < NC; j++) {
+            if (STRIDE == 1) { r0[j] = r1[j]; r1[j] = r2[j]; }
+            else r0[j] = r2[j];
+        }
+    }
+}
+
 // bf16 storage, 8 channels (16 bytes) per lane: the fp32 kernel's decomposition with 4-channel lanes moves 8 bytes per
 // lane-load in bf16 and is instruction-bound at ~2.2 TB/s (27 % of HBM); here a lane loads whole 16-byte vectors, widens
 // them to fp32 once (a shift / a mask per element) and keeps the 3 x NC window in fp32 registers. Weights, scale, shift stay fp32 in registers; arithmetic and rounding are the 4-channel kernel's.
@@ -384,6 +493,21 @@ int launch_dw(const mbn_call &c, DwArgs &a, int rows, int cols, int fs, int stri
     if (tw == 1) {
         if (stride == 1) hipLaunchKernelGGL((dw3x3_nhwc<1, 1, T>), grid, dim3(256), 0, c.stream, a);
         else hipLaunchKernelGGL((dw3x3_nhwc<2, 1, T>), grid, dim3(256), 0, c.stream, a);
+        return MBN_OK;
+    }
+#endif
+#ifdef MBN_LAB
+    // LAB ONLY (slower, profiles/r03/f_depthwise_variants.txt): branch-free buffer loads, exp0 = 2 without / 3 with one row of look-ahead
+    const bool small_in = (double)c.batch * a.in_rows * a.in_cols * channels * sizeof(T) < 1073741824.0;
+    const int dv = g_mbn_tune.exp0;
+    if (small_in && (dv == 2 || dv == 3)) {
+        if (dv == 2) {
+            if (stride == 1) hipLaunchKernelGGL((dw3x3_nhwc_b<1, 2, T, 0>), grid, dim3(256), 0, c.stream, a);
+            else hipLaunchKernelGGL((dw3x3_nhwc_b<2, 2, T, 0>), grid, dim3(256), 0, c.stream, a);
+        } else {
+            if (stride == 1) hipLaunchKernelGGL((dw3x3_nhwc_b<1, 2, T, 1>), grid, dim3(256), 0, c.stream, a);
+            else hipLaunchKernelGGL((dw3x3_nhwc_b<2, 2, T, 1>), grid, dim3(256), 0, c.stream, a);
+        }
         return MBN_OK;
     }
 #endif

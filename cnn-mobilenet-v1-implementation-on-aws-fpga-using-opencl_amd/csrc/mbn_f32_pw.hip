@@ -553,11 +553,19 @@ int mbn_launch_f32_pointwise(const mbn_call &c, void *out, const void *in, const
     // fp32, few tiles (batch 1..4): K split over the waves of a 16x16-tile workgroup (mbn_f32_pw_splitk.hip)
     if (!bf && g_mbn_tune.pw_tile == 0 && mbn_launch_f32_pw_splitk(c, (float *)out, (const float *)in, (const float *)filt, m, cin, op_size) == MBN_OK)
         return MBN_OK;
+#ifdef MBN_LAB
+    // LAB ONLY (measured slower than pw_gemm<bf16>, profiles/r03/e_bf16_wide_gemm.txt): wide layers with a packed filter image behind
+    // the plain filter (MBN_IO_FILT_PACKED): 196 x 256 tiles, filter straight into registers, activations through a 3-slot LDS ring,
+    // deferred epilogue (mbn_bf16_pw_wide.hip). pw_ring = 6 selects it.
+    if (bf && (c.io_flags & MBN_IO_FILT_PACKED) && ring_mode == 6 && g_mbn_tune.pw_tile == 0 &&
+        mbn_launch_bf16_pw_wide(c, out, in, (const char *)filt + mbn_packed_filter_offset(op_size, cin), m, cin, op_size) == MBN_OK)
+        return MBN_OK;
+#endif
     // measured per layer at batch 512 (profiles/r03/b_bf16_stream_gemm.txt, same call, against pw_gemm<bf16>): K = 64 0.179 -> 0.116 ms,
     // K = 128 0.080 -> 0.076, K = 256 with N = 256 0.114 -> 0.100; K = 256 with N = 512 and every K >= 512 layer 0-5 % SLOWER (there the
     // L2 -> LDS operand stream of a 128 x 128 tile, not the look-ahead, is the limit: ablation in the same file) -> pw_gemm keeps those.
     // pw_ring = 4 (lab): the streaming kernel wherever eligible.
-    if (bf && (ring_mode == 4 || (ring_mode == 0 && (cin <= 128 || (cin <= 256 && op_size <= 256)))) && g_mbn_tune.pw_tile == 0 &&
+    if (bf && (ring_mode == 4 || ((ring_mode == 0 || ring_mode == 6) && (cin <= 128 || (cin <= 256 && op_size <= 256)))) && g_mbn_tune.pw_tile == 0 &&
         mbn_launch_bf16_pw_stream(c, out, in, filt, m, cin, op_size) == MBN_OK)
         return MBN_OK;
 #ifdef MBN_LAB

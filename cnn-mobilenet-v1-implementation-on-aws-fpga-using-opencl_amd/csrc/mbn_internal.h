@@ -137,6 +137,9 @@ int mbn_launch_f32_dwpw2_x6(mbn_context *ctx, hipStream_t stream, float *out, co
                             const float *b2, const float *wp, const float *s3, const float *b3, int batch, int in_rows, int in_cols,
                             int out_rows, int out_cols, int cin, int cout, int stride, int pad_top, int pad_left);
 int mbn_launch_bf16_pw_ring(const mbn_call &c, void *out, const void *in, const void *filt, long m, int cin, int op_size);      // lab build only
+int mbn_launch_bf16_pw_wide(const mbn_call &c, void *out, const void *in, const void *fpk, long m, int cin, int op_size);
+int mbn_launch_pack_filter_bf16(mbn_context *ctx, hipStream_t s, void *dst, const void *src, int n, int k);
+int mbn_bf16_pw_wide_eligible(long m, int cin, int op_size);
 int mbn_launch_bf16_pw_stream(const mbn_call &c, void *out, const void *in, const void *filt, long m, int cin, int op_size);
 int mbn_launch_f32_pool(const mbn_call &c, void *out, const void *in, int rows, int cols, int fs, int channels);
 // floor(v / d) == umulhi(v, *m) >> *s for every v < 2^31 (d >= 2); d == 1 gives *m = 0 (callers skip the multiply)

@@ -42,6 +42,7 @@ struct mbn_net {
     int nstreams;              /* sub-batch pipelining (mbn_net_set_streams); 1 = everything on the context's stream */
     void *streams[8];
     void *bf16_filt[MBN_MAX_LAYERS];   /* bf16 copies of the pointwise / FC filters (bf16 mode) */
+    unsigned char bf16_packed[MBN_MAX_LAYERS];   /* the copy is followed by its packed image (mbn_pack_filter_bf16) */
     void *keep_buf[MBN_MAX_LAYERS];
     void *logits_buf;          /* mbn_net_classify: [max_batch][classes] fp32 */
     void *last_out[MBN_MAX_LAYERS];
@@ -138,10 +139,15 @@ int mbn_net_set_dtype(mbn_net *net, int dtype)
         for (int i = 0; i < net->plan.n_layers; i++) {
             const mbn_layer_desc *l = &net->plan.layer[i];
             if ((l->kind != MBN_L_PW && l->kind != MBN_L_FC) || net->bf16_filt[i]) continue;
-            int rc = mbn_alloc(net->ctx, (size_t)l->w_count * 2, &net->bf16_filt[i]);
+            /* lab build only (the wide-tile GEMM measured slower and is not shipped): wide pointwise layers (Cout % 256 == 0,
+             * Cin % 64 == 0) carry the packed image of their filter behind the plain bf16 copy (MBN_IO_FILT_PACKED) */
+            const size_t pk = (l->kind == MBN_L_PW && mbn_lab_build()) ? mbn_packed_filter_offset(l->out_ch, l->in_ch) : 0;
+            int rc = mbn_alloc(net->ctx, pk ? pk + (size_t)l->w_count * 2 : (size_t)l->w_count * 2, &net->bf16_filt[i]);
             if (rc == MBN_OK)
                 rc = mbn_convert_f32_to_bf16(net->ctx, net->bf16_filt[i], blob_at(net, l->w_offset), (size_t)l->w_count, NULL);
+            if (rc == MBN_OK && pk) rc = mbn_pack_filter_bf16(net->ctx, net->bf16_filt[i], l->out_ch, l->in_ch, NULL);
             if (rc != MBN_OK) return rc;
+            net->bf16_packed[i] = pk != 0;
         }
         int rc = mbn_sync(net->ctx);     /* the copies are ready before any (possibly free-running) sub-stream reads them */
         if (rc != MBN_OK) return rc;
@@ -373,6 +379,7 @@ static int run_layer(mbn_net *net, const mbn_layer_desc *l, const void *src, voi
         ext.in_cols = l->in_cols;
         return mbn_depthwise(net->ctx, dst, src, filt, l->out_rows, l->out_cols, 3, l->stride, l->out_ch, &ext);
     case MBN_L_PW:                         /* MobileNet.c:417-470, with filtersize = true Cin (B3) */
+        if (bf && net->bf16_packed[l->index - 1]) ext.io_flags |= MBN_IO_FILT_PACKED;
         return mbn_pointwise(net->ctx, dst, src, filt, l->out_rows, l->out_cols, l->in_ch, l->out_ch, &ext);
     case MBN_L_POOL:                       /* MobileNet.c:2603-2656 */
         ext.act = MBN_ACT_NONE;

@@ -120,6 +120,9 @@ typedef struct mbn_layer_ext {
  * else (conv1/depthwise filters, scale/shift, accumulation) fp32. */
 #define MBN_IO_IN_F32   0x1   /* the input tensor is fp32 (convolute: the normalised image) */
 #define MBN_IO_OUT_F32  0x2   /* the output tensor is fp32 (pointwise as FC: the logits) */
+#define MBN_IO_FILT_PACKED 0x8 /* pointwise, MBN_DT_BF16: `filter_k` holds the plain [Cout][Cin] bf16 filter FOLLOWED, at byte offset
+                                * mbn_packed_filter_offset(Cout, Cin), by its packed image (mbn_pack_filter_bf16): the wide-layer GEMM
+                                * (mbn_bf16_pw_wide.hip) loads the filter in matrix-operand order straight into registers */
 #define MBN_IO_IN_U8    0x4   /* convolute, fp32/bf16 mode: the input is the raw uint8 HWC image (what decode_image /
                                * mbn_read_ppm produce, MobileNet.c:49-57); the Keras MobileNet preprocessing x/127.5 - 1
                                * is applied at load — SURVEY §8f-2, replaces a separate mbn_normalize_u8_to_f32 pass */
@@ -305,6 +308,17 @@ int mbn_normalize_u8_to_f32(mbn_context *ctx, void *out_f32, const void *in_u8, 
 /* fp32 <-> bf16 (round to nearest even) on device; used to build the bf16 copy of the pointwise/FC filters. */
 int mbn_convert_f32_to_bf16(mbn_context *ctx, void *dst_bf16, const void *src_f32, size_t count, void *stream);
 int mbn_convert_bf16_to_f32(mbn_context *ctx, void *dst_f32, const void *src_bf16, size_t count, void *stream);
+/* LAB BUILD ONLY as far as any kernel reads it (mbn_bf16_pw_wide.hip: 196 x 256 tiles with the filter loaded from this image straight
+ * into matrix-operand registers — built and measured in round 3, slower than the tiled GEMM, not shipped; profiles/LOG.md). The shipped
+ * library accepts MBN_IO_FILT_PACKED and ignores the image; mbn_pack_filter_bf16 answers MBN_EUNSUPPORTED there.
+ * Packed image of a bf16 pointwise filter [cout][cin]: the same cout * cin bf16 values in the order
+ * [cout / 256][cin / 64][8 waves][4 k16 steps][64 lanes][8], i.e. the B operand of v_mfma_f32_32x32x16_bf16 per 32-column
+ * wave, so that a wave's share of a k-tile is four contiguous 1-KB loads. mbn_packed_filter_offset = where the image goes
+ * inside the filter buffer (cout * cin * 2 bytes rounded up to 256), 0 when the shape has no packed form (cout % 256 or
+ * cin % 64 != 0). mbn_pack_filter_bf16 writes the image from the plain filter at the start of `filter_buf` (which must hold
+ * offset + cout * cin * 2 bytes). */
+size_t mbn_packed_filter_offset(int cout, int cin);
+int mbn_pack_filter_bf16(mbn_context *ctx, void *filter_buf, int cout, int cin, void *stream);
 
 /* ------------------------------------------------------------------ loaders
  * The two reference symbols are kept with their exact signatures (CPU only). They return without

@@ -1617,6 +1617,63 @@ def test_bf16_pointwise_stream_kernel(pkg, orc, ctx, shape):
         b.free()
 
 
+@pytest.mark.parametrize("shape", [(4 * 196, 256, 256), (8 * 196 + 57, 256, 512), (16 * 196, 512, 512), (50176, 512, 512), (25088, 512, 1024),
+                                   (6 * 196 - 1, 1024, 1024), (100352, 512, 512), (100352, 256, 512), (25088, 1024, 1024), (31 * 196 + 100, 512, 256)])
+def test_bf16_pointwise_wide_kernel(pkg, orc, ctx, shape):
+    """mbn_bf16_pw_wide.hip (196 x 256 tiles, filter from its packed image straight into registers, activations through a 3-slot LDS
+    ring, DPP-paired 4-byte stores), taken for pointwise calls that carry IO_FILT_PACKED with K in {256, 512, 1024} and N % 256 == 0.
+    Against the oracle's bf16 emulation (sampled rows at the headline sizes), repeatable, no store past the output or into rows of
+    the next tile (canary + ragged M), exact small integers through an asymmetric filter (packing order, operand maps, channel
+    pairing by DPP, both filter register sets, every ring slot, 1 to 8 tiles per workgroup), and bit for bit equal to the same call
+    WITHOUT the flag (pw_gemm<bf16> / the streaming kernel: same k-order of the sums)."""
+    _tune_lab(ctx, b"pw_ring", 6)                              # lab build only: the kernel is not part of the shipped library
+    m, cin, cout = shape
+    rng = np.random.default_rng(m + cin + cout)
+    x = orc.bf16_round(rng.uniform(-1, 1, (m, cin)))
+    f = orc.bf16_round(rng.normal(0, (2.0 / cin) ** 0.5, (cout, cin)))
+    sc, sh = rng.uniform(0.5, 1.5, cout).astype(np.float32), rng.normal(0, 0.1, cout).astype(np.float32)
+    d_x, d_sc, d_sh = _bf16_dev(pkg, ctx, x), ctx.to_device(sc), ctx.to_device(sh)
+    d_f, flag = pkg.packed_filter_dev(ctx, f)
+    assert flag == pkg.IO_FILT_PACKED
+    d_o, d_p = ctx.alloc(m * cout * 2 + 64), ctx.alloc(m * cout * 2)
+    ext = pkg.make_ext(dtype=pkg.DT_BF16, act=2, scale=d_sc.ptr, shift=d_sh.ptr, io_flags=flag)
+    ext0 = pkg.make_ext(dtype=pkg.DT_BF16, act=2, scale=d_sc.ptr, shift=d_sh.ptr)
+    ctx.lib.mbn_memset(ctx.h, d_o.ptr, 0xFF, m * cout * 2 + 64)
+    ctx.pointwise(d_o.ptr, d_x.ptr, d_f.ptr, m, 1, cin, cout, ext)
+    ctx.sync()
+    raw = d_o.download((m * cout + 32,), np.uint16)
+    assert np.all(raw[m * cout:] == 0xFFFF), "stores past the output"
+    got = _bf16_get(pkg, d_o, (m, cout))
+    assert np.isfinite(got).all()
+    rows = np.arange(m) if m * cin * cout <= 2e9 else np.unique(np.concatenate([np.arange(0, 420), np.arange(m - 420, m), rng.integers(0, m, 2000)]))
+    ref = orc.bf16_round(orc.f32_pointwise(x[rows], f, sc, sh, 2))
+    assert_close(got[rows], ref, TOL_BF16, "wide %s vs oracle" % (shape,))
+    ctx.pointwise(d_p.ptr, d_x.ptr, d_f.ptr, m, 1, cin, cout, ext0)          # the same call without the packed image: pw_gemm<bf16> / stream kernel
+    ctx.sync()
+    other = _bf16_get(pkg, d_p, (m, cout))
+    assert np.array_equal(got, other), "wide vs unpacked path %s: max diff %g" % (shape, np.abs(got - other).max())
+    ctx.pointwise(d_o.ptr, d_x.ptr, d_f.ptr, m, 1, cin, cout, ext)
+    ctx.sync()
+    assert np.array_equal(got, _bf16_get(pkg, d_o, (m, cout))), "not repeatable"
+    # exact integers with an asymmetric filter and identity BN
+    xi = rng.integers(-3, 4, (m, cin)).astype(np.float32)
+    fi = rng.integers(-2, 3, (cout, cin)).astype(np.float32)
+    fi[:, 0] = np.arange(cout) % 5
+    fi[:, cin - 1] = np.arange(cout) % 3
+    one, zero = ctx.to_device(np.ones(cout, np.float32)), ctx.to_device(np.zeros(cout, np.float32))
+    d_x.upload(pkg.f32_to_bf16_bits(xi))
+    d_fi, _ = pkg.packed_filter_dev(ctx, fi)
+    ctx.pointwise(d_o.ptr, d_x.ptr, d_fi.ptr, m, 1, cin, cout, pkg.make_ext(dtype=pkg.DT_BF16, act=2, scale=one.ptr, shift=zero.ptr, io_flags=flag))
+    ctx.sync()
+    goti = _bf16_get(pkg, d_o, (m, cout))
+    for lo in (0, max(0, m - 4096)):
+        want = np.clip(xi[lo:lo + 4096].astype(np.float64) @ fi.astype(np.float64).T, 0, 6)
+        assert np.array_equal(goti[lo:lo + 4096].astype(np.float64), orc.bf16_round(want.astype(np.float32)).astype(np.float64))
+    ctx.lib.mbn_tune_set(b"pw_ring", 0)
+    for b in (d_x, d_f, d_fi, d_sc, d_sh, d_o, d_p, one, zero):
+        b.free()
+
+
 @pytest.mark.parametrize("shape", [(196, 512, 512, 1), (49, 1024, 1024, 1), (4 * 196, 256, 512, 4), (3 * 49 , 512, 1024, 3), (1, 1024, 1000, 1),
                                    (4, 1024, 1000, 4), (2 * 25, 128, 256, 2), (37, 192, 40, 1), (100, 320, 72, 1), (2 * 81, 384, 104, 2)])
 def test_f32_pointwise_splitk_kernel(pkg, orc, ctx, shape):

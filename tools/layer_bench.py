@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--tune", action="append", default=[], help="key=v1,v2,... : A/B over tuning values, interleaved")
     ap.add_argument("--json", action="store_true")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32")
+    ap.add_argument("--packed", action="store_true", help="bf16: give every pointwise layer a filter buffer with the packed image behind it (IO_FILT_PACKED)")
     ap.add_argument("--custom-pw", default="", help="M,K,N[;M,K,N...]: time raw pointwise GEMMs of these shapes instead")
     args = ap.parse_args()
 
@@ -62,6 +63,8 @@ def main():
     bf = args.dtype == "bf16"
     ab = 2.0 if bf else 4.0
 
+    packed = {}
+
     def call(l):
         ext = pkg.make_ext(batch=n, dtype=pkg.DT_BF16 if bf else pkg.DT_F32, act=pkg.ACT_RELU6, pad_top=l.pad_top,
                            pad_left=l.pad_left,
@@ -76,6 +79,12 @@ def main():
             ext.in_rows, ext.in_cols = l.in_rows, l.in_cols
             ctx.depthwise(d_b.ptr, d_a.ptr, filt, l.out_rows, l.out_cols, 3, l.stride, l.out_ch, ext)
         elif l.kind == pkg.L_PW:
+            if bf and args.packed:
+                if l.index not in packed:
+                    w = blob[l.w_offset:l.w_offset + l.w_count].reshape(l.out_ch, l.in_ch)
+                    packed[l.index] = pkg.packed_filter_dev(ctx, w)
+                filt, fl = packed[l.index][0].ptr, packed[l.index][1]
+                ext.io_flags |= fl
             ctx.pointwise(d_b.ptr, d_a.ptr, filt, l.out_rows, l.out_cols, l.in_ch, l.out_ch, ext)
         elif l.kind == pkg.L_POOL:
             ctx.pool(d_b.ptr, d_a.ptr, l.in_rows, l.in_cols, l.in_rows, l.out_ch, ext)
