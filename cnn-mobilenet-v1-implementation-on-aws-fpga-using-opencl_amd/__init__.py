@@ -23,6 +23,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libmbn_lab.so" if os.environ.get("MBN_LAB") ==
 HOST_LIB_PATH = os.path.join(PKG_DIR, "libmbn_host.so")
 HEADER = os.path.join(REPO_ROOT, "include", "mbn.h")
 
+RANK_FN = C.CFUNCTYPE(C.c_int, C.c_int, C.c_void_p, C.c_void_p)     # mbn_rank_fn(rank, arg, sync)
 OK, EINVAL, ENOMEM, EDEVICE, EIO, EFORMAT, ENOTFOUND, ESHAPE, EUNSUPPORTED, ENODEVICE = 0, -1, -2, -3, -4, -5, -6, -7, -8, -9
 DT_U8, DT_F32, DT_BF16 = 0, 1, 2
 LAYOUT_NCHW_PLANAR, LAYOUT_NHWC = 0, 1
@@ -101,6 +102,9 @@ def _declare_host(lib):
     lib.readSquezeNetKernel.restype = None
     lib.decode_image.argtypes = [C.c_void_p, C.c_char_p]
     lib.mbn_shard_range.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.mbn_run_ranks.argtypes = [C.c_int, RANK_FN, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    lib.mbn_rank_barrier.argtypes = [C.c_void_p]
+    lib.mbn_rank_fail.argtypes = [C.c_void_p]
     return lib
 
 

@@ -60,6 +60,7 @@ struct DwPw2Args {
     int pad_top, pad_left;
     int mt, nt;
     unsigned in_bytes, wp_bytes;
+    int stagger;            // start delay of a workgroup in units of 1024 cycles x its phase (see the kernel): 0 = all workgroups in phase
     int dbg;                // experiments (tune dwpw_variant = 100 + bits): 1 = no x loads after the first, 2 = no depthwise math, 4 = no output stores, 128 = x loads as one burst (before: -2.5 %), 256 = no s_setprio around the depthwise part (-1 %),
                             // 8 = no filter DMA, 16 = no MFMA, 32 = unpaired column blocks (4-byte stores)
     unsigned wo_m, wo_s, ho_m, ho_s;   // floor(v / wo) = umulhi(v, wo_m) >> wo_s for v < 2^31 (m == 0: the divisor is 1)
@@ -133,6 +134,16 @@ __global__ __launch_bounds__(NT) void dwpw2_f32(DwPw2Args a)
     for (int i = tid; i < a.cout; i += NT) { sc3_s[i] = a.s3[i]; sh3_s[i] = a.b3[i]; }
     __syncthreads();
     if ((int)blockIdx.x >= nwg) return;
+    // De-phasing. All workgroups run the same steps on the same amount of work, so they reach their epilogues together: a
+    // chip-wide store burst during which — vmcnt retires in order — no wave sees a younger load complete (round 3: loads and stores of
+    // such a kernel add up instead of overlapping). A quarter of the workgroups starts immediately, the others 1, 2, 3 x `stagger`
+    // kcycles later, so that at any time some workgroups load while others store. Arithmetic untouched.
+    if (a.stagger > 0) {
+        const int phase = ((int)blockIdx.x >> 3) & 3;
+        const long long t0 = __builtin_readcyclecounter();
+        const long long wait = (long long)phase * a.stagger * 1024;
+        while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+    }
 
     // ---- roles of this lane
     const int c4 = tid & 7, pair = tid >> 3;                        // depthwise: tile rows 2*pair, 2*pair+1, channels 4*c4..+3 of the chunk
@@ -389,6 +400,7 @@ int mbn_launch_f32_dwpw2(mbn_context *ctx, hipStream_t stream, float *out, const
     a.in_bytes = (unsigned)(4.0 * batch * in_rows * in_cols * cin);
     a.wp_bytes = (unsigned)(4.0 * cin * cout);
     a.dbg = variant >= 100 ? variant - 100 : 0;
+    a.stagger = g_mbn_tune.exp2;                                             // lab: start stagger of the workgroups in kcycles per phase
     const bool pre = variant != 3;                                       // 3: taps read from LDS inside the step (A/B hook)
     // 256-column tiles only when they alone fill the chip (see mbn_dwpw_fused); pw_tile=1: force the 128-column tile (A/B hook)
     const bool wide = (cout % 256) == 0 && g_mbn_tune.pw_tile != 1 && ((a.m + BM - 1) / BM) * (cout / 256) >= ctx->num_cus;

@@ -93,8 +93,10 @@ __device__ __forceinline__ void split8(const f4 &x0, const f4 &x1, u4 &H, u4 &M,
 template <int NP> struct Prod;
 template <> struct Prod<9> { static constexpr int pa[9] = { 2, 2, 1, 2, 0, 1, 1, 0, 0 }, pb[9] = { 2, 1, 2, 0, 2, 1, 0, 1, 0 }; };
 template <> struct Prod<6> { static constexpr int pa[6] = { 2, 0, 1, 1, 0, 0 }, pb[6] = { 0, 2, 1, 0, 1, 0 }; };
+#ifdef MBN_LAB
 template <> struct Prod<3> { static constexpr int pa[3] = { 1, 0, 0 }, pb[3] = { 0, 1, 0 }; };      // measurement only: 2^-16
 template <> struct Prod<1> { static constexpr int pa[1] = { 0 }, pb[1] = { 0 }; };                  // measurement only: bf16 operands
+#endif
 
 template <int BM, int BN, int WM, int WN, int NP, int NBUF, int OCC>
 __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void pw_gemm_x(XArgs a)

@@ -153,10 +153,10 @@ typedef struct {
     mbn_dist *dist;
     const mbn_plan *plan;
     void *dev_blob;
-    pthread_barrier_t *bar;
     double seconds;
-    int rc;
     int top1;            /* class of this shard's first image */
+    float *logits;       /* host copy of the shard's logits after the timed steps [count][classes] (--verify, checksum) */
+    unsigned long long fnv;
 } gpu_job;
 
 static double now_s(void)
@@ -168,104 +168,150 @@ static double now_s(void)
 
 static int g_streams = 1;      /* --streams S: sub-batch streams per GPU in --gpus mode (mbn_net_set_streams) */
 
-static void *gpu_thread(void *arg)
+/* image i of the whole batch is generated from its GLOBAL index, so a shard sees the same pixels as the same images would in
+ * a single-GPU run (sharding property: concat of shards == the unsharded batch) */
+static void synth_images(unsigned char *u8, int first, int n, size_t img)
 {
-    gpu_job *j = (gpu_job *)arg;
-    mbn_context *ctx = NULL;
+    for (int i = 0; i < n; i++) {
+        unsigned long long s = 0xC0FFEEULL + (unsigned long long)(first + i) * 0x9E3779B97F4A7C15ULL;
+        unsigned char *p = u8 + (size_t)i * img;
+        for (size_t k = 0; k < img; k++) { s = s * 6364136223846793005ULL + 1442695040888963407ULL; p[k] = (unsigned char)(s >> 56); }
+    }
+}
+
+static unsigned long long fnv1a(const void *p, size_t n)
+{
+    const unsigned char *b = (const unsigned char *)p;
+    unsigned long long h = 0xcbf29ce484222325ULL;
+    for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 0x100000001b3ULL; }
+    return h;
+}
+
+/* the forward of images [first, first + n) on `ctx`, exactly as a rank runs it (same net settings, same call sizes): used by the
+ * ranks and by --verify, which replays every shard on GPU 0 */
+static int shard_forward(mbn_context *ctx, const mbn_plan *plan, void *dev_blob, int res, int first, int n, int warmup, int steps,
+                         float *host_logits, int *top1, double *seconds, mbn_rank_sync *sync)
+{
     mbn_net *net = NULL;
     void *d_u8 = NULL, *d_logits = NULL, *d_idx = NULL, *d_prob = NULL;
     unsigned char *u8 = NULL;
-    const int n = j->count > 0 ? j->count : 1;                 /* a rank without images still takes part in the barriers */
-    const size_t img = (size_t)j->res * j->res * 3;
-    int rc = mbn_dist_context(j->dist, j->rank, &ctx);
-    if (rc == MBN_OK) rc = mbn_net_create_from_device_blob(ctx, j->plan, j->dev_blob, n, &net);
+    const int nn = n > 0 ? n : 1;                             /* a rank without images still takes part in the barriers */
+    const size_t img = (size_t)res * res * 3;
+    int rc = mbn_net_create_from_device_blob(ctx, plan, dev_blob, nn, &net);
     if (rc == MBN_OK) rc = mbn_net_set_input_u8(net, 1);
     if (rc == MBN_OK && g_streams > 1) {
         rc = mbn_net_set_streams(net, g_streams);
         if (rc == MBN_OK) rc = mbn_net_set_free_running(net, 1);   /* the images are uploaded with the blocking mbn_upload below */
     }
-    if (rc == MBN_OK) rc = mbn_alloc(ctx, (size_t)n * img, &d_u8);
-    if (rc == MBN_OK) rc = mbn_alloc(ctx, (size_t)n * j->plan->classes * sizeof(float), &d_logits);
-    if (rc == MBN_OK) rc = mbn_alloc(ctx, sizeof(int) * (size_t)n, &d_idx);
-    if (rc == MBN_OK) rc = mbn_alloc(ctx, sizeof(float) * (size_t)n, &d_prob);
-    if (rc == MBN_OK && !(u8 = malloc((size_t)n * img))) rc = MBN_ENOMEM;
+    if (rc == MBN_OK) rc = mbn_alloc(ctx, (size_t)nn * img, &d_u8);
+    if (rc == MBN_OK) rc = mbn_alloc(ctx, (size_t)nn * plan->classes * sizeof(float), &d_logits);
+    if (rc == MBN_OK) rc = mbn_alloc(ctx, sizeof(int) * (size_t)nn, &d_idx);
+    if (rc == MBN_OK) rc = mbn_alloc(ctx, sizeof(float) * (size_t)nn, &d_prob);
+    if (rc == MBN_OK && !(u8 = malloc((size_t)nn * img))) rc = MBN_ENOMEM;
     if (rc == MBN_OK) {
-        /* image i of the whole batch is generated from its GLOBAL index, so a shard sees the same pixels as the same
-         * images would in a single-GPU run (sharding property: concat of shards == the unsharded batch) */
-        for (int i = 0; i < n; i++) {
-            unsigned long long s = 0xC0FFEEULL + (unsigned long long)(j->first + i) * 0x9E3779B97F4A7C15ULL;
-            unsigned char *p = u8 + (size_t)i * img;
-            for (size_t k = 0; k < img; k++) { s = s * 6364136223846793005ULL + 1442695040888963407ULL; p[k] = (unsigned char)(s >> 56); }
-        }
-        rc = mbn_upload(ctx, d_u8, u8, (size_t)n * img);
+        synth_images(u8, first, nn, img);
+        rc = mbn_upload(ctx, d_u8, u8, (size_t)nn * img);
     }
-    for (int w = 0; rc == MBN_OK && w < j->warmup && j->count > 0; w++) rc = mbn_net_forward(net, d_u8, d_logits, n, 0);
+    for (int w = 0; rc == MBN_OK && w < warmup && n > 0; w++) rc = mbn_net_forward(net, d_u8, d_logits, nn, 0);
     if (rc == MBN_OK) rc = mbn_sync(ctx);
-    pthread_barrier_wait(j->bar);
+    if (sync && (rc != MBN_OK ? (mbn_rank_fail(sync), 1) : mbn_rank_barrier(sync) != MBN_OK)) rc = rc != MBN_OK ? rc : MBN_EDEVICE;
     const double t0 = now_s();
-    for (int k = 0; rc == MBN_OK && k < j->steps && j->count > 0; k++) rc = mbn_net_forward(net, d_u8, d_logits, n, 0);
+    for (int k = 0; rc == MBN_OK && k < steps && n > 0; k++) rc = mbn_net_forward(net, d_u8, d_logits, nn, 0);
     if (rc == MBN_OK) rc = mbn_sync(ctx);
-    j->seconds = now_s() - t0;
-    pthread_barrier_wait(j->bar);
-    if (rc == MBN_OK && j->count > 0) {
+    if (seconds) *seconds = now_s() - t0;
+    if (sync && rc == MBN_OK && mbn_rank_barrier(sync) != MBN_OK) rc = MBN_EDEVICE;
+    if (rc == MBN_OK && n > 0) {
         int idx = -1;
-        rc = mbn_softmax_topk_f32(ctx, NULL, d_idx, d_prob, d_logits, n, j->plan->classes, 1, NULL);
+        rc = mbn_softmax_topk_f32(ctx, NULL, d_idx, d_prob, d_logits, nn, plan->classes, 1, NULL);
         if (rc == MBN_OK) rc = mbn_download(ctx, &idx, d_idx, sizeof(int));
-        j->top1 = idx + 1;
+        if (top1) *top1 = idx + 1;
+        if (rc == MBN_OK && host_logits) rc = mbn_download(ctx, host_logits, d_logits, (size_t)n * plan->classes * sizeof(float));
     }
-    if (rc != MBN_OK) fprintf(stderr, "Error: GPU %d: %s (%s)\n", j->rank, mbn_strerror(rc), ctx ? mbn_last_device_error(ctx) : "");
     if (net) mbn_net_destroy(net);
+    if (d_u8) mbn_free(ctx, d_u8);
+    if (d_logits) mbn_free(ctx, d_logits);
+    if (d_idx) mbn_free(ctx, d_idx);
+    if (d_prob) mbn_free(ctx, d_prob);
     free(u8);
-    j->rc = rc;
-    return NULL;
+    return rc;
 }
 
-static int run_multi(int gpus, int batch, int res, int steps, int warmup, const mbn_weights *w)
+static int gpu_rank(int rank, void *arg, mbn_rank_sync *sync)
 {
-    mbn_context *ctx = NULL;                                    /* for CHECK's message */
+    gpu_job *j = &((gpu_job *)arg)[rank];
+    mbn_context *ctx = NULL;
+    int rc = mbn_dist_context(j->dist, j->rank, &ctx);
+    if (rc == MBN_OK)
+        rc = shard_forward(ctx, j->plan, j->dev_blob, j->res, j->first, j->count, j->warmup, j->steps, j->logits, &j->top1, &j->seconds, sync);
+    if (rc == MBN_OK && j->count > 0) j->fnv = fnv1a(j->logits, (size_t)j->count * j->plan->classes * sizeof(float));
+    if (rc != MBN_OK) fprintf(stderr, "Error: GPU %d: %s (%s)\n", j->rank, mbn_strerror(rc), ctx ? mbn_last_device_error(ctx) : "");
+    return rc;
+}
+
+/* --gpus G [--verify]. Every failure leaves through `done`, which shuts the communicators and contexts down. */
+static int run_multi(int gpus, int batch, int res, int steps, int warmup, const mbn_weights *w, int verify)
+{
+    mbn_context *ctx = NULL;
     mbn_dist *dist = NULL;
+    int bad = 1;
     int rc = mbn_dist_init(gpus, NULL, &dist);
     if (rc != MBN_OK) { fprintf(stderr, "Error: mbn_dist_init(%d) -> %s\n", gpus, mbn_strerror(rc)); return 1; }
     const size_t blob_bytes = (size_t)w->plan.blob_floats * sizeof(float);
     void **blobs = calloc((size_t)gpus, sizeof(void *));
     gpu_job *jobs = calloc((size_t)gpus, sizeof(gpu_job));
-    pthread_t *th = calloc((size_t)gpus, sizeof(pthread_t));
-    if (!blobs || !jobs || !th) return 1;
+    if (!blobs || !jobs) goto done;
+#define TRY(call) do { rc = (call); if (rc != MBN_OK) { fprintf(stderr, "Error: %s -> %s (%s)\n", #call, mbn_strerror(rc), ctx ? mbn_last_device_error(ctx) : ""); goto done; } } while (0)
     for (int r = 0; r < gpus; r++) {
-        CHECK(mbn_dist_context(dist, r, &ctx));
-        CHECK(mbn_alloc(ctx, blob_bytes, &blobs[r]));
+        TRY(mbn_dist_context(dist, r, &ctx));
+        TRY(mbn_alloc(ctx, blob_bytes, &blobs[r]));
     }
-    CHECK(mbn_dist_context(dist, 0, &ctx));
-    CHECK(mbn_upload(ctx, blobs[0], w->blob, blob_bytes));      /* host -> GPU 0 once ... */
+    TRY(mbn_dist_context(dist, 0, &ctx));
+    TRY(mbn_upload(ctx, blobs[0], w->blob, blob_bytes));        /* host -> GPU 0 once ... */
     rc = mbn_dist_broadcast(dist, blobs, blob_bytes, 0);         /* ... GPU 0 -> everybody over xGMI: the path's one collective */
-    if (rc != MBN_OK) { fprintf(stderr, "Error: mbn_dist_broadcast -> %s (%s)\n", mbn_strerror(rc), mbn_dist_last_error(dist)); return 1; }
-    pthread_barrier_t bar;
-    pthread_barrier_init(&bar, NULL, (unsigned)gpus);
+    if (rc != MBN_OK) { fprintf(stderr, "Error: mbn_dist_broadcast -> %s (%s)\n", mbn_strerror(rc), mbn_dist_last_error(dist)); goto done; }
     for (int r = 0; r < gpus; r++) {
         gpu_job *j = &jobs[r];
         j->rank = r; j->world = gpus; j->batch = batch; j->res = res; j->steps = steps; j->warmup = warmup;
-        j->dist = dist; j->plan = &w->plan; j->dev_blob = blobs[r]; j->bar = &bar;
-        CHECK(mbn_shard_range(batch, gpus, r, &j->first, &j->count));
-        if (pthread_create(&th[r], NULL, gpu_thread, j) != 0) { fprintf(stderr, "Error: pthread_create\n"); return 1; }
+        j->dist = dist; j->plan = &w->plan; j->dev_blob = blobs[r];
+        TRY(mbn_shard_range(batch, gpus, r, &j->first, &j->count));
+        j->logits = malloc((size_t)(j->count > 0 ? j->count : 1) * w->plan.classes * sizeof(float));
+        if (!j->logits) goto done;
     }
+    rc = mbn_run_ranks(gpus, gpu_rank, jobs, -1, NULL);          /* one thread per GPU, gate + cancellable barrier (mbn_ranks.c) */
+    if (rc != MBN_OK) { fprintf(stderr, "Error: a rank failed: %s\n", mbn_strerror(rc)); goto done; }
     double worst = 0.0;
-    int bad = 0;
-    for (int r = 0; r < gpus; r++) {
-        pthread_join(th[r], NULL);
-        if (jobs[r].rc != MBN_OK) bad = 1;
+    for (int r = 0; r < gpus; r++)
         if (jobs[r].seconds > worst) worst = jobs[r].seconds;
+    for (int r = 0; r < gpus; r++)
+        printf("GPU %d: images [%d, %d) %d steps in %.6f s; first image -> class %d; logits fnv1a %016llx\n", r, jobs[r].first,
+               jobs[r].first + jobs[r].count, steps, jobs[r].seconds, jobs[r].top1, jobs[r].fnv);
+    printf("%d GPUs, batch %d (%s), %d steps: %.1f images/sec (slowest GPU %.6f s, %.3f ms/step)\n", gpus, batch,
+           "contiguous shards, weights broadcast once over RCCL", steps, (double)steps * batch / worst, worst,
+           1000.0 * worst / steps);
+    bad = 0;
+    if (verify) {
+        /* every shard again on GPU 0 — same images (global index), same call size, GPU 0's own copy of the blob — compared bit for
+         * bit with what the shard's GPU produced: a wrong broadcast, a wrong shard offset or a GPU that computes differently shows */
+        TRY(mbn_dist_context(dist, 0, &ctx));
+        for (int r = 0; r < gpus; r++) {
+            if (jobs[r].count <= 0) continue;
+            const size_t nb = (size_t)jobs[r].count * w->plan.classes * sizeof(float);
+            float *again = malloc(nb);
+            if (!again) { bad = 1; goto done; }
+            rc = shard_forward(ctx, &w->plan, blobs[0], res, jobs[r].first, jobs[r].count, 0, 1, again, NULL, NULL, NULL);
+            const int same = rc == MBN_OK && memcmp(again, jobs[r].logits, nb) == 0;
+            printf("verify: shard %d (GPU %d) vs the same images on GPU 0: %s (fnv1a %016llx)\n", r, r,
+                   rc != MBN_OK ? mbn_strerror(rc) : same ? "identical" : "DIFFERENT", rc == MBN_OK ? fnv1a(again, nb) : 0ULL);
+            free(again);
+            if (!same) bad = 1;
+        }
     }
-    pthread_barrier_destroy(&bar);
-    if (!bad) {
-        for (int r = 0; r < gpus; r++)
-            printf("GPU %d: images [%d, %d) %d steps in %.6f s; first image -> class %d\n", r, jobs[r].first,
-                   jobs[r].first + jobs[r].count, steps, jobs[r].seconds, jobs[r].top1);
-        printf("%d GPUs, batch %d (%s), %d steps: %.1f images/sec (slowest GPU %.6f s, %.3f ms/step)\n", gpus, batch,
-               "contiguous shards, weights broadcast once over RCCL", steps, (double)steps * batch / worst, worst,
-               1000.0 * worst / steps);
-    }
-    mbn_dist_shutdown(dist);                                    /* frees every buffer the contexts own */
-    free(blobs); free(jobs); free(th);
+#undef TRY
+done:
+    if (jobs)
+        for (int r = 0; r < gpus; r++) free(jobs[r].logits);
+    mbn_dist_shutdown(dist);                                    /* frees every buffer the contexts own, the communicators and the contexts */
+    free(blobs); free(jobs);
     return bad;
 }
 
@@ -274,7 +320,7 @@ int main(int argc, char **argv)
     if (argc == 3 && !strcmp(argv[1], "--inspect")) return inspect_h5(argv[2]);
     if (argc == 4 && !strcmp(argv[1], "--convert")) return convert_h5(argv[2], argv[3]);
     const char *h5 = NULL, *ppm = NULL, *wfile = "weights_c.txt", *image = "Cat_Image0.ppm";
-    int literal = 0, ref_args = 0, batch = 1, res = 224, have_seed = 0, gpus = 0, steps = 20, warmup = 3;
+    int literal = 0, ref_args = 0, batch = 1, res = 224, have_seed = 0, gpus = 0, steps = 20, warmup = 3, verify = 0;
     unsigned long long seed = 0;
     float alpha = 0.f;
     for (int i = 1; i < argc; i++) {
@@ -293,11 +339,12 @@ int main(int argc, char **argv)
             if (mbn_tune_set("pw_emul", atoi(argv[++i])) != MBN_OK || mbn_tune_set("pw_emul_static", 1) != MBN_OK) { fprintf(stderr, "bad --pw-emul\n"); return 2; }
         }
         else if (!strcmp(argv[i], "--warmup") && i + 1 < argc) warmup = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--verify")) verify = 1;
         else if (!strcmp(argv[i], "--literal")) literal = 1;
         else if (!strcmp(argv[i], "--ref-args")) ref_args = 1;
         else {
             fprintf(stderr, "usage: %s [--h5 F | --synthetic SEED | --literal] [--ppm F] [--batch N] [--res R] [--alpha A] "
-                            "[--gpus G [--steps K] [--warmup W] [--streams S] [--pw-emul 6]]\n", argv[0]);
+                            "[--gpus G [--steps K] [--warmup W] [--streams S] [--pw-emul 6] [--verify]]\n", argv[0]);
             return 2;
         }
     }
@@ -316,7 +363,7 @@ int main(int argc, char **argv)
         mbn_weights wm;
         CHECK(mbn_weights_from_h5(h5, alpha, res, &wm));
         if (h5 == tmpm) remove(tmpm);
-        int rc = run_multi(gpus, batch, res, steps, warmup, &wm);
+        int rc = run_multi(gpus, batch, res, steps, warmup, &wm, verify);
         mbn_weights_free(&wm);
         return rc;
     }

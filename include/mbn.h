@@ -505,6 +505,18 @@ int  mbn_dist_sync(mbn_dist *dist);
 int  mbn_dist_shutdown(mbn_dist *dist);
 const char *mbn_dist_last_error(const mbn_dist *dist);
 int  mbn_shard_range(int total, int world, int rank, int *first, int *count);
+/* One host thread per rank, for callers that drive several GPUs from one process (`mobilenet --gpus G`): mbn_run_ranks starts
+ * n threads, opens a gate once ALL of them exist and runs fn(rank, arg, sync) in each; if a thread cannot be created nobody
+ * runs fn and the call returns MBN_ENOMEM (bare pthread_create + pthread_barrier would strand the started ranks in the
+ * barrier). Inside fn, mbn_rank_barrier(sync) is a barrier over the n ranks that returns MBN_EDEVICE instead of blocking once
+ * any rank has failed (fn returned != MBN_OK, or called mbn_rank_fail). Returns the first failing rank's code;
+ * rank_rc (may be NULL) receives every rank's (MBN_EUNSUPPORTED = its job did not run). fail_create_at >= 0 simulates a
+ * failed thread creation at that rank (tests). Host code only: also in libmbn_host.so. */
+typedef struct mbn_rank_sync mbn_rank_sync;
+typedef int (*mbn_rank_fn)(int rank, void *arg, mbn_rank_sync *sync);
+int  mbn_run_ranks(int n, mbn_rank_fn fn, void *arg, int fail_create_at, int *rank_rc);
+int  mbn_rank_barrier(mbn_rank_sync *sync);
+int  mbn_rank_fail(mbn_rank_sync *sync);
 
 const char *mbn_version(void);
 

@@ -64,3 +64,46 @@ def test_gloo_broadcast_and_sharded_forward(pkg, orc, tmp_path, world, total):
     assert [x["lo"] for x in res] == sorted(x["lo"] for x in res) and res[-1]["hi"] == total
     slow = {round(x["slowest"], 9) for x in res}
     assert len(slow) == 1 and abs(res[0]["slowest"] - max(x["dt"] for x in res)) < 1e-9   # MAX over ranks
+
+
+def test_rank_thread_skeleton_with_fake_jobs():
+    """mbn_run_ranks / mbn_rank_barrier (host/mbn_ranks.c), the thread skeleton of `mobilenet --gpus G`, with three fake jobs on
+    the CPU: (1) every rank runs and the barrier really separates the phases; (2) a thread that cannot be
+    created (simulated at rank 1 and at rank 2) makes the call fail with NO job run and without hanging (bare
+    pthread_create + pthread_barrier stranded the started ranks); (3) a rank that fails before the barrier releases its peers
+    with an error instead of leaving them blocked."""
+    import ctypes as C
+    import threading
+    import time
+    from mbn_amd import import_package
+    pkg = import_package()
+    lib = pkg.host_lib()
+    events, lock = [], threading.Lock()
+
+    def job(rank, arg, sync):
+        time.sleep(0.02 * (2 - rank))                      # rank 0 arrives last
+        with lock:
+            events.append(("a", rank))
+        if lib.mbn_rank_barrier(sync) != 0:
+            return pkg.EDEVICE
+        with lock:
+            events.append(("b", rank))
+        return 0
+    fn = pkg.RANK_FN(job)
+    rcs = (C.c_int * 3)()
+    assert lib.mbn_run_ranks(3, fn, None, -1, rcs) == 0 and list(rcs) == [0, 0, 0]
+    assert sorted(events[:3]) == [("a", 0), ("a", 1), ("a", 2)] and sorted(events[3:]) == [("b", 0), ("b", 1), ("b", 2)]
+    for fail_at in (1, 2):
+        events.clear()
+        t0 = time.time()
+        assert lib.mbn_run_ranks(3, fn, None, fail_at, rcs) == pkg.ENOMEM
+        assert events == [] and list(rcs) == [pkg.EUNSUPPORTED] * 3 and time.time() - t0 < 5.0
+
+    def failing(rank, arg, sync):
+        if rank == 1:
+            return pkg.EIO                                   # leaves before the barrier
+        return lib.mbn_rank_barrier(sync)                    # must come back with an error, not block
+    t0 = time.time()
+    assert lib.mbn_run_ranks(3, pkg.RANK_FN(failing), None, -1, rcs) != 0
+    assert rcs[1] == pkg.EIO and rcs[0] == pkg.EDEVICE and rcs[2] == pkg.EDEVICE and time.time() - t0 < 5.0
+    assert lib.mbn_run_ranks(0, fn, None, -1, None) == pkg.EINVAL

@@ -1522,8 +1522,12 @@ def test_dist_single_gpu_path_and_c_host_gpus_mode(pkg, ctx, tmp_path):
     assert lib.mbn_dist_sync(d) == 0 and lib.mbn_dist_shutdown(d) == 0
     exe = os.path.join(pkg.PKG_DIR, "mobilenet")
     out = subprocess.run([exe, "--gpus", "1", "--batch", "5", "--synthetic", "3", "--alpha", "0.25", "--res", "96",
-                          "--steps", "3", "--warmup", "1"], capture_output=True, text=True, timeout=300)
+                          "--steps", "3", "--warmup", "1", "--verify"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
+    # per-shard checksum of the logits, and --verify: the shard replayed on GPU 0 is bit-identical (here the shard's GPU is GPU 0)
+    ck = re.search(r"logits fnv1a ([0-9a-f]{16})", out.stdout)
+    vf = re.search(r"verify: shard 0 \(GPU 0\) vs the same images on GPU 0: identical \(fnv1a ([0-9a-f]{16})\)", out.stdout)
+    assert ck and vf and ck.group(1) == vf.group(1), out.stdout
     m = re.search(r"GPU 0: images \[0, 5\) 3 steps in ([0-9.]+) s; first image -> class (\d+)", out.stdout)
     assert m and 1 <= int(m.group(2)) <= 1000, out.stdout
     m = re.search(r"1 GPUs, batch 5 .* ([0-9.]+) images/sec", out.stdout)
