@@ -235,6 +235,102 @@ __global__ __launch_bounds__(64 * LD_WAVES) void lit_pointwise_dot_k(uint8_t *__
     }
 }
 
+// ------------------------------------------------------------------------------------------ 3x3 taps on v_dot4 (round 3)
+// SURVEY.md 8f-4 for the two 3x3 kernels (kernel.cl:16-50 convolute, :75-86 depthwise): the three taps of one filter ROW are
+// three adjacent bytes of a uint8 plane (x-1, x, x+1 — also at stride 2: 2x-1, 2x, 2x+1), so one unaligned dword load brings
+// them (and a fourth byte that meets a zero weight) and one v_dot4_i32_i8 replaces three load + multiply-add groups with their
+// index arithmetic. Preconditions, wave-uniform per output channel and checked in the kernel: the carry quirk off (channels
+// independent) and the channel's weights inside int8; per lane: all three taps of the row inside the image / the plane and the
+// fourth byte readable — otherwise that row takes the tap-by-tap path of lit_tap (image borders; LITERAL_INDEX at stride 2,
+// whose taps are two bytes apart). Bit-exact by the same modular identity as the pointwise path: x - 128 is x ^ 0x80 as int8,
+// and  sum w x = sum w (x - 128) + 128 sum w  (mod 2^32).
+struct RowW { int pk; int bias; bool fits; int w[3]; };     // packed int8 weights (byte 3 = 0), 128 * (w0 + w1 + w2), range check
+
+__device__ __forceinline__ RowW pack_row(const int *__restrict__ f)
+{
+    RowW r;
+    r.w[0] = f[0]; r.w[1] = f[1]; r.w[2] = f[2];
+    r.fits = r.w[0] >= -128 && r.w[0] <= 127 && r.w[1] >= -128 && r.w[1] <= 127 && r.w[2] >= -128 && r.w[2] <= 127;
+    r.pk = (r.w[0] & 0xff) | ((r.w[1] & 0xff) << 8) | ((r.w[2] & 0xff) << 16);
+    r.bias = 128 * (r.w[0] + r.w[1] + r.w[2]);
+    return r;
+}
+
+// sum += the three taps (i, -1..1) of one filter row. `plane` = first byte of the input plane, `limit` = bytes readable from it.
+__device__ __forceinline__ int row3(int sum, const uint8_t *__restrict__ plane, long limit, bool lit, int ty, int tx, int i,
+                                    int stride, int g0, int in_rows, int in_cols, const RowW &rw)
+{
+    long idx;
+    bool fast;
+    if (lit) {                                         // kernel.cl:24: in[(ty+i)*G0*stride + (tx+j)*stride], zero when ty+i < 0 or tx+j < 0
+        const int yi = ty + i, xi = tx - 1;
+        idx = (long)yi * g0 * stride + (long)xi * stride;
+        fast = stride == 1 && yi >= 0 && xi >= 0 && idx + 3 < limit;
+    } else {
+        const int iy = ty * stride + i, ix = tx * stride - 1;
+        idx = (long)iy * in_cols + ix;
+        fast = iy >= 0 && iy < in_rows && ix >= 0 && ix + 2 < in_cols && idx + 3 < limit;
+    }
+    if (fast && rw.fits) {
+        unsigned x;
+        __builtin_memcpy(&x, plane + idx, 4);          // unaligned dword load
+        return (int)((unsigned)__builtin_amdgcn_sdot4((int)(x ^ 0x80808080u), rw.pk, sum, false) + (unsigned)rw.bias);
+    }
+#pragma unroll
+    for (int j = -1; j <= 1; j++) sum = mac_i32(sum, lit_tap(plane, limit, lit, ty, tx, i, j, stride, g0, in_rows, in_cols), rw.w[j + 1]);
+    return sum;
+}
+
+__global__ __launch_bounds__(256) void lit_depthwise_dot_k(uint8_t *__restrict__ out, const uint8_t *__restrict__ in,
+                                                           const int *__restrict__ filt, int rows, int cols, int stride,
+                                                           int op_size, unsigned quirks, int g0, int g1, int in_rows, int in_cols)
+{
+    const bool lit = quirks & MBN_Q_LITERAL_INDEX, plane0 = quirks & MBN_Q_DW_PLANE0;
+    const int n = blockIdx.z;
+    const long wi = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (wi >= (long)g0 * g1) return;
+    const int ty = (int)(wi / g0), tx = (int)(wi % g0);
+    const long in_plane = (long)in_rows * in_cols, total = in_plane * op_size, out_plane = (long)rows * cols;
+    const uint8_t *img = in + n * total;
+    uint8_t *o = out + n * out_plane * op_size + ((long)ty * g0 + tx);
+    // the channels are independent without the carry quirk: one grid row per channel (weights wave-uniform), not a serial loop in
+    // the lane — a 14 x 14 x 512 layer is 100 k work-items instead of 196 lanes with 512 iterations each
+    for (int oc = blockIdx.y; oc < op_size; oc += gridDim.y) {
+        const long base = plane0 ? 0 : in_plane * oc;
+        int sum = 0;
+#pragma unroll
+        for (int i = -1; i <= 1; i++)
+            sum = row3(sum, img + base, total - base, lit, ty, tx, i, stride, g0, in_rows, in_cols, pack_row(filt + oc * 9 + (i + 1) * 3));
+        if (sum <= 0) sum = 0;
+        o[out_plane * oc] = (uint8_t)sum;
+    }
+}
+
+__global__ __launch_bounds__(256) void lit_convolute_dot_k(uint8_t *__restrict__ out, const uint8_t *__restrict__ r,
+                                                           const uint8_t *__restrict__ g, const uint8_t *__restrict__ b,
+                                                           const int *__restrict__ filt, int rows, int cols, int stride, int op_size,
+                                                           unsigned quirks, int g0, int g1, long out_plane, long in_image, long out_image)
+{
+    const bool lit = quirks & MBN_Q_LITERAL_INDEX;
+    const int n = blockIdx.z;
+    const long wi = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (wi >= (long)g0 * g1) return;
+    const int ty = (int)(wi / g0), tx = (int)(wi % g0);
+    const uint8_t *planes[3] = { r + n * in_image, g + n * in_image, b + n * in_image };
+    const long limit = (long)rows * cols;
+    uint8_t *o = out + n * out_image + ((long)ty * g0 + tx);
+    for (int oc = blockIdx.y; oc < op_size; oc += gridDim.y) {
+        int sum = 0;
+#pragma unroll
+        for (int p = 0; p < 3; p++)
+#pragma unroll
+            for (int i = -1; i <= 1; i++)
+                sum = row3(sum, planes[p], limit, lit, ty, tx, i, stride, g0, rows, cols, pack_row(filt + oc * 27 + p * 9 + (i + 1) * 3));
+        if (sum <= 0) sum = 0;
+        o[out_plane * oc] = (uint8_t)sum;
+    }
+}
+
 }   // namespace
 
 // The emulated NDRange must not make two work-items write one byte (the reference's 224x224 launch over a
@@ -258,6 +354,13 @@ int mbn_launch_lit_convolute(const mbn_call &c, uint8_t *out, const uint8_t *r, 
     int rc = check_gsize(g0, g1, ocol, orow, out_plane);
     if (rc) return rc;
     dim3 grid((unsigned)(((long)g0 * g1 + 255) / 256), 1, c.batch);
+    // 3x3 without the carry quirk: filter rows on v_dot4 (tune lit_dot = 1 keeps the tap-by-tap kernel)
+    if (fs == 3 && !(c.quirks & MBN_Q_CARRY_SUM) && g_mbn_tune.lit_dot != 1) {
+        grid.y = (unsigned)(op_size < 65535 ? op_size : 65535);
+        hipLaunchKernelGGL(lit_convolute_dot_k, grid, dim3(256), 0, c.stream, out, r, g, b, filt, rows, cols, stride, op_size, c.quirks,
+                           g0, g1, out_plane, (long)rows * cols, out_plane * op_size);
+        return MBN_OK;
+    }
     hipLaunchKernelGGL(lit_convolute_k, grid, dim3(256), 0, c.stream, out, r, g, b, filt, rows, cols, fs, stride,
                        op_size, c.quirks, g0, g1, out_plane, (long)rows * cols, out_plane * op_size);
     return MBN_OK;
@@ -270,6 +373,12 @@ int mbn_launch_lit_depthwise(const mbn_call &c, uint8_t *out, const uint8_t *in,
     int rc = check_gsize(g0, g1, cols, rows, (long)rows * cols);
     if (rc) return rc;
     dim3 grid((unsigned)(((long)g0 * g1 + 255) / 256), 1, c.batch);
+    if (fs == 3 && !(c.quirks & MBN_Q_CARRY_SUM) && g_mbn_tune.lit_dot != 1) {
+        grid.y = (unsigned)(op_size < 65535 ? op_size : 65535);
+        hipLaunchKernelGGL(lit_depthwise_dot_k, grid, dim3(256), 0, c.stream, out, in, filt, rows, cols, stride, op_size, c.quirks,
+                           g0, g1, c.in_rows, c.in_cols);
+        return MBN_OK;
+    }
     hipLaunchKernelGGL(lit_depthwise_k, grid, dim3(256), 0, c.stream, out, in, filt, rows, cols, fs, stride, op_size,
                        c.quirks, g0, g1, c.in_rows, c.in_cols);
     return MBN_OK;

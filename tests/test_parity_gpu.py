@@ -51,6 +51,52 @@ def test_literal_depthwise(pkg, orc, ctx, quirks, shape):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("quirks", [0x0, 0x2, 0x4, 0x6])
+@pytest.mark.parametrize("case", [(112, 32, 1, 3), (56, 24, 2, 3), (9, 7, 1, 127), (14, 16, 2, 128), (10, 5, 1, 300)])
+def test_literal_3x3_rows_on_dot4_are_bit_exact(pkg, orc, ctx, quirks, case):
+    """Round 3: without the carry quirk the filter rows of `depthwise` and `convolute` (kernel.cl:75-86, 16-50) run
+    on v_dot4_i32_i8 — one unaligned dword per filter row, x ^ 0x80 as int8 plus 128 * sum(w). Bit for bit against the oracle and
+    against the tap-by-tap kernels (tune lit_dot = 1): image borders (tap-by-tap rows), weights at the int8 limits (+-127/-128),
+    weights outside int8 (the channel falls back), DW_PLANE0 / LITERAL_INDEX at stride 1 (dot) and 2 (dilated taps: fallback)."""
+    rows, ch, stride, wmax = case
+    rng = np.random.default_rng(rows * 31 + ch + quirks + wmax)
+    in_rows = rows * stride
+    x = rng.integers(0, 256, (ch, in_rows, in_rows), dtype=np.uint8)
+    f = rng.integers(-wmax - 1 if wmax >= 127 else -wmax, wmax + 1, (ch, 3, 3), dtype=np.int32)
+    if wmax == 127:
+        f[0] = 127; f[1 % ch] = -128
+    want = orc.lit_depthwise(x, f, rows, rows, 3, stride, ch, quirks=quirks)
+    d_x, d_f, d_o = ctx.to_device(x), ctx.to_device(f), ctx.alloc(ch * rows * rows)
+    ext = pkg.make_ext(dtype=pkg.DT_U8, quirks=quirks)
+    outs = []
+    try:
+        for mode in (0, 1):
+            assert ctx.lib.mbn_tune_set(b"lit_dot", mode) == 0
+            ctx.lib.mbn_memset(ctx.h, d_o.ptr, 0, ch * rows * rows)
+            ctx.depthwise(d_o.ptr, d_x.ptr, d_f.ptr, rows, rows, 3, stride, ch, ext)
+            ctx.sync()
+            outs.append(d_o.download((ch * rows * rows,), np.uint8))
+    finally:
+        ctx.lib.mbn_tune_set(b"lit_dot", 0)
+    assert np.array_equal(outs[0], want) and np.array_equal(outs[1], want)
+    # first conv: three planes, stride 2
+    oc = min(ch, 12)
+    r, g, b = (rng.integers(0, 256, in_rows * in_rows, dtype=np.uint8) for _ in range(3))
+    fc = rng.integers(-wmax - 1 if wmax >= 127 else -wmax, wmax + 1, (oc, 3, 3, 3), dtype=np.int32)
+    qc = quirks & ~0x2                                           # DW_PLANE0 is a depthwise quirk
+    wantc = orc.lit_convolute(r, g, b, fc, in_rows, in_rows, 3, 2, oc, quirks=qc)
+    d = [ctx.to_device(a) for a in (r, g, b, fc)]
+    d_oc = ctx.alloc(wantc.size)
+    try:
+        for mode in (0, 1):
+            assert ctx.lib.mbn_tune_set(b"lit_dot", mode) == 0
+            ctx.convolute(d_oc.ptr, d[0].ptr, d[1].ptr, d[2].ptr, d[3].ptr, in_rows, in_rows, 3, 2, oc, pkg.make_ext(dtype=pkg.DT_U8, quirks=qc))
+            ctx.sync()
+            assert np.array_equal(d_oc.download(wantc.shape, np.uint8), wantc), mode
+    finally:
+        ctx.lib.mbn_tune_set(b"lit_dot", 0)
+
+
 def test_literal_depthwise_null_ext_is_kernel_cl(pkg, orc, ctx):
     """ext == NULL => the context default = MBN_QUIRKS_KERNEL_CL (what kernel.cl computes in bounds)."""
     rng = np.random.default_rng(5)

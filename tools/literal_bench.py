@@ -29,3 +29,41 @@ for name, rows, cin, oc in (("L3", 112, 32, 64), ("L7", 56, 128, 128), ("L11", 2
     lib.mbn_tune_set(b"lit_dot", 0)
     print("%-34s %12.4f %12.4f %7.1fx %10.1f" % ("%s  %dx%d %d -> %d" % (name, rows, rows, cin, oc), t[1], t[0], t[1] / t[0],
                                                  rows * rows * cin * oc / t[0] / 1e6))
+
+print()
+print("%-34s %12s %12s %8s" % ("3x3 layer, quirks off", "tap-by-tap ms", "v_dot4 ms", "speedup"))
+for name, rows, ch, stride in (("L2 depthwise", 112, 32, 1), ("L4 depthwise", 56, 64, 2), ("L6 depthwise", 56, 128, 1), ("L14 depthwise", 14, 512, 1), ("L26 depthwise", 7, 1024, 1)):
+    x = rng.integers(0, 256, (ch, rows * stride, rows * stride), dtype=np.uint8)
+    f = rng.integers(-4, 5, (ch, 3, 3), dtype=np.int32)
+    d_x, d_f, d_o = ctx.to_device(x), ctx.to_device(f), ctx.alloc(ch * rows * rows)
+    ext = pkg.make_ext(dtype=pkg.DT_U8, quirks=0)
+    t = {}
+    for mode in (1, 0):
+        lib.mbn_tune_set(b"lit_dot", mode)
+        for _ in range(3):
+            ctx.depthwise(d_o.ptr, d_x.ptr, d_f.ptr, rows, rows, 3, stride, ch, ext)
+        ctx.sync()
+        reps = 10
+        ctx.profile_begin(reps)
+        for _ in range(reps):
+            ctx.depthwise(d_o.ptr, d_x.ptr, d_f.ptr, rows, rows, 3, stride, ch, ext)
+        t[mode] = float(np.median(ctx.profile_end(reps)))
+    lib.mbn_tune_set(b"lit_dot", 0)
+    print("%-34s %12.4f %12.4f %7.1fx" % ("%s  %dx%d x%d s%d" % (name, rows, rows, ch, stride), t[1], t[0], t[1] / t[0]))
+r, g, b = (rng.integers(0, 256, 224 * 224, dtype=np.uint8) for _ in range(3))
+f = rng.integers(-4, 5, (32, 3, 3, 3), dtype=np.int32)
+d = [ctx.to_device(a) for a in (r, g, b, f)]
+d_o = ctx.alloc(112 * 112 * 32)
+t = {}
+for mode in (1, 0):
+    lib.mbn_tune_set(b"lit_dot", mode)
+    reps = 10
+    for _ in range(3):
+        ctx.convolute(d_o.ptr, d[0].ptr, d[1].ptr, d[2].ptr, d[3].ptr, 224, 224, 3, 2, 32, pkg.make_ext(dtype=pkg.DT_U8, quirks=0))
+    ctx.sync()
+    ctx.profile_begin(reps)
+    for _ in range(reps):
+        ctx.convolute(d_o.ptr, d[0].ptr, d[1].ptr, d[2].ptr, d[3].ptr, 224, 224, 3, 2, 32, pkg.make_ext(dtype=pkg.DT_U8, quirks=0))
+    t[mode] = float(np.median(ctx.profile_end(reps)))
+lib.mbn_tune_set(b"lit_dot", 0)
+print("%-34s %12.4f %12.4f %7.1fx" % ("L1 convolute 224x224x3 -> 32", t[1], t[0], t[1] / t[0]))
