@@ -602,6 +602,8 @@ int mbn_launch_f32_pointwise(const mbn_call &c, void *out, const void *in, const
         case 4: launch_cfg<__bf16, 256, 128, 64, 64>(a, c.stream, cus); break;   // 8 waves of 64x64, 96 KB
         case 7: launch_cfg<__bf16, 128, 64, 32, 32>(a, c.stream, cus); break;    // 8 waves of 32x32, 48 KB LDS: 3 WG = 24 waves per CU
         case 8: launch_cfg<__bf16, 64, 128, 32, 32>(a, c.stream, cus); break;
+        case 9: launch_cfg<__bf16, 256, 256, 64, 64>(a, c.stream, cus); break;   // r3: 16 waves of 64x64, 136 KB LDS: half the L2 -> LDS bytes per flop of 128x128
+        case 10: launch_cfg<__bf16, 256, 256, 128, 64>(a, c.stream, cus); break; // r3: 8 waves of 128x64
 #endif
         default: return MBN_EUNSUPPORTED;
         }

@@ -180,11 +180,14 @@ __global__ __launch_bounds__(256, WPE) void stem_fused_f32(StemArgs a)
     constexpr int PC = 128 * Q1 / 256;             // depthwise pixels per lane (4 / 2)
     constexpr int NI = C3 / 32;                    // 32-column blocks of the pointwise output (2 / 1)
     constexpr int KG = C1 / 8;                     // fp32 MFMA k-groups of 8 (4 / 2)
+    // fp32 alpha = 1 at three workgroups per CU: the pointwise filter's MFMA fragments (the same 8 float4 per lane for every tile) live in
+    // 32 VGPRs instead of an 8 KB LDS tile — with the taps in LDS (WDL) that is 52.7 KB and <= 168 VGPRs: a third workgroup fits
+    constexpr bool BREG = !BF && X6 == 0 && WPE >= 3 && C1 == 32;
     __shared__ __attribute__((aligned(16))) float in_s[PR * PROW + PROWPAD]; //  9.4 KB
     __shared__ __attribute__((aligned(16))) float w1_s[27 * C1];          //  3.4 KB
     __shared__ __attribute__((aligned(16))) float c1_s[CR * CC * C1];     // 22.5 KB
     __shared__ __attribute__((aligned(16))) float a_s[X6 ? 3 * APL : TH * TW * C1 / (BF ? 2 : 1)];   // 16 KB (fp32, C1 = 32) ... 4 KB (bf16, C1 = 16); X6: three bf16 planes, 24 KB
-    __shared__ __attribute__((aligned(16))) float b_s[X6 ? 3 * BPL : C3 * C1 / (BF ? 2 : 1)];        //  8 KB ... 1 KB; X6: 12 KB
+    __shared__ __attribute__((aligned(16))) float b_s[BREG ? 4 : X6 ? 3 * BPL : C3 * C1 / (BF ? 2 : 1)];        //  8 KB ... 1 KB; X6: 12 KB; BREG: none
     __shared__ __attribute__((aligned(16))) float sb_s[4 * C1];           // s1 | b1 | s2 | b2
     __shared__ __attribute__((aligned(16))) float wd_s[WDL ? 9 * C1 : 4]; // depthwise taps [ky][kx][C1] (WDL)
 
@@ -214,10 +217,17 @@ __global__ __launch_bounds__(256, WPE) void stem_fused_f32(StemArgs a)
             *reinterpret_cast<u4e *>(b_s + BPL + swzb<C1>(row, slot)) = u4e{ mw[0], mw[1], mw[2], mw[3] };
             *reinterpret_cast<u4e *>(b_s + 2 * BPL + swzb<C1>(row, slot)) = u4e{ lw[0], lw[1], lw[2], lw[3] };
         }
-    } else
+    } else if constexpr (!BREG)
     for (int i = tid; i < C3 * Q1; i += 256) {                            // pointwise filter [C3][C1] -> swizzled B tile
         const int row = i / Q1, ch = i % Q1;
         *reinterpret_cast<f4 *>(b_s + swz<C1>(row, ch)) = *reinterpret_cast<const f4 *>(a.wp + row * C1 + ch * 4);
+    }
+    [[maybe_unused]] f4 bfr[BREG ? KG : 1][NI];                           // BREG: filter rows ni*32 + li, k = 8g + 4lh .. +3
+    if constexpr (BREG) {
+#pragma unroll
+        for (int g = 0; g < KG; g++)
+#pragma unroll
+            for (int ni = 0; ni < NI; ni++) bfr[g][ni] = *reinterpret_cast<const f4 *>(a.wp + (ni * 32 + (tid & 31)) * C1 + (2 * g + ((tid & 63) >> 5)) * 4);
     }
     if (tid < 4 * C1) {
         const float *src = tid < C1 ? a.s1 : tid < 2 * C1 ? a.b1 : tid < 3 * C1 ? a.s2 : a.b2;
@@ -491,13 +501,16 @@ __global__ __launch_bounds__(256, WPE) void stem_fused_f32(StemArgs a)
             const f4 av = *reinterpret_cast<const f4 *>(a_s + swz<C1>(wave * 32 + li, chunk));
             f4 bv[NI];
 #pragma unroll
-            for (int ni = 0; ni < NI; ni++) bv[ni] = *reinterpret_cast<const f4 *>(b_s + swz<C1>(ni * 32 + li, chunk));
+            for (int ni = 0; ni < NI; ni++) {
+                if constexpr (BREG) bv[ni] = bfr[g][ni];
+                else bv[ni] = *reinterpret_cast<const f4 *>(b_s + swz<C1>(ni * 32 + li, chunk));
+            }
 #pragma unroll
             for (int s = 0; s < 4; s++)
 #pragma unroll
                 for (int ni = 0; ni < NI; ni++) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[ni][s], acc[ni], 0, 0, 0);
         }
-        if constexpr (C1 == 32) {
+        if constexpr (C1 == 32 && !BREG) {
             // alpha = 1 in fp32 keeps plain global stores: the buffer-store form below measured 1.2 % SLOWER here (0.3077 against 0.3040 ms,
             // same call, three repetitions) although it drops ~80 address instructions and 32 VGPRs; it wins at alpha = 0.5 (-6 %) and in bf16
             float *obase = a.out + ((n * a.h + TH * ty) * a.h + TW * tx) * C3;
@@ -562,6 +575,16 @@ int mbn_launch_f32_stem(mbn_context *ctx, hipStream_t stream, float *out, const 
         if (bf16) hipLaunchKernelGGL((stem_fused_f32<32, 64, true, 3, true>), g, b, 0, stream, a);   // conv1 on the bf16 MFMA, three workgroups per CU
         else if (g_mbn_tune.pw_emul == 6) hipLaunchKernelGGL((stem_fused_f32<32, 64, false, 2, false, 6>), g, b, 0, stream, a);   // opt-in split products in phase D
         else if (g_mbn_tune.pw_emul == 9) hipLaunchKernelGGL((stem_fused_f32<32, 64, false, 2, false, 9>), g, b, 0, stream, a);
+#ifdef MBN_LAB
+        // r3 A/B (profiles/r03/k_stem_three_workgroups.txt): the fp32 alpha = 1 stem at three workgroups per CU — filter fragments in 32 VGPRs instead of
+        // the 8 KB LDS tile, taps in LDS, buffer stores: 52.7 KB, 156 VGPRs. SLOWER: 0.370 ms against 0.307 (that kernel on a 2-per-CU grid,
+        // conv_variant = 4: 0.338): the leaner code costs 10 % and the third workgroup another 10 %; not shipped
+        else if (g_mbn_tune.conv_variant == 3 || g_mbn_tune.conv_variant == 4) {
+            long g3 = (long)ctx->num_cus * (g_mbn_tune.conv_variant == 3 ? 3 : 2);
+            if (g3 > (long)a.ntiles) g3 = (long)a.ntiles;
+            hipLaunchKernelGGL((stem_fused_f32<32, 64, false, 3>), dim3((unsigned)g3), b, 0, stream, a);
+        }
+#endif
         else hipLaunchKernelGGL((stem_fused_f32<32, 64, false, 2>), g, b, 0, stream, a);
     } else {
 #ifdef MBN_LAB
