@@ -38,14 +38,27 @@ typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf2e __attribute__((ext_vector_type(2)));
 typedef mbn_f16v f16v;
 
-constexpr int BM = 128, BN = 128, BKE = 64, BKF = 32;      // k-tile: 64 bf16 = 128-byte rows = 32 LDS words
-constexpr int NT = 512;
-constexpr int WM = 32, WN = 64, NI = 2, WAVES_N = BN / WN;
-constexpr int ASLOTS = 3, BSLOTS = 2;
-constexpr int AF = BM * BKF, BF_ = BN * BKF;               // floats per A / B slot (16 KB each)
-constexpr int LDP = 2;                                     // 16-byte pieces per lane per operand per k-tile
-constexpr int NST = 16;                                    // store instructions per lane per epilogue
+constexpr int BKE = 64, BKF = 32;                          // k-tile: 64 bf16 = 128-byte rows = 32 LDS words
+constexpr int LDP = 2;                                     // 16-byte pieces per lane per operand per k-tile (both tile shapes)
 constexpr unsigned OOB = 0xF0000000u;                      // a buffer offset past every tensor in the envelope (< 3.75 GiB): the load is dropped
+
+// Two shapes of the same kernel:
+//   <128,128,32,64,3,4>  the form described above: 8 waves, 80 KB, two workgroups per CU
+//   <256,256,64,64,2,4>  "big tile" (round 3): 16 waves of 64 x 64 on a 256 x 256 tile, two slots per operand (128 KB, one workgroup per
+//                        CU, still 4 waves per SIMD). A 128 x 128 tile moves (128+128) x 128 B through the CU's 64 B/clk L1 path per
+//                        1024 MFMA cycles per SIMD — the path is as busy as the matrix pipe, and the K >= 512 layers sit on BOTH limits
+//                        (profiles/r03/d_l2_to_cu_fill_rate.txt, b_bf16_stream_gemm.txt); 256 x 256 halves the bytes per flop.
+template <int BM_, int BN_, int WM_, int WN_, int ASLOTS_>
+struct Shape {
+    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, ASLOTS = ASLOTS_, BSLOTS = 2;
+    static constexpr int MI = WM / 32, NI = WN / 32, WAVES_N = BN / WN;
+    static constexpr int NT = 64 * (BM / WM) * WAVES_N;
+    static constexpr int AF = BM * BKF, BF_ = BN * BKF;       // floats per A / B slot
+    static constexpr int NST = 16 * MI;                       // store instructions per lane per epilogue
+    static constexpr int AHEAD = ASLOTS - 1;                  // k-tiles of activations in flight ahead of the compute cursor
+    static_assert(NI == 2, "channel-paired epilogue: two column blocks per wave");
+    static_assert(BM * 8 == LDP * NT && BN * 8 == LDP * NT, "two pieces per lane per operand");
+};
 
 struct StreamArgs {
     __bf16 *out;
@@ -71,6 +84,7 @@ __device__ __forceinline__ void stream_barrier()
     else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(VM_LEFT) : "memory");
 }
 
+template <int NT>
 __device__ __forceinline__ void dma2(__amdgpu_buffer_rsrc_t rsrc, float *slot, const unsigned (&voff)[LDP], int soff, int wave_u)
 {
 #pragma unroll
@@ -82,10 +96,12 @@ __device__ __forceinline__ void dma2(__amdgpu_buffer_rsrc_t rsrc, float *slot, c
 // ABL (lab build only; 0 in the shipped kernel): ablation bits for timing — results are wrong with any of them set.
 //   1 = no LDS-DMA in the steps (the ring keeps what the prologue loaded), 2 = no fragment reads (one set read before the loop),
 //   4 = no MFMAs, 8 = no barriers (the counted waits stay), 16 = no epilogue stores
-template <int ABL>
-__global__ __launch_bounds__(NT, 4) void pw_stream_bf16(StreamArgs a)
+template <typename SH, int ABL>
+__global__ __launch_bounds__(SH::NT, 4) void pw_stream_bf16(StreamArgs a)
 {
-    __shared__ __attribute__((aligned(16))) float lds[ASLOTS * AF + BSLOTS * BF_];      // 81 920 bytes: two workgroups per CU
+    constexpr int BM = SH::BM, BN = SH::BN, WM = SH::WM, WN = SH::WN, MI = SH::MI, NI = SH::NI, WAVES_N = SH::WAVES_N, NT = SH::NT;
+    constexpr int ASLOTS = SH::ASLOTS, BSLOTS = SH::BSLOTS, AF = SH::AF, BF_ = SH::BF_, NST = SH::NST, AHEAD = SH::AHEAD;
+    __shared__ __attribute__((aligned(16))) float lds[ASLOTS * AF + BSLOTS * BF_];      // 81 920 bytes: two workgroups per CU (131 072: one)
     float *const Bring = lds + ASLOTS * AF;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -148,7 +164,7 @@ __global__ __launch_bounds__(NT, 4) void pw_stream_bf16(StreamArgs a)
         }
     };
     auto issue_a = [&]() __attribute__((always_inline)) {
-        dma2(arsrc, lds + a_slot * AF, a_vo, a_kt * BKE * 2, wave_u);
+        dma2<NT>(arsrc, lds + a_slot * AF, a_vo, a_kt * BKE * 2, wave_u);
         if (++a_slot == ASLOTS) a_slot = 0;
         if (++a_kt == nk) {
             a_kt = 0;
@@ -157,7 +173,7 @@ __global__ __launch_bounds__(NT, 4) void pw_stream_bf16(StreamArgs a)
         }
     };
     auto issue_b = [&]() __attribute__((always_inline)) {
-        dma2(brsrc, Bring + b_slot * BF_, b_vo, b_kt * BKE * 2, wave_u);
+        dma2<NT>(brsrc, Bring + b_slot * BF_, b_vo, b_kt * BKE * 2, wave_u);
         b_slot ^= 1;
         if (++b_kt == nk) {
             b_kt = 0;
@@ -169,14 +185,16 @@ __global__ __launch_bounds__(NT, 4) void pw_stream_bf16(StreamArgs a)
     set_b_tile(b_vb);
     // prologue: B(0), A(0), A(1) — in this order, so that "everything up to B(i)" is one counted wait from the first step on
     issue_b();
-    issue_a();
-    issue_a();
+#pragma unroll
+    for (int q = 0; q < AHEAD; q++) issue_a();
 
-    f16v acc[NI];
+    f16v acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; mi++)
 #pragma unroll
     for (int ni = 0; ni < NI; ni++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) acc[ni][r] = 0.f;
+        for (int r = 0; r < 16; r++) acc[mi][ni][r] = 0.f;
     int cvb = blockIdx.x, cas = 0, cbs = 0;
     f4 fa_fix = f4{ 0.f, 0.f, 0.f, 0.f };
     if (ABL & 2) { stream_barrier<0>(); fa_fix = *reinterpret_cast<const f4 *>(lds + fr_a[0]); }
@@ -189,8 +207,8 @@ __global__ __launch_bounds__(NT, 4) void pw_stream_bf16(StreamArgs a)
         constexpr bool LAST = decltype(last_tag)::value;
         // younger than B(i) at this point: A(i+1) (issued behind B(i) in step i-1 / the prologue), then step i-1's stores
         if (ABL & 1) stream_barrier<0, !(ABL & 8)>();
-        else if (prev_end && !(ABL & 16)) stream_barrier<LDP + NST, !(ABL & 8)>();
-        else stream_barrier<LDP, !(ABL & 8)>();
+        else if (prev_end && !(ABL & 16)) stream_barrier<LDP * (AHEAD - 1) + NST, !(ABL & 8)>();
+        else stream_barrier<LDP * (AHEAD - 1), !(ABL & 8)>();
         f2e sc, sh;
         int n0 = 0;
         unsigned m0 = 0;
@@ -209,33 +227,38 @@ __global__ __launch_bounds__(NT, 4) void pw_stream_bf16(StreamArgs a)
         const float *As = lds + cas * AF, *Bs = Bring + cbs * BF_;
         if (++cas == ASLOTS) cas = 0;
         cbs ^= 1;
-        f4 fa[2], fb[2][NI];
+        f4 fa[2][MI], fb[2][NI];
         if (ABL & 2) {
 #pragma unroll
             for (int q = 0; q < 2; q++) {
-                fa[q] = fa_fix;
+#pragma unroll
+                for (int mi = 0; mi < MI; mi++) fa[q][mi] = fa_fix;
 #pragma unroll
                 for (int ni = 0; ni < NI; ni++) fb[q][ni] = fa_fix;
             }
         } else {
-        fa[0] = *reinterpret_cast<const f4 *>(As + fr_a[0]);
+#pragma unroll
+        for (int mi = 0; mi < MI; mi++) fa[0][mi] = *reinterpret_cast<const f4 *>(As + fr_a[0] + mi * 32 * BKF);
 #pragma unroll
         for (int ni = 0; ni < NI; ni++) fb[0][ni] = *reinterpret_cast<const f4 *>(Bs + fr_b[0] + ni * 32 * BKF);
         }
 #pragma unroll
         for (int g = 0; g < 4; g++) {
             if (g < 3 && !(ABL & 2)) {
-                fa[(g + 1) & 1] = *reinterpret_cast<const f4 *>(As + fr_a[g + 1]);
+#pragma unroll
+                for (int mi = 0; mi < MI; mi++) fa[(g + 1) & 1][mi] = *reinterpret_cast<const f4 *>(As + fr_a[g + 1] + mi * 32 * BKF);
 #pragma unroll
                 for (int ni = 0; ni < NI; ni++) fb[(g + 1) & 1][ni] = *reinterpret_cast<const f4 *>(Bs + fr_b[g + 1] + ni * 32 * BKF);
             }
             if (ABL & 4) {
-                asm volatile("" ::"v"(fa[g & 1]), "v"(fb[g & 1][0]), "v"(fb[g & 1][1]));      // keep the reads alive
+                asm volatile("" ::"v"(fa[g & 1][0]), "v"(fb[g & 1][0]), "v"(fb[g & 1][1]));      // keep the reads alive
             } else {
 #pragma unroll
+            for (int mi = 0; mi < MI; mi++)
+#pragma unroll
             for (int ni = 0; ni < NI; ni++)
-                acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, fa[g & 1]), __builtin_bit_cast(bf8, fb[g & 1][ni]),
-                                                                  acc[ni], 0, 0, 0);
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, fa[g & 1][mi]), __builtin_bit_cast(bf8, fb[g & 1][ni]),
+                                                                      acc[mi][ni], 0, 0, 0);
             }
         }
         prev_end = LAST;
@@ -245,10 +268,12 @@ __global__ __launch_bounds__(NT, 4) void pw_stream_bf16(StreamArgs a)
             const bool inside = (long)m0 + BM <= a.m;
             const unsigned lane_off = ((unsigned)(4 * lh) * (unsigned)a.n + (unsigned)(2 * li)) * 2u;
 #pragma unroll
+            for (int mi = 0; mi < MI; mi++)
+#pragma unroll
             for (int r = 0; r < 16; r++) {
-                const unsigned ro = m0 + wm + (r & 3) + 8 * (r >> 2);
-                const float v0 = fminf(fmaxf(fmaf(acc[0][r], sc.x, sh.x), 0.f), 6.f);
-                const float v1 = fminf(fmaxf(fmaf(acc[1][r], sc.y, sh.y), 0.f), 6.f);
+                const unsigned ro = m0 + wm + mi * 32 + (r & 3) + 8 * (r >> 2);
+                const float v0 = fminf(fmaxf(fmaf(acc[mi][0][r], sc.x, sh.x), 0.f), 6.f);
+                const float v1 = fminf(fmaxf(fmaf(acc[mi][1][r], sc.y, sh.y), 0.f), 6.f);
                 const unsigned v = __builtin_bit_cast(unsigned, bf2e{ (__bf16)v0, (__bf16)v1 });
                 const unsigned soff = (ro * (unsigned)a.n + (unsigned)(n0 + wn)) * 2u;
                 if (ABL & 16) asm volatile("" ::"v"(v));
@@ -256,9 +281,11 @@ __global__ __launch_bounds__(NT, 4) void pw_stream_bf16(StreamArgs a)
                 else __builtin_amdgcn_raw_buffer_store_b32(v, orsrc, lane_off + soff, 0, 0);
             }
 #pragma unroll
+            for (int mi = 0; mi < MI; mi++)
+#pragma unroll
             for (int ni = 0; ni < NI; ni++)
 #pragma unroll
-                for (int r = 0; r < 16; r++) acc[ni][r] = 0.f;
+                for (int r = 0; r < 16; r++) acc[mi][ni][r] = 0.f;
             cvb += gridDim.x;
         }
     };
@@ -270,17 +297,25 @@ __global__ __launch_bounds__(NT, 4) void pw_stream_bf16(StreamArgs a)
 
 }   // namespace
 
+typedef Shape<128, 128, 32, 64, 3> ShapeStd;
+typedef Shape<256, 256, 64, 64, 2> ShapeBig;
+
+static bool stream_common_ok(const mbn_call &c, const void *out, const void *in, const void *filt, long m, int cin, int op_size)
+{
+    if (c.dtype != MBN_DT_BF16 || (c.io_flags & (MBN_IO_OUT_F32 | MBN_IO_IN_F32)) || c.act != MBN_ACT_RELU6 || !c.scale || !c.shift) return false;
+    if (((uintptr_t)in % 16) != 0 || ((uintptr_t)filt % 16) != 0 || ((uintptr_t)out % 4) != 0 || ((uintptr_t)c.scale % 8) != 0 ||
+        ((uintptr_t)c.shift % 8) != 0)
+        return false;
+    if ((double)m * cin * 2 >= (double)OOB || (double)m * op_size * 2 >= 4294967296.0 || (double)op_size * cin * 2 >= (double)OOB) return false;
+    return true;
+}
+
 // MBN_OK when launched; MBN_EUNSUPPORTED when the shape is outside this kernel's envelope (the caller uses pw_gemm).
 int mbn_launch_bf16_pw_stream(const mbn_call &c, void *out, const void *in, const void *filt, long m, int cin, int op_size)
 {
-    if (c.dtype != MBN_DT_BF16 || (c.io_flags & (MBN_IO_OUT_F32 | MBN_IO_IN_F32)) || c.act != MBN_ACT_RELU6 || !c.scale || !c.shift)
-        return MBN_EUNSUPPORTED;
+    constexpr int BM = ShapeStd::BM, BN = ShapeStd::BN, NT = ShapeStd::NT;
+    if (!stream_common_ok(c, out, in, filt, m, cin, op_size)) return MBN_EUNSUPPORTED;
     if (cin < BKE || (cin % BKE) != 0 || op_size < BN || (op_size % BN) != 0 || m < 4 * BM) return MBN_EUNSUPPORTED;
-    if (((uintptr_t)in % 16) != 0 || ((uintptr_t)filt % 16) != 0 || ((uintptr_t)out % 4) != 0 || ((uintptr_t)c.scale % 8) != 0 ||
-        ((uintptr_t)c.shift % 8) != 0)
-        return MBN_EUNSUPPORTED;
-    if ((double)m * cin * 2 >= (double)OOB || (double)m * op_size * 2 >= 4294967296.0 || (double)op_size * cin * 2 >= (double)OOB)
-        return MBN_EUNSUPPORTED;
     StreamArgs a;
     a.out = (__bf16 *)out; a.in = (const __bf16 *)in; a.filt = (const __bf16 *)filt; a.scale = c.scale; a.shift = c.shift;
     a.m = m; a.k = cin; a.n = op_size;
@@ -293,18 +328,58 @@ int mbn_launch_bf16_pw_stream(const mbn_call &c, void *out, const void *in, cons
     if (grid > nwg) grid = nwg;
 #ifdef MBN_LAB
     switch (g_mbn_tune.exp1) {                                 // ablations (timing only)
-    case 1: hipLaunchKernelGGL(pw_stream_bf16<1>, dim3((unsigned)grid), dim3(NT), 0, c.stream, a); return MBN_OK;
-    case 2: hipLaunchKernelGGL(pw_stream_bf16<2>, dim3((unsigned)grid), dim3(NT), 0, c.stream, a); return MBN_OK;
-    case 3: hipLaunchKernelGGL(pw_stream_bf16<3>, dim3((unsigned)grid), dim3(NT), 0, c.stream, a); return MBN_OK;
-    case 4: hipLaunchKernelGGL(pw_stream_bf16<4>, dim3((unsigned)grid), dim3(NT), 0, c.stream, a); return MBN_OK;
-    case 8: hipLaunchKernelGGL(pw_stream_bf16<8>, dim3((unsigned)grid), dim3(NT), 0, c.stream, a); return MBN_OK;
-    case 16: hipLaunchKernelGGL(pw_stream_bf16<16>, dim3((unsigned)grid), dim3(NT), 0, c.stream, a); return MBN_OK;
-    case 6: hipLaunchKernelGGL(pw_stream_bf16<6>, dim3((unsigned)grid), dim3(NT), 0, c.stream, a); return MBN_OK;
-    case 7: hipLaunchKernelGGL(pw_stream_bf16<7>, dim3((unsigned)grid), dim3(NT), 0, c.stream, a); return MBN_OK;
-    case 5: hipLaunchKernelGGL(pw_stream_bf16<5>, dim3((unsigned)grid), dim3(NT), 0, c.stream, a); return MBN_OK;
+    case 1: hipLaunchKernelGGL((pw_stream_bf16<ShapeStd, 1>), dim3((unsigned)grid), dim3(NT), 0, c.stream, a); return MBN_OK;
+    case 2: hipLaunchKernelGGL((pw_stream_bf16<ShapeStd, 2>), dim3((unsigned)grid), dim3(NT), 0, c.stream, a); return MBN_OK;
+    case 3: hipLaunchKernelGGL((pw_stream_bf16<ShapeStd, 3>), dim3((unsigned)grid), dim3(NT), 0, c.stream, a); return MBN_OK;
+    case 4: hipLaunchKernelGGL((pw_stream_bf16<ShapeStd, 4>), dim3((unsigned)grid), dim3(NT), 0, c.stream, a); return MBN_OK;
+    case 8: hipLaunchKernelGGL((pw_stream_bf16<ShapeStd, 8>), dim3((unsigned)grid), dim3(NT), 0, c.stream, a); return MBN_OK;
+    case 16: hipLaunchKernelGGL((pw_stream_bf16<ShapeStd, 16>), dim3((unsigned)grid), dim3(NT), 0, c.stream, a); return MBN_OK;
+    case 6: hipLaunchKernelGGL((pw_stream_bf16<ShapeStd, 6>), dim3((unsigned)grid), dim3(NT), 0, c.stream, a); return MBN_OK;
+    case 7: hipLaunchKernelGGL((pw_stream_bf16<ShapeStd, 7>), dim3((unsigned)grid), dim3(NT), 0, c.stream, a); return MBN_OK;
+    case 5: hipLaunchKernelGGL((pw_stream_bf16<ShapeStd, 5>), dim3((unsigned)grid), dim3(NT), 0, c.stream, a); return MBN_OK;
     default: break;
     }
 #endif
-    hipLaunchKernelGGL(pw_stream_bf16<0>, dim3((unsigned)grid), dim3(NT), 0, c.stream, a);
+    hipLaunchKernelGGL((pw_stream_bf16<ShapeStd, 0>), dim3((unsigned)grid), dim3(NT), 0, c.stream, a);
+    return MBN_OK;
+}
+
+// Big-tile form: 256 x 256 tiles, one 16-wave workgroup per CU, for the first `rounds` x CUs tiles of the problem (whole rounds of the
+// persistent grid: a 4th round on 16 of 256 CUs would cost a whole tile time). *rows_done = the rows those tiles cover; the caller runs
+// the remaining rows [*rows_done, m) through pw_gemm. MBN_EUNSUPPORTED (and *rows_done = 0) outside the envelope.
+int mbn_launch_bf16_pw_big(const mbn_call &c, void *out, const void *in, const void *filt, long m, int cin, int op_size, long *rows_done)
+{
+    constexpr int BM = ShapeBig::BM, BN = ShapeBig::BN, NT = ShapeBig::NT;
+    *rows_done = 0;
+    if (!stream_common_ok(c, out, in, filt, m, cin, op_size)) return MBN_EUNSUPPORTED;
+    if (cin < 2 * BKE || (cin % BKE) != 0 || (op_size % BN) != 0) return MBN_EUNSUPPORTED;
+    const int nt = op_size / BN;
+    const long mt = m / BM;                                 // whole row tiles only
+    const long cus = c.ctx->num_cus;
+    long tiles = (mt * nt / cus) * cus;                     // whole rounds
+    tiles -= tiles % nt;                                    // ... and whole row tiles
+    if (g_mbn_tune.exp0 == 99) tiles = mt * nt;             // lab: every whole tile, ragged last round included
+    if (tiles < cus) return MBN_EUNSUPPORTED;
+    StreamArgs a;
+    a.out = (__bf16 *)out; a.in = (const __bf16 *)in; a.filt = (const __bf16 *)filt; a.scale = c.scale; a.shift = c.shift;
+    a.m = (tiles / nt) * BM; a.k = cin; a.n = op_size;
+    a.mt = (int)(tiles / nt);
+    a.nt = nt;
+    *rows_done = a.m;
+#ifdef MBN_LAB
+    switch (g_mbn_tune.exp1) {                                 // ablations (timing only)
+    case 1: hipLaunchKernelGGL((pw_stream_bf16<ShapeBig, 1>), dim3((unsigned)cus), dim3(NT), 0, c.stream, a); return MBN_OK;
+    case 2: hipLaunchKernelGGL((pw_stream_bf16<ShapeBig, 2>), dim3((unsigned)cus), dim3(NT), 0, c.stream, a); return MBN_OK;
+    case 3: hipLaunchKernelGGL((pw_stream_bf16<ShapeBig, 3>), dim3((unsigned)cus), dim3(NT), 0, c.stream, a); return MBN_OK;
+    case 4: hipLaunchKernelGGL((pw_stream_bf16<ShapeBig, 4>), dim3((unsigned)cus), dim3(NT), 0, c.stream, a); return MBN_OK;
+    case 8: hipLaunchKernelGGL((pw_stream_bf16<ShapeBig, 8>), dim3((unsigned)cus), dim3(NT), 0, c.stream, a); return MBN_OK;
+    case 16: hipLaunchKernelGGL((pw_stream_bf16<ShapeBig, 16>), dim3((unsigned)cus), dim3(NT), 0, c.stream, a); return MBN_OK;
+    case 6: hipLaunchKernelGGL((pw_stream_bf16<ShapeBig, 6>), dim3((unsigned)cus), dim3(NT), 0, c.stream, a); return MBN_OK;
+    case 7: hipLaunchKernelGGL((pw_stream_bf16<ShapeBig, 7>), dim3((unsigned)cus), dim3(NT), 0, c.stream, a); return MBN_OK;
+    case 5: hipLaunchKernelGGL((pw_stream_bf16<ShapeBig, 5>), dim3((unsigned)cus), dim3(NT), 0, c.stream, a); return MBN_OK;
+    default: break;
+    }
+#endif
+    hipLaunchKernelGGL((pw_stream_bf16<ShapeBig, 0>), dim3((unsigned)cus), dim3(NT), 0, c.stream, a);
     return MBN_OK;
 }

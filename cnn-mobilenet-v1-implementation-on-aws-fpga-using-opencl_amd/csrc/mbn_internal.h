@@ -141,6 +141,7 @@ int mbn_launch_bf16_pw_wide(const mbn_call &c, void *out, const void *in, const 
 int mbn_launch_pack_filter_bf16(mbn_context *ctx, hipStream_t s, void *dst, const void *src, int n, int k);
 int mbn_bf16_pw_wide_eligible(long m, int cin, int op_size);
 int mbn_launch_bf16_pw_stream(const mbn_call &c, void *out, const void *in, const void *filt, long m, int cin, int op_size);
+int mbn_launch_bf16_pw_big(const mbn_call &c, void *out, const void *in, const void *filt, long m, int cin, int op_size, long *rows_done);
 int mbn_launch_f32_pool(const mbn_call &c, void *out, const void *in, int rows, int cols, int fs, int channels);
 // floor(v / d) == umulhi(v, *m) >> *s for every v < 2^31 (d >= 2); d == 1 gives *m = 0 (callers skip the multiply)
 static inline void mbn_udiv_magic(unsigned d, unsigned *m, unsigned *s)

@@ -1724,6 +1724,62 @@ def test_bf16_pointwise_wide_kernel(pkg, orc, ctx, shape):
         b.free()
 
 
+@pytest.mark.parametrize("shape", [(100352, 512, 512), (100352 + 77, 256, 512), (66000, 128, 256), (131072 + 300, 1024, 256), (40000, 512, 1024)])
+def test_bf16_pointwise_big_tile_kernel(pkg, orc, ctx, shape):
+    """The 256 x 256 form of mbn_bf16_pw_stream.hip (16 waves, two LDS slots per operand, one workgroup per CU) for whole rounds of the
+    persistent grid, the remaining rows through pw_gemm<bf16> in a second launch: against the oracle's bf16 emulation on sampled rows
+    (first and last rows of both launches included), no store past the output, bit for bit equal to the default path (same k-order of
+    the sums in every kernel), repeatable, and exact small integers through an asymmetric filter (operand maps, channel pairing, both
+    slots of both rings, every wave's 64 x 64 block)."""
+    _tune_lab(ctx, b"pw_ring", 7)
+    m, cin, cout = shape
+    rng = np.random.default_rng(m + cin + cout)
+    x = orc.bf16_round(rng.uniform(-1, 1, (m, cin)))
+    f = orc.bf16_round(rng.normal(0, (2.0 / cin) ** 0.5, (cout, cin)))
+    sc, sh = rng.uniform(0.5, 1.5, cout).astype(np.float32), rng.normal(0, 0.1, cout).astype(np.float32)
+    d_x, d_f, d_sc, d_sh = _bf16_dev(pkg, ctx, x), _bf16_dev(pkg, ctx, f), ctx.to_device(sc), ctx.to_device(sh)
+    d_o, d_p = ctx.alloc(m * cout * 2 + 64), ctx.alloc(m * cout * 2)
+    ext = pkg.make_ext(dtype=pkg.DT_BF16, act=2, scale=d_sc.ptr, shift=d_sh.ptr)
+    ctx.lib.mbn_memset(ctx.h, d_o.ptr, 0xFF, m * cout * 2 + 64)
+    ctx.pointwise(d_o.ptr, d_x.ptr, d_f.ptr, m, 1, cin, cout, ext)
+    ctx.sync()
+    raw = d_o.download((m * cout + 32,), np.uint16)
+    assert np.all(raw[m * cout:] == 0xFFFF), "stores past the output"
+    got = _bf16_get(pkg, d_o, (m, cout))
+    assert np.isfinite(got).all()
+    tiles = (m // 256) * (cout // 256)
+    split = (tiles // 256 * 256) // (cout // 256) * 256            # first row of the second launch
+    assert 0 < split <= m
+    rows = np.unique(np.concatenate([np.arange(0, 300), np.arange(max(0, split - 300), min(m, split + 300)), np.arange(m - 300, m), rng.integers(0, m, 1500)]))
+    ref = orc.bf16_round(orc.f32_pointwise(x[rows], f, sc, sh, 2))
+    assert_close(got[rows], ref, TOL_BF16, "big tile %s vs oracle" % (shape,))
+    ctx.pointwise(d_o.ptr, d_x.ptr, d_f.ptr, m, 1, cin, cout, ext)
+    ctx.sync()
+    assert np.array_equal(got, _bf16_get(pkg, d_o, (m, cout))), "not repeatable"
+    ctx.lib.mbn_tune_set(b"pw_ring", 0)
+    ctx.pointwise(d_p.ptr, d_x.ptr, d_f.ptr, m, 1, cin, cout, ext)
+    ctx.sync()
+    other = _bf16_get(pkg, d_p, (m, cout))
+    assert np.array_equal(got, other), "big tile vs default path %s: max diff %g" % (shape, np.abs(got - other).max())
+    _tune_lab(ctx, b"pw_ring", 7)
+    xi = rng.integers(-3, 4, (m, cin)).astype(np.float32)
+    fi = rng.integers(-2, 3, (cout, cin)).astype(np.float32)
+    fi[:, 0] = np.arange(cout) % 5
+    fi[:, cin - 1] = np.arange(cout) % 3
+    one, zero = ctx.to_device(np.ones(cout, np.float32)), ctx.to_device(np.zeros(cout, np.float32))
+    d_x.upload(pkg.f32_to_bf16_bits(xi))
+    d_f.upload(pkg.f32_to_bf16_bits(fi))
+    ctx.pointwise(d_o.ptr, d_x.ptr, d_f.ptr, m, 1, cin, cout, pkg.make_ext(dtype=pkg.DT_BF16, act=2, scale=one.ptr, shift=zero.ptr))
+    ctx.sync()
+    goti = _bf16_get(pkg, d_o, (m, cout))
+    for lo in (0, max(0, split - 2048), max(0, m - 4096)):
+        want = np.clip(xi[lo:lo + 4096].astype(np.float64) @ fi.astype(np.float64).T, 0, 6)
+        assert np.array_equal(goti[lo:lo + 4096].astype(np.float64), orc.bf16_round(want.astype(np.float32)).astype(np.float64))
+    ctx.lib.mbn_tune_set(b"pw_ring", 0)
+    for b in (d_x, d_f, d_sc, d_sh, d_o, d_p, one, zero):
+        b.free()
+
+
 @pytest.mark.parametrize("shape", [(196, 512, 512, 1), (49, 1024, 1024, 1), (4 * 196, 256, 512, 4), (3 * 49 , 512, 1024, 3), (1, 1024, 1000, 1),
                                    (4, 1024, 1000, 4), (2 * 25, 128, 256, 2), (37, 192, 40, 1), (100, 320, 72, 1), (2 * 81, 384, 104, 2)])
 def test_f32_pointwise_splitk_kernel(pkg, orc, ctx, shape):
