@@ -298,7 +298,9 @@ __global__ __launch_bounds__(SH::NT, 4) void pw_stream_bf16(StreamArgs a)
 }   // namespace
 
 typedef Shape<128, 128, 32, 64, 3> ShapeStd;
+#ifdef MBN_LAB
 typedef Shape<256, 256, 64, 64, 2> ShapeBig;
+#endif
 
 static bool stream_common_ok(const mbn_call &c, const void *out, const void *in, const void *filt, long m, int cin, int op_size)
 {
@@ -344,6 +346,8 @@ int mbn_launch_bf16_pw_stream(const mbn_call &c, void *out, const void *in, cons
     return MBN_OK;
 }
 
+#ifdef MBN_LAB
+// LAB ONLY (profiles/r03/l_bf16_big_tile_gemm.txt: no gain where the network would use it).
 // Big-tile form: 256 x 256 tiles, one 16-wave workgroup per CU, for the first `rounds` x CUs tiles of the problem (whole rounds of the
 // persistent grid: a 4th round on 16 of 256 CUs would cost a whole tile time). *rows_done = the rows those tiles cover; the caller runs
 // the remaining rows [*rows_done, m) through pw_gemm. MBN_EUNSUPPORTED (and *rows_done = 0) outside the envelope.
@@ -383,3 +387,4 @@ int mbn_launch_bf16_pw_big(const mbn_call &c, void *out, const void *in, const v
     hipLaunchKernelGGL((pw_stream_bf16<ShapeBig, 0>), dim3((unsigned)cus), dim3(NT), 0, c.stream, a);
     return MBN_OK;
 }
+#endif

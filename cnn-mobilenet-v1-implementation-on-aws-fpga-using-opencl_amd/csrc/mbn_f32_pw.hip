@@ -561,6 +561,7 @@ int mbn_launch_f32_pointwise(const mbn_call &c, void *out, const void *in, const
         mbn_launch_bf16_pw_wide(c, out, in, (const char *)filt + mbn_packed_filter_offset(op_size, cin), m, cin, op_size) == MBN_OK)
         return MBN_OK;
 #endif
+#ifdef MBN_LAB
     // big-tile form of the streaming kernel (256 x 256, one 16-wave workgroup per CU) for whole rounds of the grid; the rows it leaves
     // (less than one round) go through this function again and land on pw_gemm. Lab knob pw_ring = 7: wherever eligible.
     if (bf && ring_mode == 7 && g_mbn_tune.pw_tile == 0) {
@@ -571,6 +572,7 @@ int mbn_launch_f32_pointwise(const mbn_call &c, void *out, const void *in, const
             return MBN_OK;
         }
     }
+#endif
     // measured per layer at batch 512 (profiles/r03/b_bf16_stream_gemm.txt, same call, against pw_gemm<bf16>): K = 64 0.179 -> 0.116 ms,
     // K = 128 0.080 -> 0.076, K = 256 with N = 256 0.114 -> 0.100; K = 256 with N = 512 and every K >= 512 layer 0-5 % SLOWER (there the
     // L2 -> LDS operand stream of a 128 x 128 tile, not the look-ahead, is the limit: ablation in the same file) -> pw_gemm keeps those.
