@@ -19,7 +19,10 @@ def per_dispatch(d, counter):
     rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter and
             ("pw_gemm" in r["Kernel_Name"] or "pw_ring" in r["Kernel_Name"] or "pw_stream" in r["Kernel_Name"] or "pw_generic" in r["Kernel_Name"] or "dw3x3" in r["Kernel_Name"] or "dw_generic" in r["Kernel_Name"] or "conv3x3" in r["Kernel_Name"])]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-    return [(r["Kernel_Name"].split("(")[0][-60:], float(r["Counter_Value"])) for r in rows]
+    def label(n):      # "void (anonymous namespace)::pw_gemm<float, 64, ...>((anonymous namespace)::PwArgs)" -> "pw_gemm<float, 64, ...>"
+        n = n.replace("void ", "").replace("(anonymous namespace)::", "")
+        return n.split("(")[0][-72:]
+    return [(label(r["Kernel_Name"]), float(r["Counter_Value"])) for r in rows]
 
 
 def combine():
