@@ -66,6 +66,7 @@ struct StreamArgs {
     const float *scale, *shift;
     long m;
     int k, n, mt, nt;
+    int stag;       // lab (exp2): 1 = odd waves issue their LDS-DMA behind the second MFMA group instead of ahead of the first, 2 = all waves
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return (row << 5) + (((chunk ^ (row >> 1)) & 7) << 2); }
@@ -203,8 +204,9 @@ __global__ __launch_bounds__(SH::NT, 4) void pw_stream_bf16(StreamArgs a)
     // sequence is written as tiles x (nk-1 plain steps + one LAST step) so that the scale/shift registers are defined and
     // consumed inside one straight-line region: as loop-carried values of a single flattened loop the compiler's counter model
     // put s_waitcnt vmcnt(0) in front of every redefinition of them, i.e. drained the ring in every step (seen in the ISA).
-    auto step = [&](auto last_tag) __attribute__((always_inline)) {
+    auto step = [&](auto last_tag, auto late_tag) __attribute__((always_inline)) {
         constexpr bool LAST = decltype(last_tag)::value;
+        constexpr bool LATE = decltype(late_tag)::value;     // this wave issues the step's LDS-DMA behind MFMA group 1 (see the launcher)
         // younger than B(i) at this point: A(i+1) (issued behind B(i) in step i-1 / the prologue), then step i-1's stores
         if (ABL & 1) stream_barrier<0, !(ABL & 8)>();
         else if (prev_end && !(ABL & 16)) stream_barrier<LDP * (AHEAD - 1) + NST, !(ABL & 8)>();
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(SH::NT, 4) void pw_stream_bf16(StreamArgs a)
             sc = __builtin_bit_cast(f2e, __builtin_amdgcn_raw_buffer_load_b64(scrsrc, co, 0, 0));
             sh = __builtin_bit_cast(f2e, __builtin_amdgcn_raw_buffer_load_b64(shrsrc, co, 0, 0));
         }
-        if (!(ABL & 1)) {
+        if (!(ABL & 1) && !LATE) {
             issue_b();                                                   // B(i+1)
             issue_a();                                                   // A(i+2)
         }
@@ -260,6 +262,12 @@ __global__ __launch_bounds__(SH::NT, 4) void pw_stream_bf16(StreamArgs a)
                 acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, fa[g & 1][mi]), __builtin_bit_cast(bf8, fb[g & 1][ni]),
                                                                       acc[mi][ni], 0, 0, 0);
             }
+            if (LATE && g == 1 && !(ABL & 1)) {
+                __builtin_amdgcn_sched_barrier(0);
+                issue_b();
+                issue_a();
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         prev_end = LAST;
         if constexpr (LAST) {
@@ -289,9 +297,18 @@ __global__ __launch_bounds__(SH::NT, 4) void pw_stream_bf16(StreamArgs a)
             cvb += gridDim.x;
         }
     };
+#ifdef MBN_LAB
+    if (a.stag == 2 || (a.stag == 1 && (wave_u & 1))) {
+        for (int t = 0; t < ntile; t++) {
+            for (int kt = 0; kt + 1 < nk; kt++) step(std::false_type{}, std::true_type{});
+            step(std::true_type{}, std::true_type{});
+        }
+        return;
+    }
+#endif
     for (int t = 0; t < ntile; t++) {
-        for (int kt = 0; kt + 1 < nk; kt++) step(std::false_type{});
-        step(std::true_type{});
+        for (int kt = 0; kt + 1 < nk; kt++) step(std::false_type{}, std::false_type{});
+        step(std::true_type{}, std::false_type{});
     }
 }
 
@@ -320,7 +337,7 @@ int mbn_launch_bf16_pw_stream(const mbn_call &c, void *out, const void *in, cons
     if (cin < BKE || (cin % BKE) != 0 || op_size < BN || (op_size % BN) != 0 || m < 4 * BM) return MBN_EUNSUPPORTED;
     StreamArgs a;
     a.out = (__bf16 *)out; a.in = (const __bf16 *)in; a.filt = (const __bf16 *)filt; a.scale = c.scale; a.shift = c.shift;
-    a.m = m; a.k = cin; a.n = op_size;
+    a.m = m; a.k = cin; a.n = op_size; { const int e2 = g_mbn_tune.exp2; a.stag = e2 >= 98 ? 0 : e2; }
     a.mt = (int)((m + BM - 1) / BM);
     a.nt = op_size / BN;
     const long nwg = (long)a.mt * a.nt;
@@ -366,7 +383,7 @@ int mbn_launch_bf16_pw_big(const mbn_call &c, void *out, const void *in, const v
     if (tiles < cus) return MBN_EUNSUPPORTED;
     StreamArgs a;
     a.out = (__bf16 *)out; a.in = (const __bf16 *)in; a.filt = (const __bf16 *)filt; a.scale = c.scale; a.shift = c.shift;
-    a.m = (tiles / nt) * BM; a.k = cin; a.n = op_size;
+    a.m = (tiles / nt) * BM; a.k = cin; a.n = op_size; { const int e2 = g_mbn_tune.exp2; a.stag = e2 >= 98 ? e2 - 98 : e2; }   /* 98, 99, 100: stag 0, 1, 2 without the remainder launch */
     a.mt = (int)(tiles / nt);
     a.nt = nt;
     *rows_done = a.m;

@@ -567,7 +567,7 @@ int mbn_launch_f32_pointwise(const mbn_call &c, void *out, const void *in, const
     if (bf && ring_mode == 7 && g_mbn_tune.pw_tile == 0) {
         long done = 0;
         if (mbn_launch_bf16_pw_big(c, out, in, filt, m, cin, op_size, &done) == MBN_OK) {
-            if (done < m && g_mbn_tune.exp2 != 98)                                   // lab exp2 = 98: the big-tile launch alone (timing)
+            if (done < m && g_mbn_tune.exp2 < 98)                                    // lab exp2 >= 98: the big-tile launch alone (timing)
                 return mbn_launch_f32_pointwise(c, (char *)out + done * op_size * 2, (const char *)in + done * cin * 2, filt, m - done, cin, op_size);
             return MBN_OK;
         }
