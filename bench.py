@@ -96,14 +96,14 @@ def stage_table(plan, pkg, launches, layer_ms, batch, act_bytes, mfma_peak):
         by += (4.0 if last.kind == pkg.L_FC else act_bytes) * last.out_rows * last.out_cols * last.out_ch * batch
         return fl, by
     kind_name = {pkg.L_CONV: "conv1", pkg.L_DW: "depthwise", pkg.L_PW: "pointwise", pkg.L_POOL: "pool", pkg.L_FC: "fc"}
-    stage_of = ["stem_fused" if len(idx) == 3 else "block_fused" if len(idx) == 2 else kind_name[plan.layer[idx[0]].kind]
-                for idx in launches]
+    stage_of = ["stem_fused" if len(idx) == 3 else "tail_fused" if len(idx) == 2 and plan.layer[idx[0]].kind == pkg.L_POOL else
+                "block_fused" if len(idx) == 2 else kind_name[plan.layer[idx[0]].kind] for idx in launches]
     stages, per_layer = {}, []
     for j, idx in enumerate(launches):
         f, b = launch_work(idx)
         per_layer.append({"layers": [i + 1 for i in idx], "stage": stage_of[j], "ms": round(float(layer_ms[j]), 5),
                           "GBps": round(b / layer_ms[j] / 1e6, 1), "TFLOPs": round(f / layer_ms[j] / 1e9, 2)})
-    for name in ["stem_fused", "block_fused", "conv1", "depthwise", "pointwise", "pool", "fc"]:
+    for name in ["stem_fused", "block_fused", "conv1", "depthwise", "pointwise", "pool", "fc", "tail_fused"]:
         js = [j for j in range(len(launches)) if stage_of[j] == name]
         if not js:
             continue
@@ -118,8 +118,10 @@ def stage_table(plan, pkg, launches, layer_ms, batch, act_bytes, mfma_peak):
     if "stem_fused" in stages:
         stages["stem_fused"]["layers"] = "1-3 (conv1 + depthwise + pointwise in one kernel)"
     if "block_fused" in stages:
-        stages["block_fused"]["layers"] = ", ".join("%d-%d" % (idx[0] + 1, idx[1] + 1) for idx in launches if len(idx) == 2) \
+        stages["block_fused"]["layers"] = ", ".join("%d-%d" % (idx[0] + 1, idx[1] + 1) for j, idx in enumerate(launches) if stage_of[j] == "block_fused") \
                                           + " (depthwise + pointwise in one kernel each)"
+    if "tail_fused" in stages:
+        stages["tail_fused"]["layers"] = "28-29 (average pool + FC in one kernel: 1...4 images)"
     return stages, per_layer, stage_of
 
 
@@ -153,6 +155,7 @@ def parse_args(argv=None):
                     help="skip `configs_alt`: after the headline line (N = 1, default workload only) the other single-GPU BASELINE.json "
                          "configs are measured in the same process — configs[4] (bf16 1.0x224 and 0.5x160, batch 512) and configs[1] (batch 1)")
     ap.add_argument("--no-fuse-stem", action="store_true", help="run layers 1-3 as three launches instead of mbn_stem_fused")
+    ap.add_argument("--fuse-tail", action="store_true", help="1...4 images: pool and FC as one launch (mbn_pool_fc; off by default: measured slower)")
     ap.add_argument("--fuse-blocks", type=lambda v: int(v, 0), default=None,
                     help="mask for mbn_net_set_fuse_blocks (bit L = fuse depthwise layer L with pointwise L+1); default: library's")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -275,6 +278,8 @@ def run_one(args, env):
     net = pkg.Net(ctx, plan, blob_t.data_ptr(), args.batch)
     if args.no_fuse_stem:
         net.set_fuse_stem(False)
+    if args.fuse_tail:
+        net.set_fuse_tail(True)
     if args.fuse_blocks is not None:
         net.set_fuse_blocks(args.fuse_blocks)
     if args.graph:
@@ -465,6 +470,7 @@ def run_one(args, env):
                 net.set_streams(1)
             net.set_fuse_stem(False)
             net.set_fuse_blocks(0)
+            net.set_fuse_tail(False)
             ul = [list(range(f - 1, f - 1 + c)) for f, c in net.launches(args.batch)]
             for _ in range(2):
                 net.forward(d_in.ptr, d_out.ptr, args.batch)
@@ -479,6 +485,7 @@ def run_one(args, env):
                                              "mbn_net_set_fuse_blocks(0)); same batch, same buffers" % reps,
                                      "stages": ust, "layers": ulayers, "sum_kernel_ms": round(float(ums.sum()), 4)}
             net.set_fuse_stem(not args.no_fuse_stem)
+            net.set_fuse_tail(args.fuse_tail)
             if args.fuse_blocks is not None:
                 net.set_fuse_blocks(args.fuse_blocks)
             else:

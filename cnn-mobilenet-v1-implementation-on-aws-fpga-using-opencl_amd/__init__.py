@@ -181,6 +181,10 @@ def load():
         lib.mbn_net_set_fuse_blocks.argtypes = [vp, C.c_uint]
         lib.mbn_net_get_fuse_blocks.argtypes = [vp, C.POINTER(C.c_uint)]
         lib.mbn_net_reset_fuse_blocks.argtypes = [vp]
+        lib.mbn_net_set_fuse_tail.argtypes = [vp, ci]
+        lib.mbn_pool_fc_workspace_bytes.argtypes = [ci, ci]
+        lib.mbn_pool_fc_workspace_bytes.restype = C.c_size_t
+        lib.mbn_pool_fc.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, C.c_size_t, vp]
         lib.mbn_forget.argtypes = [vp, vp, C.c_size_t]
         lib.mbn_net_classify.argtypes = [vp, vp, ci, ci, vp, vp]
         lib.mbn_net_launches.argtypes = [vp, ci, ci, C.POINTER(ci), C.POINTER(ci), ci, C.POINTER(ci)]
@@ -466,6 +470,9 @@ class Net:
 
     def reset_fuse_blocks(self):
         _chk(self.ctx.lib.mbn_net_reset_fuse_blocks(self.h))
+
+    def set_fuse_tail(self, enabled=True):
+        _chk(self.ctx.lib.mbn_net_set_fuse_tail(self.h, int(enabled)))
 
     def get_fuse_blocks(self) -> int:
         m = C.c_uint()

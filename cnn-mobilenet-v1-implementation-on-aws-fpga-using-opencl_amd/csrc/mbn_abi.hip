@@ -722,6 +722,26 @@ int mbn_classifier_tail(mbn_context *ctx, void *topk_idx_i32, void *topk_prob_f3
     return mbn_softmax_topk_f32(ctx, probs, topk_idx_i32, topk_prob_f32, logits_scratch, batch, classes, k, stream);
 }
 
+size_t mbn_pool_fc_workspace_bytes(int channels, int classes)
+{
+    if (channels < 64 || channels > 1024 || (channels % 64) != 0 || classes <= 0) return 0;
+    return mbn_pool_fc_ws_bytes(channels, classes);
+}
+
+int mbn_pool_fc(mbn_context *ctx, void *logits, const void *in, const void *fc_w, const void *fc_bias, int batch, int rows, int cols,
+                int channels, int classes, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!ctx || !logits || !in || !fc_w || !workspace || batch <= 0 || rows <= 0 || cols <= 0 || channels <= 0 || classes <= 0) return MBN_EINVAL;
+    if (batch > 4 || channels < 64 || channels > 1024 || (channels % 64) != 0) return MBN_EUNSUPPORTED;
+    if (workspace_bytes < mbn_pool_fc_ws_bytes(channels, classes)) return MBN_EINVAL;
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    MBN_SPANS(ctx, { in, 4.0 * batch * rows * cols * channels, "pool_fc input" }, { logits, 4.0 * batch * classes, "pool_fc logits" },
+              { fc_w, 4.0 * classes * channels, "pool_fc filter" }, { workspace, (double)mbn_pool_fc_ws_bytes(channels, classes), "pool_fc workspace" });
+    Scope sc(ctx, s);
+    return sc.finish(mbn_launch_f32_pool_fc(ctx, s, (float *)logits, (const float *)in, (const float *)fc_w, (const float *)fc_bias, workspace,
+                                            batch, rows * cols, channels, classes));
+}
+
 static int stem_fused_impl(mbn_context *ctx, void *out, const void *image, const void *w1, const void *s1, const void *b1,
                            const void *wd, const void *s2, const void *b2, const void *wp, const void *s3, const void *b3,
                            int batch, int res, int c1, int c3, void *stream, int in_u8, int bf16)

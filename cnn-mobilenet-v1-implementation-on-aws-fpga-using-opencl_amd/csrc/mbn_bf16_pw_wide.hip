@@ -51,7 +51,6 @@ constexpr int NT = 512;
 constexpr int SLOT_ROWS = 256;          // 32 pieces of 8 rows per slot; pieces of rows >= 224 are issued out of range (dropped)
 constexpr int AF = SLOT_ROWS * BKF;     // floats per slot (32 KB)
 constexpr int ASLOTS = 3;                 // ring slots: the activations run 2 k-tiles ahead of the compute cursor, the filter 1 (two register sets)
-constexpr int NST = 8 * MI;             // store instructions per lane per epilogue
 constexpr unsigned OOB = 0xF0000000u;   // past every tensor in the envelope (< 3.75 GiB): the buffer unit drops the access
 
 struct WideArgs {

@@ -229,6 +229,93 @@ __global__ __launch_bounds__(256) void pool_f32_nhwc(T *__restrict__ out, const 
     out[t] = (T)(acc / (float)(fr * fc));
 }
 
+// Global average pool + FC in ONE launch for 1...4 images (MobileNet.c:2601-2739: the `pool` launch and the `pointwise` launch
+// with rows = cols = 1; at batch 1 a forward is launch-bound, so a launch saved is ~3 % of it). Workgroup (ks, ns)
+// owns channels [64 ks, 64 ks + 64) and classes [ns * npc, (ns + 1) * npc):
+//   1. pooled[b][c] for its 64 channels: the same left-to-right sum over the window and the same division as pool_f32_nhwc
+//      (bit-identical pooled values), lanes along channels (256-byte rows);
+//   2. its 64-channel slice of every class row (256 contiguous bytes per row: 16 lanes x float4) against the pooled slice,
+//      16-lane butterfly sum -> partial[ks][b][n] in the workspace;
+//   3. the LAST workgroup of a class range to finish (one counter per range, agent-scope release/acquire around it) adds the
+//      K/64 partials in slice order and the bias: a fixed summation order, no float atomics, independent of the batch.
+// The filter (4 MB) is read once per forward, the pool input once per class range.
+struct PoolFcArgs {
+    float *out;              // [batch][classes]
+    const float *in;         // [batch][pix][ch]
+    const float *w, *bias;   // [classes][ch], [classes] or null
+    float *ws;               // [nks][4][classes] partial sums
+    unsigned *cnt;           // [nns] arrival counters, zero between launches
+    int batch, pix, ch, classes, nks, nns, npc;
+};
+
+__global__ __launch_bounds__(256) void poolfc_f32(PoolFcArgs a)
+{
+    __shared__ float pooled[4][64];
+    __shared__ unsigned s_last;
+    const int ks = blockIdx.x % a.nks, ns = blockIdx.x / a.nks;
+    const int tid = threadIdx.x;
+    {
+        const int b = tid >> 6, c = tid & 63;
+        float acc = 0.f;
+        if (b < a.batch) {
+            const float *ip = a.in + (long)b * a.pix * a.ch + ks * 64 + c;
+            if (a.pix == 49) {
+                float v[49];
+#pragma unroll
+                for (int i = 0; i < 49; i++) v[i] = ip[(long)i * a.ch];
+#pragma unroll
+                for (int i = 0; i < 49; i++) acc += v[i];
+            } else
+                for (int i = 0; i < a.pix; i++) acc += ip[(long)i * a.ch];
+            acc = acc / (float)a.pix;
+        }
+        pooled[b][c] = acc;
+    }
+    __syncthreads();
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int r = tid >> 4, q = tid & 15;                       // 16 class rows per pass, 16 float4 per 64-channel slice
+    f4 pv[4];
+#pragma unroll
+    for (int b = 0; b < 4; b++) pv[b] = *reinterpret_cast<const f4 *>(&pooled[b][q * 4]);
+    const int n_lo = ns * a.npc, n_hi = min(a.classes, n_lo + a.npc);
+    for (int n0 = n_lo; n0 < n_hi; n0 += 16) {
+        const int n = n0 + r;
+        const bool ok = n < n_hi;
+        const f4 wv = ok ? *reinterpret_cast<const f4 *>(a.w + (long)n * a.ch + ks * 64 + q * 4) : f4{ 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            float p = fmaf(wv.w, pv[b].w, fmaf(wv.z, pv[b].z, fmaf(wv.y, pv[b].y, wv.x * pv[b].x)));
+            p += __shfl_xor(p, 8, 64);
+            p += __shfl_xor(p, 4, 64);
+            p += __shfl_xor(p, 2, 64);
+            p += __shfl_xor(p, 1, 64);
+            // agent-scope store (sc1: written through to where every XCD sees it) — a plain store would need the release fence to write the
+            // whole L2 of this XCD back (buffer_wbl2: ~20 us with the previous layers' activations dirty in it, measured)
+            if (q == 0 && ok && b < a.batch) __hip_atomic_store(a.ws + ((long)ks * 4 + b) * a.classes + n, p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // hand-over: the write-through stores of every wave have been acknowledged (vmcnt(0) at the barrier) before the arrival is counted;
+    // the counter and the reads of the last workgroup are agent-scope accesses too, so no cache is written back or invalidated
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (tid == 0) s_last = __hip_atomic_fetch_add(a.cnt + ns, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_last != (unsigned)a.nks - 1u) return;
+    for (int i = tid; i < (n_hi - n_lo) * a.batch; i += 256) {
+        const int b = i / (n_hi - n_lo), n = n_lo + i % (n_hi - n_lo);
+        // all K/64 <= 16 partials requested before the first add (one memory round trip, not one per slice); slices past nks read slice 0
+        float pt[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            pt[k] = __hip_atomic_load(a.ws + ((long)(k < a.nks ? k : 0) * 4 + b) * a.classes + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; k++) v += k < a.nks ? pt[k] : 0.f;
+        a.out[(long)b * a.classes + n] = v + (a.bias ? a.bias[n] : 0.f);
+    }
+    if (tid == 0) __hip_atomic_store(a.cnt + ns, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch on this workspace (stream order)
+}
+
 // softmax + argmax: one 256-lane workgroup per image; wave shuffles then a 4-entry LDS combine.
 __global__ __launch_bounds__(256) void softmax_f32(float *__restrict__ probs, int *__restrict__ argmax,
                                                    const float *__restrict__ logits, int classes)
@@ -413,6 +500,33 @@ int mbn_launch_f32_pool(const mbn_call &c, void *out, const void *in, int rows, 
     else
         hipLaunchKernelGGL(pool_f32_nhwc<float>, grid, dim3(256), 0, c.stream, (float *)out, (const float *)in, c.batch,
                            rows, cols, fr, fc, channels);
+    return MBN_OK;
+}
+
+// workspace: [ch/64][4][classes] floats + 64 counters (256 bytes, at the front); zeroed once by the caller
+size_t mbn_pool_fc_ws_bytes(int channels, int classes)
+{
+    return 256 + (size_t)(channels / 64) * 4 * (size_t)classes * sizeof(float);
+}
+
+int mbn_launch_f32_pool_fc(mbn_context *ctx, hipStream_t s, float *out, const float *in, const float *w, const float *bias, void *ws,
+                           int batch, int pix, int channels, int classes)
+{
+    if (batch < 1 || batch > 4 || channels < 64 || channels > 1024 || (channels % 64) != 0 || pix <= 0 || classes <= 0) return MBN_EUNSUPPORTED;
+    if (((uintptr_t)w % 16) != 0 || ((uintptr_t)ws % 16) != 0) return MBN_EUNSUPPORTED;
+    PoolFcArgs a;
+    a.out = out; a.in = in; a.w = w; a.bias = bias;
+    a.cnt = (unsigned *)ws;
+    a.ws = (float *)((char *)ws + 256);
+    a.batch = batch; a.pix = pix; a.ch = channels; a.classes = classes;
+    a.nks = channels / 64;
+    // class ranges: enough workgroups for every CU to hold one (the filter slice of a workgroup is npc x 256 bytes), at most 64 ranges
+    int nns = (ctx->num_cus + a.nks - 1) / a.nks;
+    if (nns > 64) nns = 64;
+    if (nns > (classes + 15) / 16) nns = (classes + 15) / 16;
+    a.npc = ((classes + nns - 1) / nns + 15) / 16 * 16;
+    a.nns = (classes + a.npc - 1) / a.npc;
+    hipLaunchKernelGGL(poolfc_f32, dim3((unsigned)(a.nks * a.nns)), dim3(256), 0, s, a);
     return MBN_OK;
 }
 

@@ -45,6 +45,9 @@ struct mbn_net {
     unsigned char bf16_packed[MBN_MAX_LAYERS];   /* the copy is followed by its packed image (mbn_pack_filter_bf16) */
     void *keep_buf[MBN_MAX_LAYERS];
     void *logits_buf;          /* mbn_net_classify: [max_batch][classes] fp32 */
+    void *poolfc_ws;           /* workspace of mbn_pool_fc (1...4 images: pool + FC in one launch), allocated and zeroed at creation */
+    size_t poolfc_ws_bytes;
+    int fuse_tail;             /* mbn_net_set_fuse_tail (default 0) */
     void *last_out[MBN_MAX_LAYERS];
 };
 
@@ -71,6 +74,16 @@ static int net_alloc_common(mbn_context *ctx, const mbn_plan *plan, int max_batc
     size_t bytes = (size_t)plan->max_act_floats * (size_t)max_batch * sizeof(float);
     int rc = mbn_alloc(ctx, bytes, &net->act[0]);
     if (rc == MBN_OK) rc = mbn_alloc(ctx, bytes, &net->act[1]);
+    net->fuse_tail = 0;            /* measured slower than the two launches (mbn.h: mbn_net_set_fuse_tail): opt-in */
+    if (rc == MBN_OK && plan->n_layers >= 2 && plan->layer[plan->n_layers - 2].kind == MBN_L_POOL &&
+        plan->layer[plan->n_layers - 1].kind == MBN_L_FC) {
+        const mbn_layer_desc *fc = &plan->layer[plan->n_layers - 1];
+        net->poolfc_ws_bytes = mbn_pool_fc_workspace_bytes(fc->in_ch, fc->out_ch);     /* 0: channels outside the kernel's envelope */
+        if (net->poolfc_ws_bytes) {
+            rc = mbn_alloc(ctx, net->poolfc_ws_bytes, &net->poolfc_ws);
+            if (rc == MBN_OK) rc = mbn_memset(ctx, net->poolfc_ws, 0, net->poolfc_ws_bytes);
+        }
+    }
     if (rc != MBN_OK) { mbn_net_destroy(net); return rc; }
     *out = net;
     return MBN_OK;
@@ -111,6 +124,7 @@ int mbn_net_destroy(mbn_net *net)
     mbn_sync(net->ctx);
     if (net->graph) mbn_graph_destroy(net->ctx, net->graph);
     if (net->logits_buf) mbn_free(net->ctx, net->logits_buf);
+    if (net->poolfc_ws) mbn_free(net->ctx, net->poolfc_ws);
     for (int j = 0; j < 8; j++)
         if (net->streams[j]) mbn_stream_destroy(net->ctx, net->streams[j]);
     for (int i = 0; i < MBN_MAX_LAYERS; i++) {
@@ -249,6 +263,14 @@ static int block_fusable(const mbn_net *net, int i, int count, int last_layer)
     return 1;
 }
 
+/* layers i+1 (pool) and i+2 (FC), 0-based index i, as one launch: fp32, 1...4 images, nothing kept, the last two layers of the call */
+static int tail_fusable(const mbn_net *net, int i, int count, int last_layer)
+{
+    if (!net->fuse_tail || !net->poolfc_ws || net->dtype != MBN_DT_F32 || net->keep || count < 1 || count > 4) return 0;
+    if (i + 2 != last_layer || last_layer != net->plan.n_layers) return 0;
+    return net->plan.layer[i].kind == MBN_L_POOL && net->plan.layer[i + 1].kind == MBN_L_FC;
+}
+
 /* a captured graph bakes the launch list in: drop it when the fusion settings change */
 static void drop_graph(mbn_net *net)
 {
@@ -275,6 +297,14 @@ int mbn_net_set_fuse_blocks(mbn_net *net, unsigned mask)
     if (fuse_mask(net) != mask || !net->fuse_blocks_set) drop_graph(net);
     net->fuse_blocks = mask;
     net->fuse_blocks_set = 1;
+    return MBN_OK;
+}
+
+int mbn_net_set_fuse_tail(mbn_net *net, int enabled)
+{
+    if (!net) return MBN_EINVAL;
+    if (net->fuse_tail != (enabled != 0)) drop_graph(net);
+    net->fuse_tail = enabled != 0;
     return MBN_OK;
 }
 
@@ -306,6 +336,7 @@ int mbn_net_launches(const mbn_net *net, int batch, int last_layer, int *first_l
         int span = 1;
         if (i == 0 && stem_fusable(net, last_layer)) span = 3;
         else if (block_fusable(net, i, sub, last_layer)) span = 2;
+        else if (tail_fusable(net, i, sub, last_layer)) span = 2;
         if (first_layer && n_layers && n < capacity) { first_layer[n] = i + 1; n_layers[n] = span; }
         n++;
         i += span;
@@ -453,6 +484,18 @@ static int forward_range(mbn_net *net, const void *images, void *logits, int fir
                 }
                 i++;
                 continue;
+            }
+            if (rc != MBN_EUNSUPPORTED) return rc;
+        }
+        if (!layer_ms && tail_fusable(net, i, count, last_layer)) {
+            /* pool + FC in one launch (1...4 images: the forward is launch-bound there) */
+            const mbn_layer_desc *fc = &net->plan.layer[i + 1];
+            char *dst2 = (char *)logits + (size_t)first * fc->out_ch * sizeof(float);
+            int rc = mbn_pool_fc(net->ctx, dst2, src, blob_at(net, fc->w_offset), blob_at(net, fc->shift_offset), count, l->in_rows,
+                                 l->in_cols, l->out_ch, fc->out_ch, net->poolfc_ws, net->poolfc_ws_bytes, stream);
+            if (rc == MBN_OK) {
+                if (first == 0) { net->last_out[i] = NULL; net->last_out[i + 1] = dst2; }
+                break;
             }
             if (rc != MBN_EUNSUPPORTED) return rc;
         }

@@ -300,6 +300,17 @@ int mbn_softmax_topk_f32(mbn_context *ctx, void *probs, void *topk_idx_i32, void
 int mbn_classifier_tail(mbn_context *ctx, void *topk_idx_i32, void *topk_prob_f32, void *probs, void *logits_scratch,
                         void *pooled_scratch, const void *in, const void *fc_w, const void *fc_bias, int batch, int rows,
                         int cols, int channels, int classes, int k, void *stream);
+/* Global average pool + FC as ONE launch for 1...4 images (MobileNet.c:2601-2739: the `pool` launch, kernel.cl:116, and the
+ * `pointwise` launch with rows = cols = 1, kernel.cl:94; bias, no ReLU). fp32 NHWC in [batch][rows][cols][channels] (the window
+ * is the whole map), fc_w [classes][channels], fc_bias [classes] or NULL, logits [batch][classes]. The pooled values are those of
+ * mbn_pool bit for bit; the FC sums 64-channel slices in a fixed order (no float atomics): the result of an image does not depend
+ * on the batch it is in. `workspace`: mbn_pool_fc_workspace_bytes(channels, classes) bytes of device memory, ZEROED ONCE by the
+ * caller (mbn_memset) and then reused launch after launch on one stream at a time. MBN_EUNSUPPORTED for batch > 4 or channels
+ * not a multiple of 64 (the caller then uses mbn_pool + mbn_pointwise). */
+size_t mbn_pool_fc_workspace_bytes(int channels, int classes);
+int mbn_pool_fc(mbn_context *ctx, void *logits, const void *in, const void *fc_w, const void *fc_bias, int batch, int rows, int cols,
+                int channels, int classes, void *workspace, size_t workspace_bytes, void *stream);
+
 /* Input front-end on device: uint8 HWC [N][rows][cols][3] -> fp32 NHWC x*scale+bias
  * (Keras MobileNet preprocessing is scale=1/127.5, bias=-1). */
 int mbn_normalize_u8_to_f32(mbn_context *ctx, void *out_f32, const void *in_u8, size_t count, float scale,
@@ -458,8 +469,13 @@ int  mbn_net_get_fuse_blocks(const mbn_net *net, unsigned *mask);
 /* Back to the state before any mbn_net_set_fuse_blocks call: the measured default of the current dtype WITH its
  * default-only rules (few-tile rule in fp32, one-column-tile rule in bf16), which an explicit mask switches off. */
 int  mbn_net_reset_fuse_blocks(mbn_net *net);
+/* Pool + FC as one launch (mbn_pool_fc) for calls of 1...4 images in fp32. DEFAULT OFF: measured on MI355X the one launch takes
+ * 6.7 us against 1.9 + 2.1 us for the two (the cross-workgroup hand-over of the partial sums is three dependent memory round trips),
+ * a forward of one image 0.1371 against 0.1348 ms (profiles/r03/p_pool_fc_one_launch.txt). The pooled values are identical either
+ * way; the FC sums in another (fixed) order. */
+int  mbn_net_set_fuse_tail(mbn_net *net, int enabled);
 /* The launches the next forward(batch, last_layer) issues per (sub-)batch: launch j covers n_layers[j] layers starting
- * at the 1-based layer first_layer[j] (3 = fused stem, 2 = fused block, 1 = single layer). *count = number of
+ * at the 1-based layer first_layer[j] (3 = fused stem, 2 = fused block or fused pool + FC, 1 = single layer). *count = number of
  * launches; the arrays (may be NULL) receive at most `capacity` entries. */
 /* (The list assumes what mbn_net_forward's own buffers guarantee — 16-byte aligned tensors; a caller-provided `logits` /
  * last-layer buffer that is not 16-byte aligned makes the fused call answer MBN_EUNSUPPORTED and the forward issue the two

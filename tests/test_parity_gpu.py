@@ -1056,6 +1056,75 @@ def test_softmax_topk_and_classifier_tail(pkg, orc, ctx):
     assert_close(d_v.download((n, k), np.float32), np.take_along_axis(ref_p, got_i.astype(np.int64), axis=1), 1e-3, "tail top-k probs")
 
 
+@pytest.mark.parametrize("shape", [(1, 7, 1024, 1000), (4, 7, 1024, 1000), (3, 5, 512, 1000), (2, 7, 256, 37), (4, 2, 64, 16), (1, 3, 1024, 1001)])
+def test_pool_fc_one_launch(pkg, orc, ctx, shape):
+    """mbn_pool_fc (pool + FC in one launch for 1...4 images: MobileNet.c:2601-2739 as one kernel): against the oracle's pool ->
+    pointwise(bias, no ReLU); an image's logits do not depend on the batch it is in (bit for bit); repeatable on the same workspace
+    (the counters return to zero); exact on small integers with an asymmetric filter (slice / class-range maps); envelope errors."""
+    n, h, ch, classes = shape
+    rng = np.random.default_rng(n + h + ch + classes)
+    x = rng.uniform(0, 6, (n, h, h, ch)).astype(np.float32)
+    w = rng.normal(0, (1.0 / ch) ** 0.5, (classes, ch)).astype(np.float32)
+    b = rng.normal(0, 0.5, classes).astype(np.float32)
+    ref = orc.f32_pointwise(orc.f32_pool(x).reshape(n, ch), w, None, b, 0)
+    nb = ctx.lib.mbn_pool_fc_workspace_bytes(ch, classes)
+    assert nb >= 256 + (ch // 64) * 4 * classes * 4
+    d_x, d_w, d_b, d_o, d_ws = ctx.to_device(x), ctx.to_device(w), ctx.to_device(b), ctx.alloc(n * classes * 4 + 64), ctx.alloc(nb)
+    ctx.lib.mbn_memset(ctx.h, d_ws.ptr, 0, nb)
+    ctx.lib.mbn_memset(ctx.h, d_o.ptr, 0xFF, n * classes * 4 + 64)
+
+    def run(count, bias=d_b.ptr):
+        assert ctx.lib.mbn_pool_fc(ctx.h, d_o.ptr, d_x.ptr, d_w.ptr, bias, count, h, h, ch, classes, d_ws.ptr, nb, None) == 0
+        ctx.sync()
+        return d_o.download((count, classes), np.float32)
+    got = run(n)
+    assert np.all(d_o.download((n * classes + 16,), np.uint32)[n * classes:] == 0xFFFFFFFF), "stores past the output"
+    assert_close(got, ref, TOL_PW, "pool_fc %s vs oracle" % (shape,))
+    assert np.array_equal(got, run(n)), "not repeatable on the same workspace"
+    assert np.all(d_ws.download((64,), np.uint32) == 0), "arrival counters not back to zero"
+    for k in range(1, n):
+        assert np.array_equal(run(k), got[:k]), "logits depend on the batch (%d of %d)" % (k, n)
+    assert_close(run(n, None), ref - b, TOL_PW, "no bias")
+    xi = rng.integers(0, 4, (n, h, h, ch)).astype(np.float32)
+    xi[:, 1:] = xi[:, :1]                                        # every row equal: the pooled value is the exact integer mean over columns
+    xi[:, :, 1:] = xi[:, :, :1]
+    wi = rng.integers(-2, 3, (classes, ch)).astype(np.float32)
+    wi[:, 0] = np.arange(classes) % 5
+    wi[:, ch - 1] = np.arange(classes) % 3
+    d_x.upload(xi); d_w.upload(wi)
+    want = xi[:, 0, 0].astype(np.float64) @ wi.astype(np.float64).T
+    assert np.array_equal(run(n, None).astype(np.float64), want)
+    assert ctx.lib.mbn_pool_fc(ctx.h, d_o.ptr, d_x.ptr, d_w.ptr, None, 5, h, h, ch, classes, d_ws.ptr, nb, None) == pkg.EUNSUPPORTED
+    assert ctx.lib.mbn_pool_fc(ctx.h, d_o.ptr, d_x.ptr, d_w.ptr, None, n, h, h, ch, classes, d_ws.ptr, nb - 4, None) == pkg.EINVAL
+    assert ctx.lib.mbn_pool_fc_workspace_bytes(ch + 32, classes) == 0
+    for bfr in (d_x, d_w, d_b, d_o, d_ws):
+        bfr.free()
+
+
+def test_net_tail_one_launch_matches_two(pkg, orc, ctx, tmp_path):
+    """The net runner's pool + FC launch at 1...4 images (mbn_net_set_fuse_tail; off by default: measured slower) against the two launches: same launch list
+    except the tail, logits within the fp32 tolerance of each other and of the oracle, and forward(4)[:k] == forward(k) either way."""
+    n, res = 4, 224
+    hw, net = _make_net(pkg, ctx, tmp_path, 1.0, res, 1000, n)
+    imgs = _headline_images(n, res, 5)
+    d_in, d_out = ctx.to_device(imgs), ctx.alloc(n * 1000 * 4)
+    outs = {}
+    for fused in (True, False):
+        net.set_fuse_tail(fused)
+        la = net.launches(n)
+        assert la[-1] == ((28, 2) if fused else (29, 1)), la
+        for k in (n, 1, 3):
+            net.forward(d_in.ptr, d_out.ptr, k)
+            ctx.sync()
+            outs[(fused, k)] = d_out.download((k, 1000), np.float32)
+        for k in (1, 3):
+            assert np.array_equal(outs[(fused, k)], outs[(fused, n)][:k]), (fused, k)
+    assert_close(outs[(True, n)], outs[(False, n)], 1e-5, "one-launch tail vs two launches")
+    want, _ = orc.net_forward(orc.plan_build(1.0, res, 1000), hw.blob, imgs, threads=orc.num_threads())
+    assert_close(outs[(True, n)], np.asarray(want).reshape(n, 1000), TOL_NET, "one-launch tail vs oracle")
+    net.destroy()
+
+
 def test_net_classify_matches_forward(pkg, orc, ctx, tmp_path):
     n, res = 4, 64
     hw, net = _make_net(pkg, ctx, tmp_path, 0.5, res, 30, n)
