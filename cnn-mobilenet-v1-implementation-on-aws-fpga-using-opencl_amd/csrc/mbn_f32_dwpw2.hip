@@ -41,8 +41,8 @@ namespace {
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef mbn_f16v f16v;
 
-constexpr int BM = 128, BKF = 32;
-constexpr int NW = 8, NT = 64 * NW;            // 8 waves: 2 per SIMD, 256 VGPRs each
+constexpr int BKF = 32;
+constexpr int BM8 = 128;                       // rows of the shipped 8-wave tile (2 waves per SIMD, 256 VGPRs each); the 16-wave lab form: 256
 constexpr int NOUT = 1024;                     // widest pointwise output whose scale/shift the LDS copy holds
 constexpr int CMAX = 1024;                     // largest Cin (depthwise constants resident in LDS: 44 KB)
 constexpr unsigned OOB = 0xF0000000u;          // byte offset beyond any supported tensor: the load returns zeros
@@ -91,26 +91,29 @@ __device__ __forceinline__ void lds_barrier()
 }
 
 // pointwise filter chunk -> LDS, buffer form (a __device__ function: see mbn_f32_pw.hip lds_dma_rows)
-template <int B_LD>
+template <int B_LD, int NT, int BN>
 __device__ __forceinline__ void dma_filter(__amdgpu_buffer_rsrc_t rsrc, float *lds_b, const unsigned *voff, int soff, int wave_u)
 {
 #pragma unroll
     for (int p = 0; p < B_LD; p++)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(lds_b + (p * (NT / 8) + wave_u * 8) * BKF),
-                                                 16, voff[p], soff, 0, 0);
+        if ((B_LD * NT == BN * 8) || p * (NT / 8) + wave_u * 8 < BN)       // 12 waves: the second round of pieces exists for waves 0-3 only (wave-uniform)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(lds_b + (p * (NT / 8) + wave_u * 8) * BKF),
+                                                     16, voff[p], soff, 0, 0);
 }
 
 // DBG = false: the shipped kernel — every experiment switch (a.dbg) folds away at compile time, which takes ~40 scalar branches and the
 // conservative waits around them out of the step. DBG = true is launched only for tune dwpw_variant >= 100.
-template <int S, int BN, bool PRE, bool DBG>
-__global__ __launch_bounds__(NT) void dwpw2_f32(DwPw2Args a)
+// NW = 16 (lab, BN = 128 only): the same kernel on a 256-row tile with 16 waves = 4 per SIMD at <= 128 VGPRs (taps read from LDS inside the step)
+template <int S, int BN, bool PRE, bool DBG, int NW = 8>
+__global__ __launch_bounds__(64 * NW) void dwpw2_f32(DwPw2Args a)
 {
     const int dbg = DBG ? a.dbg : 0;
+    constexpr int NT = 64 * NW, BM = 16 * NW;
     constexpr int WN = 64, WM = BN == 256 ? 64 : 32;   // wave tile: 8 waves as 2 x 4 (BN 256) or 4 x 2 (BN 128)
     constexpr int WAVES_N = BN / WN;
-    static_assert((BM / WM) * WAVES_N == NW, "8 waves");
+    static_assert((BM / WM) * WAVES_N == NW, "wave grid");
     constexpr int MI = WM / 32, NI = WN / 32;
-    constexpr int B_LD = BN * 8 / NT;                  // 16-B filter pieces per lane per chunk (2 / 4)
+    constexpr int B_LD = (BN * 8 + NT - 1) / NT;       // 16-B filter pieces per lane per chunk (2 / 4)
     constexpr int XC = S + 3;                          // input columns feeding 2 adjacent output pixels
     constexpr int NX = 3 * XC;                         // buffer loads per lane per chunk
     constexpr int ABUF = BM * BKF, BBUF = BN * BKF;
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(NT) void dwpw2_f32(DwPw2Args a)
     unsigned b_vo[B_LD];                                                        // filter piece offsets: fixed for the kernel, the tile's
 #pragma unroll                                                                  // column origin and the chunk go into the scalar offset
     for (int p = 0; p < B_LD; p++) {
-        const int row = (p * NT + tid) >> 3;
+        const int row = ((p * NT + tid) >> 3) & (BN - 1);       // (12 waves: the unused pieces of the second round wrap; never issued)
         // channel-paired column blocks (mbn_epilogue.h): LDS filter row `row` holds output channel mbn_pair_channel(row), so the
         // epilogue stores 8 bytes per lane, 256 contiguous bytes per pixel row; `pair` = dbg bit 5 switches it off (A/B)
         b_vo[p] = ((unsigned)(paired ? mbn_pair_channel(row) : row) * (unsigned)a.cin + (unsigned)(((c4 ^ (row >> 1)) & 7) * 4)) * 4u;
@@ -218,8 +221,27 @@ __global__ __launch_bounds__(NT) void dwpw2_f32(DwPw2Args a)
     };
     // depthwise + BN + ReLU6 of the chunk in xr/wreg into A buffer `buf` (same fma order as mbn_f32_dw.hip: bit-identical)
     auto dw = [&](int kc, const int buf) __attribute__((always_inline)) {
-        if (!PRE) ldw(kc);
         f4 acc0 = f4{ 0.f, 0.f, 0.f, 0.f }, acc1 = acc0;
+        if constexpr (NW > 8) {
+            // register-lean forms (> 2 waves per SIMD): one filter row of taps at a time, read where it is used (same fma order: same bits)
+#pragma unroll
+            for (int dy = 0; dy < 3; dy++) {
+                f4 t3[3];
+#pragma unroll
+                for (int dx = 0; dx < 3; dx++) t3[dx] = *reinterpret_cast<const f4 *>(wk + kc * 32 + (dy * 3 + dx) * a.cin);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int dx = 0; dx < 3; dx++) {
+                    acc0 = __builtin_elementwise_fma(xr[dy][dx], t3[dx], acc0);
+                    acc1 = __builtin_elementwise_fma(xr[dy][dx + S], t3[dx], acc1);
+                }
+            }
+            const f4 sc2 = *reinterpret_cast<const f4 *>(sk + kc * 32), sh2 = *reinterpret_cast<const f4 *>(sk + a.cin + kc * 32);
+            *reinterpret_cast<f4 *>(a_s0 + buf * ABUF + aw0) = bn_relu6(acc0, sc2, sh2);
+            *reinterpret_cast<f4 *>(a_s0 + buf * ABUF + aw1) = bn_relu6(acc1, sc2, sh2);
+            return;
+        }
+        if (!PRE) ldw(kc);
 #pragma unroll
         for (int dy = 0; dy < 3; dy++)
 #pragma unroll
@@ -274,7 +296,7 @@ __global__ __launch_bounds__(NT) void dwpw2_f32(DwPw2Args a)
     set_offsets(m0M);
     ldx(0);
     if (PRE) ldw(0);
-    dma_filter<B_LD>(wrsrc, b_s0, b_vo, (n0M * a.cin + 0) * 4, wave_u);
+    dma_filter<B_LD, NT, BN>(wrsrc, b_s0, b_vo, (n0M * a.cin + 0) * 4, wave_u);
     dw(0, 0);
     // D cursor = successor of M
     vbD = vbM; kD = 1; m0D = m0M; n0D = n0M; validD = true;
@@ -304,12 +326,12 @@ __global__ __launch_bounds__(NT) void dwpw2_f32(DwPw2Args a)
         int vbL = vbD, kL = kD + 1, n0L = n0D;                                                                          \
         unsigned m0L = m0D;                                                                                             \
         if (validD) {                                                                                                   \
-            if (!(dbg & 8) && (dbg & 512)) dma_filter<B_LD>(wrsrc, b_s0 + (P ^ 1) * BBUF, b_vo, (n0D * a.cin + kD * 32) * 4, wave_u); /* dbg 512: DMA ahead of the depthwise part (before) */ \
+            if (!(dbg & 8) && (dbg & 512)) dma_filter<B_LD, NT, BN>(wrsrc, b_s0 + (P ^ 1) * BBUF, b_vo, (n0D * a.cin + kD * 32) * 4, wave_u); /* dbg 512: DMA ahead of the depthwise part (before) */ \
             if (!(dbg & 2)) dw(kD, P ^ 1);                                                                            \
             /* the filter DMA BEHIND the depthwise part: issued ahead of it, its two LDS-DMA operations were the wave's youngest */ \
             /* vector-memory operations when the depthwise math needed the x window, and the compiler's wait for the window     */ \
             /* (s_waitcnt vmcnt(1), vmcnt(0) in the ISA) waited out the DMA's whole L2 round trip at the start of every step   */ \
-            if (!(dbg & 8) && !(dbg & 512)) dma_filter<B_LD>(wrsrc, b_s0 + (P ^ 1) * BBUF, b_vo, (n0D * a.cin + kD * 32) * 4, wave_u); \
+            if (!(dbg & 8) && !(dbg & 512)) dma_filter<B_LD, NT, BN>(wrsrc, b_s0 + (P ^ 1) * BBUF, b_vo, (n0D * a.cin + kD * 32) * 4, wave_u); \
             validL = true;                                                                                              \
             if (kL >= nk) {                                                                                             \
                 kL = 0; vbL += gridDim.x; validL = vbL < nwg;                                                           \
@@ -364,6 +386,19 @@ __global__ __launch_bounds__(NT) void dwpw2_f32(DwPw2Args a)
 template <int S, int BN>
 void launch2(DwPw2Args &a, hipStream_t s, int num_cus, bool pre)
 {
+    constexpr int BM = BM8, NT = 512;
+#ifdef MBN_LAB
+    if (BN == 128 && (g_mbn_tune.dwpw_variant == 5 || g_mbn_tune.dwpw_variant == 6)) {      // r3 A/B: 16 / 12 waves on a 256- / 192-row tile
+        const int nw = g_mbn_tune.dwpw_variant == 5 ? 16 : 12;
+        a.mt = (int)((a.m + 16 * nw - 1) / (16 * nw));
+        a.nt = a.cout / BN;
+        long g16 = num_cus;
+        if (g16 > (long)a.mt * a.nt) g16 = (long)a.mt * a.nt;
+        if (nw == 16) hipLaunchKernelGGL((dwpw2_f32<S, 128, false, false, 16>), dim3((unsigned)g16), dim3(1024), 0, s, a);
+        else hipLaunchKernelGGL((dwpw2_f32<S, 128, false, false, 12>), dim3((unsigned)g16), dim3(768), 0, s, a);
+        return;
+    }
+#endif
     a.mt = (int)((a.m + BM - 1) / BM);
     a.nt = a.cout / BN;
     const long nwg = (long)a.mt * a.nt;
@@ -403,7 +438,7 @@ int mbn_launch_f32_dwpw2(mbn_context *ctx, hipStream_t stream, float *out, const
     a.stagger = g_mbn_tune.exp2;                                             // lab: start stagger of the workgroups in kcycles per phase
     const bool pre = variant != 3;                                       // 3: taps read from LDS inside the step (A/B hook)
     // 256-column tiles only when they alone fill the chip (see mbn_dwpw_fused); pw_tile=1: force the 128-column tile (A/B hook)
-    const bool wide = (cout % 256) == 0 && g_mbn_tune.pw_tile != 1 && ((a.m + BM - 1) / BM) * (cout / 256) >= ctx->num_cus;
+    const bool wide = (cout % 256) == 0 && g_mbn_tune.pw_tile != 1 && ((a.m + BM8 - 1) / BM8) * (cout / 256) >= ctx->num_cus;
     if (stride == 1) {
         if (wide) launch2<1, 256>(a, stream, ctx->num_cus, pre);
         else launch2<1, 128>(a, stream, ctx->num_cus, pre);

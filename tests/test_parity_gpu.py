@@ -843,10 +843,14 @@ DWPW_SHAPES = [  # (batch, in side, Cin, Cout, stride)
 ]
 
 
+@pytest.mark.parametrize("variant", [0, 6, 5])
 @pytest.mark.parametrize("shape", DWPW_SHAPES)
-def test_f32_dwpw_fused(pkg, orc, ctx, shape):
-    """mbn_dwpw_fused vs mbn_depthwise + mbn_pointwise (same arithmetic order -> bit-identical) and vs the oracle."""
+def test_f32_dwpw_fused(pkg, orc, ctx, shape, variant):
+    """mbn_dwpw_fused vs mbn_depthwise + mbn_pointwise (same arithmetic order -> bit-identical) and vs the oracle.
+    variant 6 / 5 (lab build): the unified kernel with 12 / 16 waves on 192- / 256-row tiles (128-column tiles only)."""
     n, h, cin, cout, stride = shape
+    if variant:
+        _tune_lab(ctx, b"dwpw_variant", variant)
     rng = np.random.default_rng(h * 11 + cin + cout + stride)
     x = rng.uniform(-1, 1, (n, h, h, cin)).astype(np.float32)
     wd = rng.normal(0, 0.5, (3, 3, cin)).astype(np.float32)
@@ -879,6 +883,7 @@ def test_f32_dwpw_fused(pkg, orc, ctx, shape):
         ctx.lib.mbn_tune_set(b"pw_splitk", 0)
     ctx.sync()
     unfused = d_u.download(want.shape, np.float32)
+    ctx.lib.mbn_tune_set(b"dwpw_variant", 0)
     assert np.array_equal(fused, unfused), "fused block differs from depthwise+pointwise by %g" % np.abs(fused - unfused).max()
     for b in d + [d_f, d_m, d_u]:
         b.free()
