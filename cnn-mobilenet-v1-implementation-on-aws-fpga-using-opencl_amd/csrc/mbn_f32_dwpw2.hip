@@ -312,6 +312,25 @@ __global__ __launch_bounds__(64 * NW) void dwpw2_f32(DwPw2Args a)
     if (validD) lds_barrier<NX>();        // filter chunk 0 landed; the NX newer loads may fly
     else lds_barrier<0>();
 
+    // The finished tile's epilogue is issued in the NEXT step, behind that step's depthwise part and filter DMA and ahead of its MFMAs
+    // (round 3). vmcnt retires in order: with the 16 / 32 stores issued right behind the barrier — ahead of the next step's filter DMA —
+    // the counted wait in front of the next barrier (filter landed) also waited for every store to be acknowledged, once per tile.
+    // Behind the DMA they are YOUNGER than what that wait needs and stay in flight (lds_barrier<NX + NST>). The accumulators are not
+    // touched by the depthwise part, so no second set is needed (the r2 attempt deferred the stores behind the x loads too, i.e. under
+    // the MFMAs, and paid for it in registers). Measured (profiles/r03/q_block_more_waves.txt, second table): block 6-7 -0.7 %, blocks
+    // 4-5 and 8-9 unchanged — like r2's three-slot experiment it says the "-13 % without the stores" of the ablation is the store
+    // traffic itself, not the wait for it.
+    constexpr int NST = 16 * MI * (NI / 2);            // buffer_store_dwordx2 per lane of the channel-paired epilogue, both modes
+    bool pendE = false;
+    unsigned m0E = 0;
+    int n0E = 0;
+    auto epilogue = [&](unsigned m0, int n0) __attribute__((always_inline)) {
+        if (paired) {
+            if (m0 + BM <= mtot) mbn_store_relu6_f32_pair<MI, NI, 0>(orsrc, (unsigned)a.cout, m0 + wm, n0 + wn, lane, acc, sc3_s, sh3_s);
+            else mbn_store_relu6_f32_pair<MI, NI, 1>(orsrc, (unsigned)a.cout, m0 + wm, n0 + wn, lane, acc, sc3_s, sh3_s);
+        } else if (m0 + BM <= mtot) mbn_store_relu6_f32<MI, NI, 0>(orsrc, (unsigned)a.cout, m0 + wm, n0 + wn, lane, acc, sc3_s, sh3_s, mtot, a.cout);
+        else mbn_store_relu6_f32<MI, NI, 1>(orsrc, (unsigned)a.cout, m0 + wm, n0 + wn, lane, acc, sc3_s, sh3_s, mtot, a.cout);
+    };
     int stepno = 0;
     const bool stamping = (dbg & 64) && blockIdx.x == 0;
 #define STAMP(k) do { if (stamping && stepno < 96) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) g_dwpw2_stamps[wave_u][stepno][k] = t_; } } while (0)
@@ -341,6 +360,12 @@ __global__ __launch_bounds__(64 * NW) void dwpw2_f32(DwPw2Args a)
             if (validL && !(dbg & 1) && ((dbg & 128) || (dbg & 16))) ldx(kL);      /* dbg 128: the burst form (A/B) */ \
         }                                                                                                               \
         const bool spreadL = validL && !(dbg & 1) && !(dbg & 128) && !(dbg & 16);                                 \
+        const bool didE = pendE && paired && !(dbg & 4);       /* exactly NST stores are in flight behind the DMA */      \
+        if (pendE) {                                                                                                    \
+            if (!(dbg & 4)) epilogue(m0E, n0E);                                                                       \
+            zero_acc();                                                                                                 \
+            pendE = false;                                                                                              \
+        }                                                                                                               \
         __builtin_amdgcn_s_setprio(0);                                                                                  \
         STAMP(2);                                                                                                       \
         if (!(dbg & 16)) {                                                                                            \
@@ -357,17 +382,10 @@ __global__ __launch_bounds__(64 * NW) void dwpw2_f32(DwPw2Args a)
         }                                                                                                               \
         STAMP(3);                                                                                                       \
         if (PRE && validL) ldw(kL);                                                                                     \
-        if (validL) lds_barrier<NX>();                                                                                  \
-        else lds_barrier<0>();                                                                                          \
+        if (validL) { if (didE) lds_barrier<NX + NST>(); else lds_barrier<NX>(); }                                      \
+        else { if (didE) lds_barrier<NST>(); else lds_barrier<0>(); }                                                   \
         STAMP(4);                                                                                                       \
-        if (kM == nk - 1 && !(dbg & 4)) {                                                                             \
-            if (paired) {                                                                                               \
-                if (m0M + BM <= mtot) mbn_store_relu6_f32_pair<MI, NI, 0>(orsrc, (unsigned)a.cout, m0M + wm, n0M + wn, lane, acc, sc3_s, sh3_s); \
-                else mbn_store_relu6_f32_pair<MI, NI, 1>(orsrc, (unsigned)a.cout, m0M + wm, n0M + wn, lane, acc, sc3_s, sh3_s);               \
-            } else if (m0M + BM <= mtot) mbn_store_relu6_f32<MI, NI, 0>(orsrc, (unsigned)a.cout, m0M + wm, n0M + wn, lane, acc, sc3_s, sh3_s, mtot, a.cout); \
-            else mbn_store_relu6_f32<MI, NI, 1>(orsrc, (unsigned)a.cout, m0M + wm, n0M + wn, lane, acc, sc3_s, sh3_s, mtot, a.cout);               \
-            zero_acc();                                                                                                 \
-        }                                                                                                               \
+        if (kM == nk - 1) { pendE = true; m0E = m0M; n0E = n0M; }      /* stored in the next step (or behind the loop) */ \
         STAMP(5);                                                                                                       \
         stepno++;                                                                                                       \
         if (!validD) break;                                                                                             \
@@ -379,6 +397,7 @@ __global__ __launch_bounds__(64 * NW) void dwpw2_f32(DwPw2Args a)
         MBN_DWPW2_STEP(0)
         MBN_DWPW2_STEP(1)
     }
+    if (pendE && !(dbg & 4)) epilogue(m0E, n0E);               // the workgroup's last tile
 #undef MBN_DWPW2_STEP
 #undef STAMP
 }
