@@ -66,6 +66,7 @@ struct StreamArgs {
     const float *scale, *shift;
     long m;
     int k, n, mt, nt;
+    int delay;      // lab (exp0 >= 100): start delay of a workgroup, (exp0 - 100) x 1024 cycles x its phase ((blockIdx / 8) & 3): de-phases the tiles' store bursts
     int stag;       // lab (exp2): 1 = odd waves issue their LDS-DMA behind the second MFMA group instead of ahead of the first, 2 = all waves
 };
 
@@ -112,6 +113,12 @@ __global__ __launch_bounds__(SH::NT, 4) void pw_stream_bf16(StreamArgs a)
     const int nk = a.k / BKE, nwg = a.mt * a.nt;
     if ((int)blockIdx.x >= nwg) return;
     const int ntile = (nwg - 1 - (int)blockIdx.x) / (int)gridDim.x + 1;      // tiles of this workgroup
+#ifdef MBN_LAB
+    if (a.delay > 0) {
+        const long long t0 = __builtin_readcyclecounter(), wait = (long long)(((int)blockIdx.x >> 3) & 3) * a.delay * 1024;
+        while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+    }
+#endif
 
     const __amdgpu_buffer_rsrc_t arsrc = mbn_make_rsrc(a.in, (unsigned)(a.m * a.k * 2));
     const __amdgpu_buffer_rsrc_t brsrc = mbn_make_rsrc(a.filt, (unsigned)((long)a.n * a.k * 2));
@@ -343,7 +350,7 @@ int mbn_launch_bf16_pw_stream(const mbn_call &c, void *out, const void *in, cons
     const long nwg = (long)a.mt * a.nt;
     if (nwg > 0x7fffffffL) return MBN_EUNSUPPORTED;
     long grid = 2L * c.ctx->num_cus;                       // 80 KB of LDS: two workgroups per CU
-    if (g_mbn_tune.exp0 > 0) grid = (long)g_mbn_tune.exp0 * c.ctx->num_cus;      // lab: workgroups per CU of the persistent grid
+    { const int e0 = g_mbn_tune.exp0; a.delay = e0 >= 100 ? e0 - 100 : 0; if (e0 > 0 && e0 < 100) grid = (long)e0 * c.ctx->num_cus; }      // lab: workgroups per CU of the persistent grid / start delay
     if (grid > nwg) grid = nwg;
 #ifdef MBN_LAB
     switch (g_mbn_tune.exp1) {                                 // ablations (timing only)
@@ -383,6 +390,7 @@ int mbn_launch_bf16_pw_big(const mbn_call &c, void *out, const void *in, const v
     if (tiles < cus) return MBN_EUNSUPPORTED;
     StreamArgs a;
     a.out = (__bf16 *)out; a.in = (const __bf16 *)in; a.filt = (const __bf16 *)filt; a.scale = c.scale; a.shift = c.shift;
+    a.delay = 0;
     a.m = (tiles / nt) * BM; a.k = cin; a.n = op_size; { const int e2 = g_mbn_tune.exp2; a.stag = e2 >= 98 ? e2 - 98 : e2; }   /* 98, 99, 100: stag 0, 1, 2 without the remainder launch */
     a.mt = (int)(tiles / nt);
     a.nt = nt;
