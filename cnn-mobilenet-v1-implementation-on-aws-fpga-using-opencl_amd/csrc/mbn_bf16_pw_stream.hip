@@ -60,6 +60,11 @@ struct Shape {
     static_assert(BM * 8 == LDP * NT && BN * 8 == LDP * NT, "two pieces per lane per operand");
 };
 
+#ifdef MBN_LAB
+// lab: workgroup 0 / wave 0 of the last launch: { s_memtime at start, at end (core clock cycles), s_memrealtime at start, at end (100 MHz) }
+__device__ unsigned long long g_stream_clk[4];
+#endif
+
 struct StreamArgs {
     __bf16 *out;
     const __bf16 *in, *filt;
@@ -114,6 +119,8 @@ __global__ __launch_bounds__(SH::NT, 4) void pw_stream_bf16(StreamArgs a)
     if ((int)blockIdx.x >= nwg) return;
     const int ntile = (nwg - 1 - (int)blockIdx.x) / (int)gridDim.x + 1;      // tiles of this workgroup
 #ifdef MBN_LAB
+    const bool clk = blockIdx.x == 0 && tid == 0;
+    if (clk) { g_stream_clk[0] = __builtin_amdgcn_s_memtime(); g_stream_clk[2] = __builtin_amdgcn_s_memrealtime(); }
     if (a.delay > 0) {
         const long long t0 = __builtin_readcyclecounter(), wait = (long long)(((int)blockIdx.x >> 3) & 3) * a.delay * 1024;
         while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(32);
@@ -310,6 +317,7 @@ __global__ __launch_bounds__(SH::NT, 4) void pw_stream_bf16(StreamArgs a)
             for (int kt = 0; kt + 1 < nk; kt++) step(std::false_type{}, std::true_type{});
             step(std::true_type{}, std::true_type{});
         }
+        if (clk) { g_stream_clk[1] = __builtin_amdgcn_s_memtime(); g_stream_clk[3] = __builtin_amdgcn_s_memrealtime(); }
         return;
     }
 #endif
@@ -317,6 +325,9 @@ __global__ __launch_bounds__(SH::NT, 4) void pw_stream_bf16(StreamArgs a)
         for (int kt = 0; kt + 1 < nk; kt++) step(std::false_type{}, std::false_type{});
         step(std::true_type{}, std::false_type{});
     }
+#ifdef MBN_LAB
+    if (clk) { g_stream_clk[1] = __builtin_amdgcn_s_memtime(); g_stream_clk[3] = __builtin_amdgcn_s_memrealtime(); }
+#endif
 }
 
 }   // namespace
@@ -411,5 +422,13 @@ int mbn_launch_bf16_pw_big(const mbn_call &c, void *out, const void *in, const v
 #endif
     hipLaunchKernelGGL((pw_stream_bf16<ShapeBig, 0>), dim3((unsigned)cus), dim3(NT), 0, c.stream, a);
     return MBN_OK;
+}
+
+// lab diagnostic: the clock stamps of the last streaming-GEMM launch (see g_stream_clk)
+extern "C" int mbn_debug_stream_clock(unsigned long long *host4)
+{
+    if (!host4) return MBN_EINVAL;
+    if (hipDeviceSynchronize() != hipSuccess) return MBN_EDEVICE;
+    return hipMemcpyFromSymbol(host4, HIP_SYMBOL(g_stream_clk), sizeof(g_stream_clk)) == hipSuccess ? MBN_OK : MBN_EDEVICE;
 }
 #endif
