@@ -51,6 +51,7 @@ struct PwArgs {
     int fast_epi;   // 0 = always the general epilogue (A/B hook: tune conv_variant=9)
     int loop2;      // 1 = software-pipelined k-loop (default); 0 = plain loop (A/B hook: tune conv_variant=8)
     int no_ss;      // 1 = epilogue reads scale/shift from global memory as in round 1 (A/B hook: tune conv_variant=7)
+    int no_cw;      // 1 = __syncthreads() (vmcnt(0)) also at the first barrier behind a fast epilogue (lab A/B: exp0 = 77)
     int xn;         // XCD groups along n (1, 2 or 4): > 1 when the filter does not fit an XCD's L2 next to the streamed A panels
 };
 
@@ -222,6 +223,9 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void pw_gemm(PwArgs a)
         lds_dma_rows(a.filt, b_bytes, base + BM * BKF, b_vo, kb, wave_u, B_LD, NT);
     };
 
+    constexpr int NSTF_ = PAIRN ? 8 * MI * NI : 16 * MI * NI;      // store instructions per lane of the fast epilogue
+    constexpr int NSTF = NSTF_ > 63 ? 63 : NSTF_;                  // (vmcnt is a 6-bit counter)
+    bool prev_fast = false;                                        // the previous tile of this workgroup left through the fast epilogue
     long m0;
     int n0;
     int vb = blockIdx.x;
@@ -278,7 +282,11 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void pw_gemm(PwArgs a)
 
         // ---- K loop of this tile (registers — or, with GLDS, LDS buffer 0 in flight — hold its k-tile 0 on entry)
         if (!GLDS) stage_store(0);
-        __syncthreads();              // with a glds outstanding hipcc emits s_waitcnt vmcnt(0) ahead of the barrier
+        // with a glds outstanding hipcc emits s_waitcnt vmcnt(0) ahead of __syncthreads(): behind a tile's epilogue that also waits for every
+        // store of it to be acknowledged. The fast epilogue issues exactly NSTF stores, all YOUNGER than this tile's first LDS-DMA (issued ahead of
+        // them, below): a counted wait leaves them in flight for one more k-tile (vmcnt retires in order)
+        if (GLDS && prev_fast) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NSTF) : "memory");
+        else __syncthreads();
         if (GLDS && a.loop2) {
             // Software-pipelined form (default): the LDS fragments of group g+1 are requested before the MFMAs of group g
             // — for the last group of a k-tile that is group 0 of the next buffer, right behind the hand-over barrier — so
@@ -391,9 +399,11 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void pw_gemm(PwArgs a)
         // fp32: one store instruction writes two 128-B row segments (full cache lines). bf16 with an even number of column
         // blocks per wave (PAIRN): the filter rows were staged channel-paired, so blocks 2t and 2t+1 hold adjacent channels
         // and mbn_store_relu6_bf16_pair writes the same two 128-B segments per instruction with packed pairs.
+        prev_fast = false;
         if (!(BF && a.out_f32) && a.act == MBN_ACT_RELU6 && a.scale && a.shift && cm0 + BM <= a.m && cn0 + BN <= a.n &&
             g_fast_epilogue && (!PAIRN || (a.n & 1) == 0)) {
             // interior tile of a BN + ReLU6 layer (every pointwise layer of the network): lean stores, mbn_epilogue.h
+            prev_fast = ss_lds && a.loop2 && !a.no_cw;
             const float *scp = ss_lds ? sc_s : a.scale, *shp = ss_lds ? sh_s : a.shift;
             if constexpr (PAIRN) {
                 if (ss_lds) mbn_store_relu6_bf16_pair<MI, NI, 0>(orsrc, (unsigned)a.n, (unsigned)cm0 + wm_u, cn0 + wn_u, lane, acc, sc_s, sh_s);
@@ -532,6 +542,7 @@ int mbn_launch_f32_pointwise(const mbn_call &c, void *out, const void *in, const
     a.loop2 = (g_mbn_tune.conv_variant == 8 || ((cin / (bf ? 64 : 32)) & 1) || (cin % (bf ? 64 : 32)) ||
                (double)m * cin * (bf ? 2 : 4) >= 4294967296.0 || (double)op_size * cin * (bf ? 2 : 4) >= 4294967296.0) ? 0 : 1;
     a.no_ss = g_mbn_tune.conv_variant == 7 ? 1 : 0;
+    a.no_cw = g_mbn_tune.exp0 == 77 ? 1 : 0;
     a.fast_epi = (g_mbn_tune.conv_variant == 9 || (double)m * op_size * 4.0 >= 4294967296.0) ? 0 : 1;   // buffer stores: < 4 GiB
     if (m <= 0 || (long)((m + 31) / 32) * ((op_size + 31) / 32) > 0x7fffffffL) return MBN_EINVAL;
     const int epc = bf ? 8 : 4;
