@@ -234,7 +234,9 @@ def configs_alt(args, env):
         a = copy.copy(args)
         for k, v in kw.items():
             setattr(a, k, v)
-        a.steps, a.warmup = (200, 20) if a.batch == 1 else (20, 5)
+        # 5 profiled steps each (per-kernel event pairs cost 5-9 us per launch: on these 0.6-1.9 ms steps 5 of 20 profiled steps took 4-9 % off
+        # `value`, profiles/r03/u_profiled_steps_cost.txt; 5 of 60 keep the evidence and 1-2 % of that)
+        a.steps, a.warmup = (200, 20) if a.batch == 1 else (60, 8)
         a.profile_every = max(1, a.steps // 5)
         a.no_cpu_variants = a.no_unfused_stages = a.no_pw_emul_alt = True
         a.cpu_images = 1 if a.batch == 1 else 8
