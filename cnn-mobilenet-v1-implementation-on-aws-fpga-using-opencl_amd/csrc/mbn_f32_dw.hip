@@ -405,6 +405,120 @@ __global__ __launch_bounds__(256) void dw_generic_nhwc(DwArgs a, int fs, int str
     reinterpret_cast<T *>(a.out)[t] = (T)v;
 }
 
+#ifdef MBN_LAB
+// ---- round 3, LAB ONLY: the `north_star` form ("LDS-staged 3x3 input halos"), fp32, C % 32 == 0. A workgroup owns (image, 32-channel slab,
+// column strip, row segment) and marches down its output rows; the input rows of the strip (64 pixels x 128 B = 8 KB each) go through a
+// RING of LDS rows filled by buffer_load ... lds, LAO output rows ahead of the row being computed (no VGPRs in flight; a pixel outside
+// the image carries an out-of-range offset and the DMA writes zeros = the padding). A lane computes ONE output pixel x 4 channels per
+// pass (two passes per row: 62 / 31 output pixels per strip) from nine ds_read_b128; stride 2 stores the strip's even input pixels in
+// the first half of a ring row and the odd ones in the second, so adjacent lanes read adjacent LDS pixels at both strides (no bank
+// conflicts). One raw s_barrier per output row with a counted vmcnt (the stores of a row are issued unconditionally — out-of-range when
+// the lane has no pixel — so the count is a constant). Same fma order as dw3x3_nhwc: same bits.
+struct DwLdsArgs {
+    float *out;
+    const float *in, *filt, *scale, *shift;
+    int batch, in_rows, in_cols, rows, cols, ch, pad_top, pad_left, act;
+    int nslab, nstrip, nseg, seg_rows, tw;      // tw = output pixels per strip
+    unsigned in_img_bytes, out_img_bytes;
+};
+
+template <int S>
+__global__ __launch_bounds__(256) void dw3x3_lds(DwLdsArgs a)
+{
+    constexpr int LAO = S == 1 ? 3 : 2;                 // look-ahead in output rows
+    constexpr int RING = S * LAO + 3;                   // 6 / 7 ring rows of 8 KB
+    constexpr int ROWF = 64 * 32;                       // floats per ring row
+    constexpr unsigned OOB = 0xF0000000u;
+    __shared__ __attribute__((aligned(16))) float ring[RING * ROWF];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int b = blockIdx.x;
+    const int strip = b % a.nstrip; b /= a.nstrip;
+    const int seg = b % a.nseg; b /= a.nseg;
+    const int slab = b % a.nslab;
+    const int n = b / a.nslab;
+    const int c0 = slab * 32, q = tid & 7;
+    const int ox0 = strip * a.tw;
+    const int oy0 = seg * a.seg_rows, oy1 = min(oy0 + a.seg_rows, a.rows);
+    const int ix0 = ox0 * S - a.pad_left;               // input column of ring pixel 0 (stride 1) / of relative column 0 (stride 2)
+    const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.in) + (size_t)n * a.in_rows * a.in_cols * a.ch, 0, a.in_img_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)n * a.rows * a.cols * a.ch, 0, a.out_img_bytes, 0x00020000);
+
+    // the two DMA pieces of this wave per input row: ring pixels (2 wave + k) * 8 + lane / 8; column part of the source offset, or OOB
+    unsigned col_off[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int sp = (wave_u * 2 + k) * 8 + (lane >> 3);                          // ring pixel slot 0..63
+        const int rel = S == 1 ? sp : (sp < 32 ? 2 * sp : 2 * (sp - 32) + 1);       // relative input column held in that slot
+        const int ix = ix0 + rel;
+        const bool ok = ix >= 0 && ix < a.in_cols && rel < a.tw * S + 2;
+        col_off[k] = ok ? (unsigned)((ix * a.ch + c0 + (lane & 7) * 4) * 4) : OOB;
+    }
+    const unsigned row_bytes = (unsigned)(a.in_cols * a.ch * 4);
+    auto issue_row = [&](int iy) __attribute__((always_inline)) {                 // input row iy -> ring slot iy mod RING (iy may be outside: zeros)
+        int slot = (iy + 2 * RING) % RING;                                          // iy >= -1
+        const bool rok = iy >= 0 && iy < a.in_rows;
+        const int soff = rok ? iy * (int)row_bytes : 0;
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(irsrc, (__attribute__((address_space(3))) void *)(ring + slot * ROWF + (wave_u * 2 + k) * 256),
+                                                     16, rok ? col_off[k] : OOB, soff, 0, 0);
+    };
+    f4 w[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) w[k] = ld4(a.filt + (long)k * a.ch + c0 + q * 4);
+    const f4 sc = a.scale ? ld4(a.scale + c0 + q * 4) : f4{ 1.f, 1.f, 1.f, 1.f };
+    const f4 sh = a.shift ? ld4(a.shift + c0 + q * 4) : f4{ 0.f, 0.f, 0.f, 0.f };
+    // this lane's output pixels (pass 0 / 1) and their LDS pixel slots of the three taps of a row
+    int px[2];
+    unsigned st_off[2];
+#pragma unroll
+    for (int ps = 0; ps < 2; ps++) {
+        px[ps] = (tid >> 3) + 32 * ps;
+        const bool ok = px[ps] < a.tw && ox0 + px[ps] < a.cols;
+        st_off[ps] = ok ? (unsigned)(((ox0 + px[ps]) * a.ch + c0 + q * 4) * 4) : OOB;
+        if (!ok) px[ps] = 0;                                                        // reads stay inside the ring row
+    }
+    auto tap_slot = [&](int p, int dx) __attribute__((always_inline)) {
+        if (S == 1) return p + dx;
+        return dx == 1 ? 32 + p : p + (dx >> 1);                                    // 2p (even), 2p+1 (odd half), 2p+2 (even)
+    };
+    const int iy_first = oy0 * S - a.pad_top;
+    // prologue: the rows of output rows oy0 .. oy0 + LAO - 1 (first one: 3 rows, then S per row); every iteration then issues S rows
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                // the tap / scale loads above: keep the counted waits below exact
+    for (int r = 0; r < 3 + S * (LAO - 1); r++) issue_row(iy_first + r);
+    for (int oy = oy0; oy < oy1; oy++) {
+        const int iy = oy * S - a.pad_top;
+        // rows iy .. iy+2 have landed for every wave: younger than them are (LAO - 1) x (S rows x 2 pieces + 2 stores), and — except in
+        // the first iteration, whose prologue issued no stores — 2 more stores
+        // (iterations 1 .. LAO-1 still wait for rows of the prologue: 2 S (LAO - 1 - t) younger pieces of it + t x (2 S pieces + 2 stores))
+        const int t = oy - oy0;
+        if (t == 0) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((LAO - 1) * 2 * S) : "memory");
+        else if (t == 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((LAO - 1) * 2 * S + 2) : "memory");
+        else if (t == 2 && LAO > 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((LAO - 1) * 2 * S + 4) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 + (LAO - 1) * (2 * S + 2)) : "memory");
+        // rows of output row oy + LAO (their ring slots held rows of output row oy - 1 and older: every wave is past them)
+#pragma unroll
+        for (int r = 0; r < S; r++) issue_row(iy + 2 + S * (LAO - 1) + 1 + r);
+        const unsigned orow = (unsigned)(oy * a.cols * a.ch * 4);
+#pragma unroll
+        for (int ps = 0; ps < 2; ps++) {
+            f4 acc = f4{ 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+            for (int dy = 0; dy < 3; dy++) {
+                const float *rp = ring + ((iy + dy + 2 * RING) % RING) * ROWF + q * 4;
+#pragma unroll
+                for (int dx = 0; dx < 3; dx++) acc = fma4(*reinterpret_cast<const f4 *>(rp + tap_slot(px[ps], dx) * 32), w[dy * 3 + dx], acc);
+            }
+            acc = act4(fma4(acc, sc, sh), a.act);
+            typedef unsigned u4e __attribute__((ext_vector_type(4)));
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4e, acc), orsrc, st_off[ps] == OOB ? OOB : st_off[ps] + orow, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+#endif
+
 template <typename T>
 int launch_dw(const mbn_call &c, DwArgs &a, int rows, int cols, int fs, int stride, int channels)
 {
@@ -497,6 +611,32 @@ int launch_dw(const mbn_call &c, DwArgs &a, int rows, int cols, int fs, int stri
     }
 #endif
 #ifdef MBN_LAB
+    // LAB ONLY: the LDS-staged form (exp0 = 6), fp32, C % 32 == 0
+    if (g_mbn_tune.exp0 == 6 && sizeof(T) == 4 && (channels % 32) == 0 && (double)a.in_rows * a.in_cols * channels * 4 < 3.5e9 &&
+        (double)rows * cols * channels * 4 < 3.5e9) {
+        DwLdsArgs l;
+        l.out = (float *)a.out; l.in = (const float *)a.in; l.filt = a.filt; l.scale = a.scale; l.shift = a.shift;
+        l.batch = a.batch; l.in_rows = a.in_rows; l.in_cols = a.in_cols; l.rows = a.rows; l.cols = a.cols; l.ch = a.ch;
+        l.pad_top = a.pad_top; l.pad_left = a.pad_left; l.act = a.act;
+        l.tw = stride == 1 ? 62 : 31;
+        l.nstrip = (cols + l.tw - 1) / l.tw;
+        l.tw = (cols + l.nstrip - 1) / l.nstrip;                       // even strips (112 -> 2 x 56)
+        l.nslab = channels / 32;
+        const long base = (long)c.batch * l.nslab * l.nstrip;
+        const long want = 8L * 3 * c.ctx->num_cus;                    // >= 8 rounds of the resident workgroups, >= 4 rows per segment
+        int ns = (int)((want + base - 1) / base);
+        if (g_mbn_tune.dw_nseg > 0) ns = g_mbn_tune.dw_nseg;
+        if (ns > rows / 4) ns = rows / 4 > 0 ? rows / 4 : 1;
+        if (ns < 1) ns = 1;
+        l.seg_rows = (rows + ns - 1) / ns;
+        l.nseg = (rows + l.seg_rows - 1) / l.seg_rows;
+        l.in_img_bytes = (unsigned)((size_t)a.in_rows * a.in_cols * channels * 4);
+        l.out_img_bytes = (unsigned)((size_t)rows * cols * channels * 4);
+        const dim3 g((unsigned)(base * l.nseg));
+        if (stride == 1) hipLaunchKernelGGL(dw3x3_lds<1>, g, dim3(256), 0, c.stream, l);
+        else hipLaunchKernelGGL(dw3x3_lds<2>, g, dim3(256), 0, c.stream, l);
+        return MBN_OK;
+    }
     // LAB ONLY (slower, profiles/r03/f_depthwise_variants.txt): branch-free buffer loads, exp0 = 2 without / 3 with one row of look-ahead
     const bool small_in = (double)c.batch * a.in_rows * a.in_cols * channels * sizeof(T) < 1073741824.0;
     const int dv = g_mbn_tune.exp0;

@@ -225,6 +225,41 @@ def test_f32_depthwise(pkg, orc, ctx, shape, act):
         b.free()
 
 
+@pytest.mark.parametrize("shape", [(2, 112, 32, 1), (2, 112, 64, 2), (3, 56, 128, 1), (2, 56, 128, 2), (2, 28, 256, 1), (5, 14, 512, 1), (3, 14, 512, 2),
+                                   (2, 7, 1024, 1), (1, 40, 32, 1), (2, 70, 64, 1), (1, 37, 96, 2), (1, 130, 32, 1), (1, 5, 32, 1), (2, 9, 64, 2)])
+def test_f32_depthwise_lds_staged_form(pkg, orc, ctx, shape):
+    """LAB: dw3x3_lds (north_star's 'LDS-staged 3x3 input halos': input rows of a column strip through a ring of LDS rows filled by
+    buffer_load ... lds, nine ds_read_b128 per output pixel) against the oracle and bit for bit against the shipped register column march
+    (same fma order); strips (widths above 62 / 31 output pixels), row segments, odd sizes, both strides, no store outside the output."""
+    _tune_lab(ctx, b"exp0", 6)
+    n, h, ch, stride = shape
+    rng = np.random.default_rng(h * 5 + ch + stride)
+    x = rng.uniform(-1, 1, (n, h, h, ch)).astype(np.float32)
+    f = rng.normal(0, 0.5, (3, 3, ch)).astype(np.float32)
+    sc, sh = rng.uniform(0.5, 1.5, ch).astype(np.float32), rng.normal(0, 0.1, ch).astype(np.float32)
+    want = orc.f32_depthwise(x, f, sc, sh, stride, 2)
+    oh = want.shape[1]
+    d_x, d_f, d_sc, d_sh = (ctx.to_device(a) for a in (x, f, sc, sh))
+    d_o, d_p = ctx.alloc(want.nbytes + 64), ctx.alloc(want.nbytes)
+    ext = pkg.make_ext(batch=n, act=2, in_rows=h, in_cols=h, scale=d_sc.ptr, shift=d_sh.ptr)
+    for nseg in (0, 1, 3):
+        ctx.lib.mbn_tune_set(b"dw_nseg", nseg)
+        ctx.lib.mbn_memset(ctx.h, d_o.ptr, 0xFF, want.nbytes + 64)
+        ctx.depthwise(d_o.ptr, d_x.ptr, d_f.ptr, oh, oh, 3, stride, ch, ext)
+        ctx.sync()
+        raw = d_o.download((want.size + 16,), np.float32)
+        assert np.all(raw[want.size:].view(np.uint32) == 0xFFFFFFFF), "stores past the output"
+        got = raw[:want.size].reshape(want.shape)
+        assert_close(got, want, TOL_DW, "dw lds %s nseg %d" % (shape, nseg))
+    ctx.lib.mbn_tune_set(b"dw_nseg", 0)
+    ctx.lib.mbn_tune_set(b"exp0", 0)
+    ctx.depthwise(d_p.ptr, d_x.ptr, d_f.ptr, oh, oh, 3, stride, ch, ext)
+    ctx.sync()
+    assert np.array_equal(got, d_p.download(want.shape, np.float32)), "LDS-staged form differs from the column march"
+    for b in (d_x, d_f, d_sc, d_sh, d_o, d_p):
+        b.free()
+
+
 def test_f32_depthwise_explicit_padding_and_generic_path(pkg, orc, ctx):
     """pad_top/left = 1 with stride 2 (the reference's top/left convention, B6) and a channel count that is
     not a multiple of 4 (generic kernel)."""
