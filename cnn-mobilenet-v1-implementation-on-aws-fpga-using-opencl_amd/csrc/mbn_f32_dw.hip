@@ -405,8 +405,10 @@ __global__ __launch_bounds__(256) void dw_generic_nhwc(DwArgs a, int fs, int str
     reinterpret_cast<T *>(a.out)[t] = (T)v;
 }
 
-#ifdef MBN_LAB
-// ---- round 3, LAB ONLY: the `north_star` form ("LDS-staged 3x3 input halos"), fp32, C % 32 == 0. A workgroup owns (image, 32-channel slab,
+// ---- round 3: the `north_star` form ("LDS-staged 3x3 input halos"), fp32, C % 32 == 0. SHIPPED for stride 1 on maps at least 50 pixels wide
+// whose input + output do not fit the Infinity Cache (layers 2 and 6 at batch 256: -6 % / -5 % against the register column march below,
+// profiles/r03/f_depthwise_variants.txt (e)); every other instantiation and the forcing knobs are lab-only (narrow maps, stride 2 and
+// cache-resident sizes measured equal or slower). A workgroup owns (image, 32-channel slab,
 // column strip, row segment) and marches down its output rows; the input rows of the strip (64 pixels x 128 B = 8 KB each) go through a
 // RING of LDS rows filled by buffer_load ... lds, LAO output rows ahead of the row being computed (no VGPRs in flight; a pixel outside
 // the image carries an out-of-range offset and the DMA writes zeros = the padding). A lane computes ONE output pixel x 4 channels per
@@ -422,12 +424,17 @@ struct DwLdsArgs {
     unsigned in_img_bytes, out_img_bytes;
 };
 
-template <int S>
+// S = stride, LAO = look-ahead in output rows, CH = channels per slab: a ring row is 8 KB = 64 pixels x 32 channels or 32 pixels x 64 channels
+// (narrow maps: 28-wide rows fill a 32-pixel ring row, and 16 lanes = one pixel's 256 bytes, conflict-free as well)
+template <int S, int LAO, int CH>
 __global__ __launch_bounds__(256) void dw3x3_lds(DwLdsArgs a)
 {
-    constexpr int LAO = S == 1 ? 3 : 2;                 // look-ahead in output rows
-    constexpr int RING = S * LAO + 3;                   // 6 / 7 ring rows of 8 KB
-    constexpr int ROWF = 64 * 32;                       // floats per ring row
+    constexpr int RING = S * LAO + 3;                   // ring rows of 8 KB
+    constexpr int ROWF = 2048;                          // floats per ring row
+    constexpr int PX = ROWF / CH;                       // pixels per ring row (64 / 32)
+    constexpr int QL = CH / 4;                          // lanes per pixel (8 / 16)
+    constexpr int PP = 256 / QL;                        // pixels per pass (32 / 16): two passes per row
+    constexpr int PPC = 64 / QL;                        // pixels per DMA piece (8 / 4)
     constexpr unsigned OOB = 0xF0000000u;
     __shared__ __attribute__((aligned(16))) float ring[RING * ROWF];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -437,26 +444,26 @@ __global__ __launch_bounds__(256) void dw3x3_lds(DwLdsArgs a)
     const int seg = b % a.nseg; b /= a.nseg;
     const int slab = b % a.nslab;
     const int n = b / a.nslab;
-    const int c0 = slab * 32, q = tid & 7;
+    const int c0 = slab * CH, q = tid % QL;
     const int ox0 = strip * a.tw;
     const int oy0 = seg * a.seg_rows, oy1 = min(oy0 + a.seg_rows, a.rows);
-    const int ix0 = ox0 * S - a.pad_left;               // input column of ring pixel 0 (stride 1) / of relative column 0 (stride 2)
+    const int ix0 = ox0 * S - a.pad_left;               // input column of relative column 0
     const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.in) + (size_t)n * a.in_rows * a.in_cols * a.ch, 0, a.in_img_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)n * a.rows * a.cols * a.ch, 0, a.out_img_bytes, 0x00020000);
 
-    // the two DMA pieces of this wave per input row: ring pixels (2 wave + k) * 8 + lane / 8; column part of the source offset, or OOB
+    // the two DMA pieces of this wave per input row: ring pixels (2 wave + k) * PPC + lane / QL; column part of the source offset, or OOB
     unsigned col_off[2];
 #pragma unroll
     for (int k = 0; k < 2; k++) {
-        const int sp = (wave_u * 2 + k) * 8 + (lane >> 3);                          // ring pixel slot 0..63
-        const int rel = S == 1 ? sp : (sp < 32 ? 2 * sp : 2 * (sp - 32) + 1);       // relative input column held in that slot
+        const int sp = (wave_u * 2 + k) * PPC + lane / QL;                            // ring pixel slot 0..PX-1
+        const int rel = S == 1 ? sp : (sp < PX / 2 ? 2 * sp : 2 * (sp - PX / 2) + 1); // relative input column held in that slot
         const int ix = ix0 + rel;
         const bool ok = ix >= 0 && ix < a.in_cols && rel < a.tw * S + 2;
-        col_off[k] = ok ? (unsigned)((ix * a.ch + c0 + (lane & 7) * 4) * 4) : OOB;
+        col_off[k] = ok ? (unsigned)((ix * a.ch + c0 + (lane % QL) * 4) * 4) : OOB;
     }
     const unsigned row_bytes = (unsigned)(a.in_cols * a.ch * 4);
     auto issue_row = [&](int iy) __attribute__((always_inline)) {                 // input row iy -> ring slot iy mod RING (iy may be outside: zeros)
-        int slot = (iy + 2 * RING) % RING;                                          // iy >= -1
+        const int slot = (iy + 2 * RING) % RING;                                    // iy >= -1
         const bool rok = iy >= 0 && iy < a.in_rows;
         const int soff = rok ? iy * (int)row_bytes : 0;
 #pragma unroll
@@ -474,14 +481,14 @@ __global__ __launch_bounds__(256) void dw3x3_lds(DwLdsArgs a)
     unsigned st_off[2];
 #pragma unroll
     for (int ps = 0; ps < 2; ps++) {
-        px[ps] = (tid >> 3) + 32 * ps;
+        px[ps] = tid / QL + PP * ps;
         const bool ok = px[ps] < a.tw && ox0 + px[ps] < a.cols;
         st_off[ps] = ok ? (unsigned)(((ox0 + px[ps]) * a.ch + c0 + q * 4) * 4) : OOB;
         if (!ok) px[ps] = 0;                                                        // reads stay inside the ring row
     }
     auto tap_slot = [&](int p, int dx) __attribute__((always_inline)) {
         if (S == 1) return p + dx;
-        return dx == 1 ? 32 + p : p + (dx >> 1);                                    // 2p (even), 2p+1 (odd half), 2p+2 (even)
+        return dx == 1 ? PX / 2 + p : p + (dx >> 1);                                // 2p (even), 2p+1 (odd half), 2p+2 (even)
     };
     const int iy_first = oy0 * S - a.pad_top;
     // prologue: the rows of output rows oy0 .. oy0 + LAO - 1 (first one: 3 rows, then S per row); every iteration then issues S rows
@@ -489,14 +496,20 @@ __global__ __launch_bounds__(256) void dw3x3_lds(DwLdsArgs a)
     for (int r = 0; r < 3 + S * (LAO - 1); r++) issue_row(iy_first + r);
     for (int oy = oy0; oy < oy1; oy++) {
         const int iy = oy * S - a.pad_top;
-        // rows iy .. iy+2 have landed for every wave: younger than them are (LAO - 1) x (S rows x 2 pieces + 2 stores), and — except in
-        // the first iteration, whose prologue issued no stores — 2 more stores
-        // (iterations 1 .. LAO-1 still wait for rows of the prologue: 2 S (LAO - 1 - t) younger pieces of it + t x (2 S pieces + 2 stores))
+        // rows iy .. iy+2 have landed for every wave. Younger than them in the steady state (t >= LAO): 2 stores of iteration t - LAO and
+        // (LAO - 1) x (S rows x 2 pieces + 2 stores); iterations t < LAO still wait for rows of the prologue: 2 S (LAO - 1 - t) younger
+        // pieces of it + t x (2 S pieces + 2 stores) = 2 S (LAO - 1) + 2 t
         const int t = oy - oy0;
-        if (t == 0) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((LAO - 1) * 2 * S) : "memory");
-        else if (t == 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((LAO - 1) * 2 * S + 2) : "memory");
-        else if (t == 2 && LAO > 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((LAO - 1) * 2 * S + 4) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 + (LAO - 1) * (2 * S + 2)) : "memory");
+#define MBN_DWL_WAIT(N) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((N) > 63 ? 63 : (N)) : "memory")
+        if (t >= LAO) MBN_DWL_WAIT(2 + (LAO - 1) * (2 * S + 2));
+        else if (t == 0) MBN_DWL_WAIT((LAO - 1) * 2 * S);
+        else if (t == 1) MBN_DWL_WAIT((LAO - 1) * 2 * S + 2);
+        else if (t == 2) MBN_DWL_WAIT((LAO - 1) * 2 * S + 4);
+        else if (t == 3) MBN_DWL_WAIT((LAO - 1) * 2 * S + 6);
+        else if (t == 4) MBN_DWL_WAIT((LAO - 1) * 2 * S + 8);
+        else MBN_DWL_WAIT((LAO - 1) * 2 * S + 10);
+#undef MBN_DWL_WAIT
+        static_assert(LAO <= 6, "the chain above covers t < LAO <= 6");
         // rows of output row oy + LAO (their ring slots held rows of output row oy - 1 and older: every wave is past them)
 #pragma unroll
         for (int r = 0; r < S; r++) issue_row(iy + 2 + S * (LAO - 1) + 1 + r);
@@ -508,7 +521,7 @@ __global__ __launch_bounds__(256) void dw3x3_lds(DwLdsArgs a)
             for (int dy = 0; dy < 3; dy++) {
                 const float *rp = ring + ((iy + dy + 2 * RING) % RING) * ROWF + q * 4;
 #pragma unroll
-                for (int dx = 0; dx < 3; dx++) acc = fma4(*reinterpret_cast<const f4 *>(rp + tap_slot(px[ps], dx) * 32), w[dy * 3 + dx], acc);
+                for (int dx = 0; dx < 3; dx++) acc = fma4(*reinterpret_cast<const f4 *>(rp + tap_slot(px[ps], dx) * CH), w[dy * 3 + dx], acc);
             }
             acc = act4(fma4(acc, sc, sh), a.act);
             typedef unsigned u4e __attribute__((ext_vector_type(4)));
@@ -517,7 +530,58 @@ __global__ __launch_bounds__(256) void dw3x3_lds(DwLdsArgs a)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
 }
+
+// launch of the LDS-staged form; `la` = look-ahead variant (0 = short ring, 1 = long ring), ch64 = 64-channel slabs (32-pixel ring rows)
+static int launch_dw_lds(const mbn_call &c, const DwArgs &a, int rows, int cols, int stride, int channels, bool ch64, int la, int nseg_force)
+{
+    DwLdsArgs l;
+    l.out = (float *)a.out; l.in = (const float *)a.in; l.filt = a.filt; l.scale = a.scale; l.shift = a.shift;
+    l.batch = a.batch; l.in_rows = a.in_rows; l.in_cols = a.in_cols; l.rows = a.rows; l.cols = a.cols; l.ch = a.ch;
+    l.pad_top = a.pad_top; l.pad_left = a.pad_left; l.act = a.act;
+    const int px = ch64 ? 32 : 64;
+    l.tw = stride == 1 ? px - 2 : (px - 1) / 2;
+    l.nstrip = (cols + l.tw - 1) / l.tw;
+    l.tw = (cols + l.nstrip - 1) / l.nstrip;                       // even strips (112 -> 2 x 56)
+    l.nslab = channels / (ch64 ? 64 : 32);
+    const int lao = stride == 1 ? (la ? 6 : 3) : (la ? 3 : 2);
+    const int ring_kb = 8 * (stride * lao + 3);
+    const long slots = (long)c.ctx->num_cus * (160 / ring_kb);      // resident workgroups
+    const long base = (long)c.batch * l.nslab * l.nstrip;
+    // row segments: a whole number of rounds of the resident workgroups (no tail), as few segments as that allows (each re-reads halo rows)
+    int ns = 1;
+    if (nseg_force > 0) ns = nseg_force;
+    else if (base > slots || base * 10 < slots * 6) {
+        double best = 1e30;
+        for (int k = 1; k <= rows / 8 && k <= 16; k++) {
+            const int sr = (rows + k - 1) / k, kk = (rows + sr - 1) / sr;
+            const double w = (double)base * kk / slots;
+            const double rounds = w <= 1.0 ? (w >= 0.6 ? w : 0.6) : ceil(w);      // under-filled is fine down to 60 % of the slots
+            const double cost = rounds / w * (1.0 + 0.5 / sr);
+            if (cost < best - 1e-9) { best = cost; ns = k; }
+        }
+    }
+    if (ns > rows) ns = rows;
+    l.seg_rows = (rows + ns - 1) / ns;
+    l.nseg = (rows + l.seg_rows - 1) / l.seg_rows;
+    l.in_img_bytes = (unsigned)((size_t)a.in_rows * a.in_cols * channels * 4);
+    l.out_img_bytes = (unsigned)((size_t)rows * cols * channels * 4);
+    const dim3 g((unsigned)(base * l.nseg));
+#define MBN_DWL(S_, L_, C_) hipLaunchKernelGGL((dw3x3_lds<S_, L_, C_>), g, dim3(256), 0, c.stream, l)
+#ifdef MBN_LAB
+    if (stride == 1) {
+        if (ch64) { if (la) MBN_DWL(1, 6, 64); else MBN_DWL(1, 3, 64); }
+        else { if (la) MBN_DWL(1, 6, 32); else MBN_DWL(1, 3, 32); }
+    } else {
+        if (ch64) { if (la) MBN_DWL(2, 3, 64); else MBN_DWL(2, 2, 64); }
+        else { if (la) MBN_DWL(2, 3, 32); else MBN_DWL(2, 2, 32); }
+    }
+#else
+    if (stride != 1 || ch64 || la) return MBN_EUNSUPPORTED;       // the shipped library holds the one instantiation its rule can reach
+    MBN_DWL(1, 3, 32);
 #endif
+#undef MBN_DWL
+    return MBN_OK;
+}
 
 template <typename T>
 int launch_dw(const mbn_call &c, DwArgs &a, int rows, int cols, int fs, int stride, int channels)
@@ -610,32 +674,20 @@ int launch_dw(const mbn_call &c, DwArgs &a, int rows, int cols, int fs, int stri
         return MBN_OK;
     }
 #endif
+    // the LDS-staged form where it measured faster: fp32, stride 1, maps >= 50 pixels wide, tensors beyond the Infinity Cache
+    // (lab: exp0 = 1 never)
+    if (sizeof(T) == 4 && stride == 1 && cols >= 50 && (channels % 32) == 0 && g_mbn_tune.exp0 == 0 &&
+        (double)c.batch * (a.in_rows * a.in_cols + rows * cols) * channels * 4 >= 512.0 * 1048576 &&
+        (double)a.in_rows * a.in_cols * channels * 4 < 3.5e9 && (double)rows * cols * channels * 4 < 3.5e9)
+        return launch_dw_lds(c, a, rows, cols, stride, channels, false, 0, g_mbn_tune.dw_nseg);
 #ifdef MBN_LAB
-    // LAB ONLY: the LDS-staged form (exp0 = 6), fp32, C % 32 == 0
-    if (g_mbn_tune.exp0 == 6 && sizeof(T) == 4 && (channels % 32) == 0 && (double)a.in_rows * a.in_cols * channels * 4 < 3.5e9 &&
-        (double)rows * cols * channels * 4 < 3.5e9) {
-        DwLdsArgs l;
-        l.out = (float *)a.out; l.in = (const float *)a.in; l.filt = a.filt; l.scale = a.scale; l.shift = a.shift;
-        l.batch = a.batch; l.in_rows = a.in_rows; l.in_cols = a.in_cols; l.rows = a.rows; l.cols = a.cols; l.ch = a.ch;
-        l.pad_top = a.pad_top; l.pad_left = a.pad_left; l.act = a.act;
-        l.tw = stride == 1 ? 62 : 31;
-        l.nstrip = (cols + l.tw - 1) / l.tw;
-        l.tw = (cols + l.nstrip - 1) / l.nstrip;                       // even strips (112 -> 2 x 56)
-        l.nslab = channels / 32;
-        const long base = (long)c.batch * l.nslab * l.nstrip;
-        const long want = 8L * 3 * c.ctx->num_cus;                    // >= 8 rounds of the resident workgroups, >= 4 rows per segment
-        int ns = (int)((want + base - 1) / base);
-        if (g_mbn_tune.dw_nseg > 0) ns = g_mbn_tune.dw_nseg;
-        if (ns > rows / 4) ns = rows / 4 > 0 ? rows / 4 : 1;
-        if (ns < 1) ns = 1;
-        l.seg_rows = (rows + ns - 1) / ns;
-        l.nseg = (rows + l.seg_rows - 1) / l.seg_rows;
-        l.in_img_bytes = (unsigned)((size_t)a.in_rows * a.in_cols * channels * 4);
-        l.out_img_bytes = (unsigned)((size_t)rows * cols * channels * 4);
-        const dim3 g((unsigned)(base * l.nseg));
-        if (stride == 1) hipLaunchKernelGGL(dw3x3_lds<1>, g, dim3(256), 0, c.stream, l);
-        else hipLaunchKernelGGL(dw3x3_lds<2>, g, dim3(256), 0, c.stream, l);
-        return MBN_OK;
+    // LAB: the LDS-staged form forced: exp0 = 6 (32-channel slabs) / 7 (64-channel slabs), + 10 = long ring
+    {
+        const int e = g_mbn_tune.exp0;
+        const int kind = e % 10, la = e >= 10 && e < 20 ? 1 : 0;
+        if ((kind == 6 || kind == 7) && e < 20 && sizeof(T) == 4 && (channels % (kind == 7 ? 64 : 32)) == 0 &&
+            (double)a.in_rows * a.in_cols * channels * 4 < 3.5e9 && (double)rows * cols * channels * 4 < 3.5e9)
+            return launch_dw_lds(c, a, rows, cols, stride, channels, kind == 7, la, g_mbn_tune.dw_nseg);
     }
     // LAB ONLY (slower, profiles/r03/f_depthwise_variants.txt): branch-free buffer loads, exp0 = 2 without / 3 with one row of look-ahead
     const bool small_in = (double)c.batch * a.in_rows * a.in_cols * channels * sizeof(T) < 1073741824.0;

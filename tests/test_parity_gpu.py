@@ -225,13 +225,45 @@ def test_f32_depthwise(pkg, orc, ctx, shape, act):
         b.free()
 
 
+@pytest.mark.parametrize("shape", [(160, 112, 32), (161, 56, 128)])
+def test_f32_depthwise_streaming_sizes_take_the_lds_staged_kernel(pkg, orc, ctx, shape):
+    """Stride-1 depthwise on maps >= 50 pixels wide whose input + output exceed 512 MB (layers 2 and 6 at the headline batch) run on
+    dw3x3_lds (input rows through an LDS ring by LDS-DMA): against the oracle on the first and last images, no store past the output, and
+    bit for bit equal to the register column march, which a call with the first 8 images alone takes (same fma order; an image's result
+    does not depend on the batch)."""
+    n, h, ch = shape
+    rng = np.random.default_rng(n + h + ch)
+    x = rng.uniform(-1, 1, (n, h, h, ch)).astype(np.float32)
+    f = rng.normal(0, 0.5, (3, 3, ch)).astype(np.float32)
+    sc, sh = rng.uniform(0.5, 1.5, ch).astype(np.float32), rng.normal(0, 0.1, ch).astype(np.float32)
+    sel = np.r_[0:3, n - 2:n]
+    want = orc.f32_depthwise(x[sel], f, sc, sh, 1, 2)
+    d_x, d_f, d_sc, d_sh = (ctx.to_device(a) for a in (x, f, sc, sh))
+    d_o, d_p = ctx.alloc(x.nbytes + 64), ctx.alloc(8 * h * h * ch * 4)
+    ctx.lib.mbn_memset(ctx.h, d_o.ptr, 0xFF, x.nbytes + 64)
+    ctx.depthwise(d_o.ptr, d_x.ptr, d_f.ptr, h, h, 3, 1, ch, pkg.make_ext(batch=n, act=2, in_rows=h, in_cols=h, scale=d_sc.ptr, shift=d_sh.ptr))
+    ctx.sync()
+    raw = d_o.download((x.size + 16,), np.float32)
+    assert np.all(raw[x.size:].view(np.uint32) == 0xFFFFFFFF), "stores past the output"
+    got = raw[:x.size].reshape(x.shape)
+    assert_close(got[sel], want, TOL_DW, "dw streaming size %s" % (shape,))
+    ctx.depthwise(d_p.ptr, d_x.ptr, d_f.ptr, h, h, 3, 1, ch, pkg.make_ext(batch=8, act=2, in_rows=h, in_cols=h, scale=d_sc.ptr, shift=d_sh.ptr))
+    ctx.sync()
+    assert np.array_equal(got[:8], d_p.download((8, h, h, ch), np.float32)), "LDS-staged kernel differs from the column march"
+    for b in (d_x, d_f, d_sc, d_sh, d_o, d_p):
+        b.free()
+
+
 @pytest.mark.parametrize("shape", [(2, 112, 32, 1), (2, 112, 64, 2), (3, 56, 128, 1), (2, 56, 128, 2), (2, 28, 256, 1), (5, 14, 512, 1), (3, 14, 512, 2),
                                    (2, 7, 1024, 1), (1, 40, 32, 1), (2, 70, 64, 1), (1, 37, 96, 2), (1, 130, 32, 1), (1, 5, 32, 1), (2, 9, 64, 2)])
-def test_f32_depthwise_lds_staged_form(pkg, orc, ctx, shape):
+@pytest.mark.parametrize("knob", [6, 7, 16, 17])
+def test_f32_depthwise_lds_staged_form(pkg, orc, ctx, shape, knob):
     """LAB: dw3x3_lds (north_star's 'LDS-staged 3x3 input halos': input rows of a column strip through a ring of LDS rows filled by
     buffer_load ... lds, nine ds_read_b128 per output pixel) against the oracle and bit for bit against the shipped register column march
-    (same fma order); strips (widths above 62 / 31 output pixels), row segments, odd sizes, both strides, no store outside the output."""
-    _tune_lab(ctx, b"exp0", 6)
+    (same fma order); strips (widths above 62 / 31 output pixels), row segments, odd sizes, both strides, no store outside the output.
+    knob: 6 = 32-channel slabs (64-pixel ring rows), 7 = 64-channel slabs (32-pixel ring rows; C % 64 != 0 falls back to the shipped
+    kernel), + 10 = the long ring (look-ahead 6 / 3 output rows)."""
+    _tune_lab(ctx, b"exp0", knob)
     n, h, ch, stride = shape
     rng = np.random.default_rng(h * 5 + ch + stride)
     x = rng.uniform(-1, 1, (n, h, h, ch)).astype(np.float32)
