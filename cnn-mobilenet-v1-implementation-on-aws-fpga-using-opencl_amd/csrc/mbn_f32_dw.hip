@@ -563,8 +563,9 @@ static int launch_dw_lds(const mbn_call &c, const DwArgs &a, int rows, int cols,
     if (ns > rows) ns = rows;
     l.seg_rows = (rows + ns - 1) / ns;
     l.nseg = (rows + l.seg_rows - 1) / l.seg_rows;
-    l.in_img_bytes = (unsigned)((size_t)a.in_rows * a.in_cols * channels * 4);
-    l.out_img_bytes = (unsigned)((size_t)rows * cols * channels * 4);
+    l.in_img_bytes = (unsigned)((size_t)a.in_rows * a.in_cols * channels * 4);      // one image: < 2^31 bytes (callers check), so the kernel's
+    l.out_img_bytes = (unsigned)((size_t)rows * cols * channels * 4);              // 32-bit row offsets cannot wrap
+    if ((double)base * l.nseg >= 2147483647.0) return MBN_EUNSUPPORTED;
     const dim3 g((unsigned)(base * l.nseg));
 #define MBN_DWL(S_, L_, C_) hipLaunchKernelGGL((dw3x3_lds<S_, L_, C_>), g, dim3(256), 0, c.stream, l)
 #ifdef MBN_LAB
@@ -678,16 +679,22 @@ int launch_dw(const mbn_call &c, DwArgs &a, int rows, int cols, int fs, int stri
     // (lab: exp0 = 1 never)
     if (sizeof(T) == 4 && stride == 1 && cols >= 50 && (channels % 32) == 0 && g_mbn_tune.exp0 == 0 &&
         (double)c.batch * (a.in_rows * a.in_cols + rows * cols) * channels * 4 >= 512.0 * 1048576 &&
-        (double)a.in_rows * a.in_cols * channels * 4 < 3.5e9 && (double)rows * cols * channels * 4 < 3.5e9)
-        return launch_dw_lds(c, a, rows, cols, stride, channels, false, 0, g_mbn_tune.dw_nseg);
+        (double)a.in_rows * a.in_cols * channels * 4 < 2.0e9 && (double)rows * cols * channels * 4 < 2.0e9)
+    {
+        const int rc = launch_dw_lds(c, a, rows, cols, stride, channels, false, 0, g_mbn_tune.dw_nseg);
+        if (rc != MBN_EUNSUPPORTED) return rc;                 // (grid too large: the column march below)
+    }
 #ifdef MBN_LAB
     // LAB: the LDS-staged form forced: exp0 = 6 (32-channel slabs) / 7 (64-channel slabs), + 10 = long ring
     {
         const int e = g_mbn_tune.exp0;
         const int kind = e % 10, la = e >= 10 && e < 20 ? 1 : 0;
         if ((kind == 6 || kind == 7) && e < 20 && sizeof(T) == 4 && (channels % (kind == 7 ? 64 : 32)) == 0 &&
-            (double)a.in_rows * a.in_cols * channels * 4 < 3.5e9 && (double)rows * cols * channels * 4 < 3.5e9)
-            return launch_dw_lds(c, a, rows, cols, stride, channels, kind == 7, la, g_mbn_tune.dw_nseg);
+            (double)a.in_rows * a.in_cols * channels * 4 < 2.0e9 && (double)rows * cols * channels * 4 < 2.0e9)
+        {
+            const int rc = launch_dw_lds(c, a, rows, cols, stride, channels, kind == 7, la, g_mbn_tune.dw_nseg);
+            if (rc != MBN_EUNSUPPORTED) return rc;
+        }
     }
     // LAB ONLY (slower, profiles/r03/f_depthwise_variants.txt): branch-free buffer loads, exp0 = 2 without / 3 with one row of look-ahead
     const bool small_in = (double)c.batch * a.in_rows * a.in_cols * channels * sizeof(T) < 1073741824.0;
