@@ -129,7 +129,11 @@ int mbn_launch_f32_pw_splitk(const mbn_call &c, float *out, const float *in, con
     // images — so every batch of 1..4 images takes the same kernel for a given layer, and S below depends on K alone:
     // forward(n)[:k] == forward(k) stays bit-exact within 1..4 images as it is within 5 and more.
     // Rule: pw_gemm's 64x64 tiles of a 4-image call would cover less than half of the CUs.
-    if (mode != 2 && mode != 16 && mode != 32) {            // 2 / 16 / 32: wherever the shape allows (16, 32: with that workgroup tile forced — tests)
+    // One pixel per image (the FC layer, MobileNet.c:2681-2763; pointwise layers on 1 x 1 maps): this kernel at EVERY batch. Measured
+    // (profiles/r03/v_fc_splitk.txt): 22 -> 7-13 us for 8 ... 256 images (pw_gemm's 64 x 64 tiles are 16 ... 64 workgroups walking all of K),
+    // equal at 512, slower from 1024 up (+15 us on a step of > 10 ms) — and the logits' summation order no longer depends on the batch at all.
+    const bool one_px = c.batch >= 1 && m == (long)c.batch;
+    if (mode != 2 && mode != 16 && mode != 32 && !one_px) {            // 2 / 16 / 32: wherever the shape allows (16, 32: with that workgroup tile forced — tests)
         if (c.batch < 1 || c.batch > 4 || m % c.batch) return MBN_EUNSUPPORTED;
         const long m4 = m / c.batch * 4;
         if (((m4 + 63) / 64) * ((op_size + 63) / 64) * 2 > c.ctx->num_cus) return MBN_EUNSUPPORTED;
