@@ -598,6 +598,7 @@ int launch_dw(const mbn_call &c, DwArgs &a, int rows, int cols, int fs, int stri
         hipLaunchKernelGGL(dw_generic_nhwc<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c.stream, a, fs, stride);
         return MBN_OK;
     }
+    const bool cache_resident = (double)c.batch * ((double)a.in_rows * a.in_cols + (double)rows * cols) * channels * sizeof(T) < 64.0 * 1048576;
     // variant: bits 0..1 = TW (0 = default 2), bit 4 = lanes across the full C instead of 64-channel slabs,
     // bit 5 = bf16 with 4-channel lanes (the first bf16 version; A/B hook)
     const int var = g_mbn_tune.dw_variant;
@@ -616,7 +617,7 @@ int launch_dw(const mbn_call &c, DwArgs &a, int rows, int cols, int fs, int stri
         else if (row_lanes < target) {
             nseg = (int)((target + row_lanes - 1) / row_lanes);
             int max_seg = rows / 4 > 0 ? rows / 4 : 1;
-            if (row_lanes * max_seg < (long)c.ctx->num_cus * 64) max_seg = rows;   // latency-bound (see the fp32 branch)
+            if (row_lanes * max_seg < (long)c.ctx->num_cus * 64 || cache_resident) max_seg = rows;   // latency-bound (see the fp32 branch)
             if (nseg > max_seg) nseg = max_seg;
         }
         if (nseg > rows) nseg = rows;
@@ -660,7 +661,10 @@ int launch_dw(const mbn_call &c, DwArgs &a, int rows, int cols, int fs, int stri
         // ... unless even that leaves less than one wave per CU (a few images): then the launch is bound by the length of a
         // lane's row march (one dependent memory round trip per row: 9-10 us for a 14-row map at batch 1), not by bytes, and
         // one output row per segment is best
-        if (row_lanes * max_seg < (long)c.ctx->num_cus * 64) max_seg = rows;
+        // ... or the tensors sit in L2 / Infinity Cache anyway (input + output under 64 MB: 5 ... 64 images on the 14 x 14 and 7 x 7 maps): the
+        // halo rows an extra segment re-reads come from cache, and shorter marches are what the launch is short of — measured 1-5 us per
+        // launch, 2.5-4.5 % of a forward at 8 ... 32 images (profiles/r03/w_depthwise_segments_small_batch.txt)
+        if (row_lanes * max_seg < (long)c.ctx->num_cus * 64 || cache_resident) max_seg = rows;
         if (nseg > max_seg) nseg = max_seg;
     }
     if (nseg > rows) nseg = rows;
