@@ -40,6 +40,11 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 typedef mbn_f16v f16v;
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 
+#ifdef MBN_LAB
+// lab: workgroups 0..7 (one per XCD) of the last pw_gemm launch: { s_memtime at start, at end (core clock cycles), s_memrealtime at start, at end (100 MHz) }
+__device__ unsigned long long g_pw_clk[8][4];
+#endif
+
 struct PwArgs {
     void *out;
     const void *in, *filt;
@@ -237,6 +242,10 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void pw_gemm(PwArgs a)
         vb_end = (cnt << 3) + x;                 // vb = 8 j + x < 8 cnt + x  <=>  j < cnt
     }
     if (vb >= vb_end) return;
+#ifdef MBN_LAB
+    const bool clk = blockIdx.x < 8 && threadIdx.x == 0;
+    if (clk) { g_pw_clk[blockIdx.x][0] = __builtin_amdgcn_s_memtime(); g_pw_clk[blockIdx.x][2] = __builtin_amdgcn_s_memrealtime(); }
+#endif
     set_tile(vb, m0, n0);
     if (GLDS) { if (a.loop2) stage_glds2(0, 0); else stage_glds(0, 0); }
     else stage_load(0);
@@ -463,6 +472,9 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void pw_gemm(PwArgs a)
         if (!more) break;
         vb = nvb;
     }
+#ifdef MBN_LAB
+    if (clk) { g_pw_clk[blockIdx.x][1] = __builtin_amdgcn_s_memtime(); g_pw_clk[blockIdx.x][3] = __builtin_amdgcn_s_memrealtime(); }
+#endif
 }
 
 // Fallback for K not a multiple of the 16-byte chunk or unaligned pointers: one lane per output element.
@@ -647,3 +659,14 @@ int mbn_launch_f32_pointwise(const mbn_call &c, void *out, const void *in, const
     }
     return MBN_OK;
 }
+
+#ifdef MBN_LAB
+// lab diagnostic: the clock stamps of the last pw_gemm launch (see g_pw_clk)
+extern "C" int mbn_debug_pw_clock(unsigned long long *host32)
+{
+    unsigned long long *host4 = host32;
+    if (!host4) return MBN_EINVAL;
+    if (hipDeviceSynchronize() != hipSuccess) return MBN_EDEVICE;
+    return hipMemcpyFromSymbol(host4, HIP_SYMBOL(g_pw_clk), sizeof(g_pw_clk)) == hipSuccess ? MBN_OK : MBN_EDEVICE;
+}
+#endif
