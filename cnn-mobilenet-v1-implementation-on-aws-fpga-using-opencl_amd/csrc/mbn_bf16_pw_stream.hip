@@ -103,7 +103,9 @@ __device__ __forceinline__ void dma2(__amdgpu_buffer_rsrc_t rsrc, float *slot, c
 // ABL (lab build only; 0 in the shipped kernel): ablation bits for timing — results are wrong with any of them set.
 //   1 = no LDS-DMA in the steps (the ring keeps what the prologue loaded), 2 = no fragment reads (one set read before the loop),
 //   4 = no MFMAs, 8 = no barriers (the counted waits stay), 16 = no epilogue stores
-template <typename SH, int ABL>
+// M16 (lab): the products on v_mfma_f32_16x16x32_bf16 instead of 32x32x16 — same LDS image, same bytes read per k-tile, the shape the chip holds a
+// higher clock under (tools/micro/mfma_shape_clock.hip); sums 32 products per instruction, so NOT bit-identical to the 32x32x16 kernels
+template <typename SH, int ABL, bool M16 = false>
 __global__ __launch_bounds__(SH::NT, 4) void pw_stream_bf16(StreamArgs a)
 {
     constexpr int BM = SH::BM, BN = SH::BN, WM = SH::WM, WN = SH::WN, MI = SH::MI, NI = SH::NI, WAVES_N = SH::WAVES_N, NT = SH::NT;
@@ -139,6 +141,13 @@ __global__ __launch_bounds__(SH::NT, 4) void pw_stream_bf16(StreamArgs a)
     for (int g = 0; g < 4; g++) {
         fr_a[g] = swz(wm + li, 2 * g + lh);
         fr_b[g] = swz(wn + li, 2 * g + lh);
+    }
+    // M16: lane (r = l & 15, q = l >> 4) holds k = 32 kg + 8 q .. + 7 of row r of a 16-row block: chunk 4 kg + q of the 128-byte row
+    [[maybe_unused]] int fr16_a[2], fr16_b[2];
+#pragma unroll
+    for (int kg = 0; kg < 2; kg++) {
+        fr16_a[kg] = swz(wm + (lane & 15), 4 * kg + (lane >> 4));
+        fr16_b[kg] = swz(wn + (lane & 15), 4 * kg + (lane >> 4));
     }
 
     // ---- issue cursors: the filter runs one k-tile ahead of the compute cursor, the activations two
@@ -210,6 +219,14 @@ __global__ __launch_bounds__(SH::NT, 4) void pw_stream_bf16(StreamArgs a)
     for (int ni = 0; ni < NI; ni++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[mi][ni][r] = 0.f;
+    constexpr int MI16 = WM / 16, NI16 = WN / 16;
+    [[maybe_unused]] f4 acc16[M16 ? MI16 : 1][M16 ? NI16 : 1];
+    if constexpr (M16) {
+#pragma unroll
+        for (int i = 0; i < MI16; i++)
+#pragma unroll
+            for (int j = 0; j < NI16; j++) acc16[i][j] = f4{ 0.f, 0.f, 0.f, 0.f };
+    }
     int cvb = blockIdx.x, cas = 0, cbs = 0;
     f4 fa_fix = f4{ 0.f, 0.f, 0.f, 0.f };
     if (ABL & 2) { stream_barrier<0>(); fa_fix = *reinterpret_cast<const f4 *>(lds + fr_a[0]); }
@@ -226,15 +243,25 @@ __global__ __launch_bounds__(SH::NT, 4) void pw_stream_bf16(StreamArgs a)
         else if (prev_end && !(ABL & 16)) stream_barrier<LDP * (AHEAD - 1) + NST, !(ABL & 8)>();
         else stream_barrier<LDP * (AHEAD - 1), !(ABL & 8)>();
         f2e sc, sh;
+        [[maybe_unused]] f2e sc16[2], sh16[2];
         int n0 = 0;
         unsigned m0 = 0;
         if constexpr (LAST) {                                            // ahead of this step's DMA: see the header
             const int lid = xcd_remap(cvb, nwg);
             n0 = (lid % a.nt) * BN;
             m0 = (unsigned)(lid / a.nt) * BM;
+            if constexpr (M16) {
+#pragma unroll
+                for (int jp = 0; jp < 2; jp++) {
+                    const unsigned co16 = (unsigned)(n0 + wn + 32 * jp + 2 * (lane & 15)) * 4u;
+                    sc16[jp] = __builtin_bit_cast(f2e, __builtin_amdgcn_raw_buffer_load_b64(scrsrc, co16, 0, 0));
+                    sh16[jp] = __builtin_bit_cast(f2e, __builtin_amdgcn_raw_buffer_load_b64(shrsrc, co16, 0, 0));
+                }
+            } else {
             const unsigned co = (unsigned)(n0 + wn + 2 * li) * 4u;
             sc = __builtin_bit_cast(f2e, __builtin_amdgcn_raw_buffer_load_b64(scrsrc, co, 0, 0));
             sh = __builtin_bit_cast(f2e, __builtin_amdgcn_raw_buffer_load_b64(shrsrc, co, 0, 0));
+            }
         }
         if (!(ABL & 1) && !LATE) {
             issue_b();                                                   // B(i+1)
@@ -243,6 +270,24 @@ __global__ __launch_bounds__(SH::NT, 4) void pw_stream_bf16(StreamArgs a)
         const float *As = lds + cas * AF, *Bs = Bring + cbs * BF_;
         if (++cas == ASLOTS) cas = 0;
         cbs ^= 1;
+        if constexpr (M16) {
+            // two k-groups of 32: 2 + 4 fragment reads and 8 MFMAs (16 cycles each) per group, the reads of group 1 ahead of the MFMAs of group 0
+            f4 a16[2][MI16], b16[2][NI16];
+#pragma unroll
+            for (int kg = 0; kg < 2; kg++) {
+#pragma unroll
+                for (int i = 0; i < MI16; i++) a16[kg][i] = *reinterpret_cast<const f4 *>(As + fr16_a[kg] + i * 16 * BKF);
+#pragma unroll
+                for (int j = 0; j < NI16; j++) b16[kg][j] = *reinterpret_cast<const f4 *>(Bs + fr16_b[kg] + j * 16 * BKF);
+            }
+#pragma unroll
+            for (int kg = 0; kg < 2; kg++)
+#pragma unroll
+                for (int i = 0; i < MI16; i++)
+#pragma unroll
+                    for (int j = 0; j < NI16; j++)
+                        acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, a16[kg][i]), __builtin_bit_cast(bf8, b16[kg][j]), acc16[i][j], 0, 0, 0);
+        } else {
         f4 fa[2][MI], fb[2][NI];
         if (ABL & 2) {
 #pragma unroll
@@ -283,11 +328,39 @@ __global__ __launch_bounds__(SH::NT, 4) void pw_stream_bf16(StreamArgs a)
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        }
         prev_end = LAST;
         if constexpr (LAST) {
             // channel-paired epilogue of mbn_store_relu6_bf16_pair with the lane's scale/shift in registers; rows past M are
             // dropped by the descriptor's range check (the whole offset goes through the VGPR then)
             const bool inside = (long)m0 + BM <= a.m;
+            if constexpr (M16) {
+                // C/D of the 16 x 16 blocks: lane (c = l & 15, q = l >> 4) holds column c, rows 4 q .. 4 q + 3. With the channel-paired filter rows, blocks j
+                // and j + NI16 / 2 of a 64-column group hold the adjacent channels 2 (16 j' + c) and + 1: packed 4-byte stores, 64 bytes per row and block
+                const int c16 = lane & 15, q16 = lane >> 4;
+#pragma unroll
+                for (int jp = 0; jp < NI16 / 2; jp++) {
+                    const f2e s2 = sc16[jp], h2 = sh16[jp];
+#pragma unroll
+                    for (int i = 0; i < MI16; i++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const unsigned ro = m0 + wm + 16 * i + 4 * q16 + r;
+                            const float v0 = fminf(fmaxf(fmaf(acc16[i][jp][r], s2.x, h2.x), 0.f), 6.f);
+                            const float v1 = fminf(fmaxf(fmaf(acc16[i][jp + NI16 / 2][r], s2.y, h2.y), 0.f), 6.f);
+                            const unsigned v = __builtin_bit_cast(unsigned, bf2e{ (__bf16)v0, (__bf16)v1 });
+                            const unsigned off = (ro * (unsigned)a.n + (unsigned)(n0 + wn + 32 * jp + 2 * c16)) * 2u;
+                            __builtin_amdgcn_raw_buffer_store_b32(v, orsrc, off, 0, 0);
+                        }
+                }
+#pragma unroll
+                for (int i = 0; i < MI16; i++)
+#pragma unroll
+                    for (int j = 0; j < NI16; j++) acc16[i][j] = f4{ 0.f, 0.f, 0.f, 0.f };
+                cvb += gridDim.x;
+                (void)inside;
+                return;
+            }
             const unsigned lane_off = ((unsigned)(4 * lh) * (unsigned)a.n + (unsigned)(2 * li)) * 2u;
 #pragma unroll
             for (int mi = 0; mi < MI; mi++)
@@ -375,6 +448,12 @@ int mbn_launch_bf16_pw_stream(const mbn_call &c, void *out, const void *in, cons
     case 7: hipLaunchKernelGGL((pw_stream_bf16<ShapeStd, 7>), dim3((unsigned)grid), dim3(NT), 0, c.stream, a); return MBN_OK;
     case 5: hipLaunchKernelGGL((pw_stream_bf16<ShapeStd, 5>), dim3((unsigned)grid), dim3(NT), 0, c.stream, a); return MBN_OK;
     default: break;
+    }
+#endif
+#ifdef MBN_LAB
+    if (g_mbn_tune.misc == 16) {                                  // lab: products on the 16 x 16 x 32 MFMA (not bit-identical to the 32 x 32 x 16 kernels)
+        hipLaunchKernelGGL((pw_stream_bf16<ShapeStd, 0, true>), dim3((unsigned)grid), dim3(NT), 0, c.stream, a);
+        return MBN_OK;
     }
 #endif
     hipLaunchKernelGGL((pw_stream_bf16<ShapeStd, 0>), dim3((unsigned)grid), dim3(NT), 0, c.stream, a);
