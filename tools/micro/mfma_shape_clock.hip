@@ -79,8 +79,8 @@ int main()
     const double flops = 512.0 * 8 * iters * (2.0 * 32 * 64 * 64);      // 512 workgroups x 8 waves x iters x (32 x 64 x k64)
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int shape = 0; shape < 2; shape++)
-        for (int rep = 0; rep < 3; rep++) {
+    for (int rep = 0; rep < 6; rep++)
+        for (int shape = 0; shape < 2; shape++) {
             CK(hipEventRecord(e0, st));
             if (shape == 0) hipLaunchKernelGGL(mfma_loop<0>, dim3(512), dim3(512), 0, st, src, sink, iters);
             else hipLaunchKernelGGL(mfma_loop<1>, dim3(512), dim3(512), 0, st, src, sink, iters);
