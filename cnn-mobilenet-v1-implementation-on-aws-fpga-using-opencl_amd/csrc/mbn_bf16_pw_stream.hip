@@ -421,11 +421,13 @@ static bool stream_common_ok(const mbn_call &c, const void *out, const void *in,
 }
 
 // MBN_OK when launched; MBN_EUNSUPPORTED when the shape is outside this kernel's envelope (the caller uses pw_gemm).
-int mbn_launch_bf16_pw_stream(const mbn_call &c, void *out, const void *in, const void *filt, long m, int cin, int op_size)
+// m16: the products on v_mfma_f32_16x16x32_bf16 (taken for K >= 512 at EVERY M, so that a layer's kernel — and with it the bits of an image's result —
+// does not depend on the batch; profiles/r03/x_bf16_mfma_shape.txt)
+int mbn_launch_bf16_pw_stream(const mbn_call &c, void *out, const void *in, const void *filt, long m, int cin, int op_size, bool m16)
 {
     constexpr int BM = ShapeStd::BM, BN = ShapeStd::BN, NT = ShapeStd::NT;
     if (!stream_common_ok(c, out, in, filt, m, cin, op_size)) return MBN_EUNSUPPORTED;
-    if (cin < BKE || (cin % BKE) != 0 || op_size < BN || (op_size % BN) != 0 || m < 4 * BM) return MBN_EUNSUPPORTED;
+    if (cin < BKE || (cin % BKE) != 0 || op_size < BN || (op_size % BN) != 0 || (!m16 && m < 4 * BM) || m < 1) return MBN_EUNSUPPORTED;
     StreamArgs a;
     a.out = (__bf16 *)out; a.in = (const __bf16 *)in; a.filt = (const __bf16 *)filt; a.scale = c.scale; a.shift = c.shift;
     a.m = m; a.k = cin; a.n = op_size; { const int e2 = g_mbn_tune.exp2; a.stag = e2 >= 98 ? 0 : e2; }
@@ -450,12 +452,10 @@ int mbn_launch_bf16_pw_stream(const mbn_call &c, void *out, const void *in, cons
     default: break;
     }
 #endif
-#ifdef MBN_LAB
-    if (g_mbn_tune.misc == 16) {                                  // lab: products on the 16 x 16 x 32 MFMA (not bit-identical to the 32 x 32 x 16 kernels)
+    if (m16 || g_mbn_tune.misc == 16) {                          // (lab: misc = 16 forces this form on every eligible shape)
         hipLaunchKernelGGL((pw_stream_bf16<ShapeStd, 0, true>), dim3((unsigned)grid), dim3(NT), 0, c.stream, a);
         return MBN_OK;
     }
-#endif
     hipLaunchKernelGGL((pw_stream_bf16<ShapeStd, 0>), dim3((unsigned)grid), dim3(NT), 0, c.stream, a);
     return MBN_OK;
 }

@@ -596,6 +596,12 @@ int mbn_launch_f32_pointwise(const mbn_call &c, void *out, const void *in, const
         }
     }
 #endif
+    // K >= 512: the streaming kernel with its products on v_mfma_f32_16x16x32_bf16 — the shape the chip holds a 16 % higher clock under: layers 15 / 25 / 27 at
+    // batch 512 -4.6 % / -3.5 % / -10.7 % against pw_gemm<bf16> (profiles/r03/x_bf16_mfma_shape.txt). It sums 32 products per instruction, so its bits are
+    // not those of the 32x32x16 kernels: it is taken for these layers at EVERY M (the choice depends on K and N alone), which keeps an image's result
+    // independent of the batch. Lab: pw_ring = 1 never.
+    if (bf && ring_mode == 0 && cin >= 512 && g_mbn_tune.pw_tile == 0 && mbn_launch_bf16_pw_stream(c, out, in, filt, m, cin, op_size, true) == MBN_OK)
+        return MBN_OK;
     // measured per layer at batch 512 (profiles/r03/b_bf16_stream_gemm.txt, same call, against pw_gemm<bf16>): K = 64 0.179 -> 0.116 ms,
     // K = 128 0.080 -> 0.076, K = 256 with N = 256 0.114 -> 0.100; K = 256 with N = 512 and every K >= 512 layer 0-5 % SLOWER (there the
     // L2 -> LDS operand stream of a 128 x 128 tile, not the look-ahead, is the limit: ablation in the same file) -> pw_gemm keeps those.

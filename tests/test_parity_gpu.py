@@ -1839,8 +1839,10 @@ def test_bf16_pointwise_wide_kernel(pkg, orc, ctx, shape):
     rows = np.arange(m) if m * cin * cout <= 2e9 else np.unique(np.concatenate([np.arange(0, 420), np.arange(m - 420, m), rng.integers(0, m, 2000)]))
     ref = orc.bf16_round(orc.f32_pointwise(x[rows], f, sc, sh, 2))
     assert_close(got[rows], ref, TOL_BF16, "wide %s vs oracle" % (shape,))
-    ctx.pointwise(d_p.ptr, d_x.ptr, d_f.ptr, m, 1, cin, cout, ext0)          # the same call without the packed image: pw_gemm<bf16> / stream kernel
+    ctx.lib.mbn_tune_set(b"pw_ring", 1)                                      # pw_gemm<bf16>: the same 32x32x16 sums (the default path takes 16x16x32 from K = 512 up)
+    ctx.pointwise(d_p.ptr, d_x.ptr, d_f.ptr, m, 1, cin, cout, ext0)
     ctx.sync()
+    ctx.lib.mbn_tune_set(b"pw_ring", 6)
     other = _bf16_get(pkg, d_p, (m, cout))
     assert np.array_equal(got, other), "wide vs unpacked path %s: max diff %g" % (shape, np.abs(got - other).max())
     ctx.pointwise(d_o.ptr, d_x.ptr, d_f.ptr, m, 1, cin, cout, ext)
@@ -1862,6 +1864,34 @@ def test_bf16_pointwise_wide_kernel(pkg, orc, ctx, shape):
         assert np.array_equal(goti[lo:lo + 4096].astype(np.float64), orc.bf16_round(want.astype(np.float32)).astype(np.float64))
     ctx.lib.mbn_tune_set(b"pw_ring", 0)
     for b in (d_x, d_f, d_fi, d_sc, d_sh, d_o, d_p, one, zero):
+        b.free()
+
+
+@pytest.mark.parametrize("shape", [(49, 1024, 1024), (196, 512, 512), (5, 512, 1024), (3 * 196 + 1, 512, 512), (12544, 1024, 1024)])
+def test_bf16_pointwise_k512_up_is_one_kernel_at_every_m(pkg, orc, ctx, shape):
+    """bf16 pointwise layers with K >= 512 (layers 15 ... 27) run on the streaming kernel's 16x16x32 form at EVERY M — one image or 512 —
+    so that an image's result does not depend on the batch: against the oracle, and the first rows of a call bit for bit equal to a call
+    with those rows alone (M = 1, 49, 196 included: fewer rows than one tile)."""
+    m, cin, cout = shape
+    rng = np.random.default_rng(m + cin + cout)
+    x = orc.bf16_round(rng.uniform(-1, 1, (m, cin)))
+    f = orc.bf16_round(rng.normal(0, (2.0 / cin) ** 0.5, (cout, cin)))
+    sc, sh = rng.uniform(0.5, 1.5, cout).astype(np.float32), rng.normal(0, 0.1, cout).astype(np.float32)
+    d_x, d_f, d_sc, d_sh = _bf16_dev(pkg, ctx, x), _bf16_dev(pkg, ctx, f), ctx.to_device(sc), ctx.to_device(sh)
+    d_o = ctx.alloc(m * cout * 2 + 64)
+    ext = pkg.make_ext(dtype=pkg.DT_BF16, act=2, scale=d_sc.ptr, shift=d_sh.ptr)
+    ctx.lib.mbn_memset(ctx.h, d_o.ptr, 0xFF, m * cout * 2 + 64)
+    ctx.pointwise(d_o.ptr, d_x.ptr, d_f.ptr, m, 1, cin, cout, ext)
+    ctx.sync()
+    raw = d_o.download((m * cout + 32,), np.uint16)
+    assert np.all(raw[m * cout:] == 0xFFFF), "stores past the output"
+    got = _bf16_get(pkg, d_o, (m, cout))
+    assert_close(got, orc.bf16_round(orc.f32_pointwise(x, f, sc, sh, 2)), TOL_BF16, "K >= 512 %s vs oracle" % (shape,))
+    for k in sorted({1, min(m, 49), min(m, 196)}):
+        ctx.pointwise(d_o.ptr, d_x.ptr, d_f.ptr, k, 1, cin, cout, ext)
+        ctx.sync()
+        assert np.array_equal(_bf16_get(pkg, d_o, (k, cout)), got[:k]), "rows depend on M (%d of %d)" % (k, m)
+    for b in (d_x, d_f, d_sc, d_sh, d_o):
         b.free()
 
 
@@ -1945,11 +1975,11 @@ def test_bf16_pointwise_big_tile_kernel(pkg, orc, ctx, shape):
     ctx.pointwise(d_o.ptr, d_x.ptr, d_f.ptr, m, 1, cin, cout, ext)
     ctx.sync()
     assert np.array_equal(got, _bf16_get(pkg, d_o, (m, cout))), "not repeatable"
-    ctx.lib.mbn_tune_set(b"pw_ring", 0)
+    ctx.lib.mbn_tune_set(b"pw_ring", 1)                         # pw_gemm<bf16> (the default path takes the 16x16x32 form from K = 512 up: other bits)
     ctx.pointwise(d_p.ptr, d_x.ptr, d_f.ptr, m, 1, cin, cout, ext)
     ctx.sync()
     other = _bf16_get(pkg, d_p, (m, cout))
-    assert np.array_equal(got, other), "big tile vs default path %s: max diff %g" % (shape, np.abs(got - other).max())
+    assert np.array_equal(got, other), "big tile vs pw_gemm %s: max diff %g" % (shape, np.abs(got - other).max())
     _tune_lab(ctx, b"pw_ring", 7)
     xi = rng.integers(-3, 4, (m, cin)).astype(np.float32)
     fi = rng.integers(-2, 3, (cout, cin)).astype(np.float32)
