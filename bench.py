@@ -434,7 +434,7 @@ def run_one(args, env):
                                                 ("f32_pw_emul%d" % args.pw_emul if args.pw_emul else "f32"))
             if bf16:       # ridge ~312 flop/B: every pointwise layer is HBM-bound in bf16
                 out["roofline"] = {
-                    "kernel": ("pw_gemm<bf16> (%d pointwise 1x1 conv launches per step)" if dom == "pointwise" else
+                    "kernel": ("bf16 pointwise GEMMs: pw_stream_bf16 (K >= 512 on 16x16x32 MFMAs; K <= 256 narrow layers) and pw_gemm<bf16> (%d pointwise 1x1 conv launches per step)" if dom == "pointwise" else
                                "fused depthwise->pointwise blocks (%d launches per step; bytes of their pointwise layers)") % len(pw_idx),
                     "bound": "hbm", "achieved": round(bytes_per_launch / avg_ms / 1e6, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(bytes_per_launch / avg_ms / 1e6 / HBM_PEAK_GBS, 4),
