@@ -375,6 +375,155 @@ __global__ __launch_bounds__(256) void dw3x3_nhwc_bf16x8(DwArgs a)
     }
 }
 
+#ifdef MBN_LAB
+// ---- round 3, LAB ONLY (measured EQUAL to dw3x3_nhwc_bf16x8 on the 14 x 14 layers, -4 % on 28 x 28, +30 % on 7 x 7: profiles/r03/y_bf16_depthwise_lds.txt — the bf16
+// depthwise is bound by its widening / packing VALU work at two waves per SIMD, not by loads in flight): the LDS-staged form in the bf16 mode, stride 1, C % 64 == 0, for the NARROW maps (14 x 14, 28 x 28, 7 x 7: the stand-alone depthwise launches of
+// the bf16 network). dw3x3_nhwc_bf16x8 above is latency-bound there: ~190 VGPRs = 2 waves per SIMD with two input rows (8 KB per wave) in flight, a lane walks
+// its 14 rows one memory round trip after the other (42.8 us for the 103 + 103 MB of a 14 x 14 x 512 layer at batch 512 = 0.60 of 8 TB/s; 33.5 us is the
+// read + write control). Here a workgroup owns G IMAGES side by side (G = 4 for 14-wide maps: image g occupies ring pixels g*SW .. g*SW+SW-1 with its zero
+// halo columns, SW = W + 2 rounded up to even), one 64-channel slab (128 B per pixel) and a row segment; the input rows go through a ring of RING LDS rows
+// (8 KB each: 64 pixels x 64 bf16) filled by buffer_load ... lds LAO rows ahead, so the loads in flight cost no VGPRs and do not depend on the occupancy;
+// the arithmetic is dw3x3_nhwc_bf16x8's (a lane = 2 adjacent pixels x 8 channels marching down the rows, every element widened once, same fma order: same
+// bits), its row loads replaced by four ds_read_b128.
+struct DwLdsBfArgs {
+    __bf16 *out;
+    const __bf16 *in;
+    const float *filt, *scale, *shift;
+    int batch, h, w, ch, pad_top, pad_left, act;
+    int nslab, nseg, seg_rows, G, SW;
+    unsigned tensor_bytes;
+};
+
+template <int LAO>
+__global__ __launch_bounds__(256) void dw3x3_lds_bf16(DwLdsBfArgs a)
+{
+    constexpr int RING = LAO + 3;
+    constexpr int ROWF = 2048;                          // floats per ring row (8 KB): 64 pixels x 32 words (64 bf16)
+    constexpr unsigned OOB = 0xF0000000u;
+    __shared__ __attribute__((aligned(16))) float ring[RING * ROWF];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int b = blockIdx.x;
+    const int seg = b % a.nseg; b /= a.nseg;
+    const int slab = b % a.nslab;
+    const int n0 = (b / a.nslab) * a.G;
+    const int c0 = slab * 64, q = tid & 7, pi = tid >> 3;                  // this lane: channels c0 + 8 q .. + 7 of ring pixels 2 pi, 2 pi + 1
+    const int oy0 = seg * a.seg_rows, oy1 = min(oy0 + a.seg_rows, a.h);
+    const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(a.in), 0, a.tensor_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.tensor_bytes, 0x00020000);
+    const unsigned img_bytes = (unsigned)(a.h * a.w * a.ch * 2), row_bytes = (unsigned)(a.w * a.ch * 2);
+
+    // the two DMA pieces of this wave per input row: ring pixels (2 wave + k) * 8 + lane / 8 (8 lanes x 16 B per pixel)
+    unsigned col_off[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int sp = (wave_u * 2 + k) * 8 + (lane >> 3);
+        const int g = sp / a.SW, ix = sp % a.SW - a.pad_left;
+        const bool ok = g < a.G && n0 + g < a.batch && ix >= 0 && ix < a.w;
+        col_off[k] = ok ? (unsigned)(n0 + g) * img_bytes + (unsigned)((ix * a.ch + c0 + (lane & 7) * 8) * 2) : OOB;
+    }
+    auto issue_row = [&](int iy) __attribute__((always_inline)) {
+        const int slot = (iy + 2 * RING) % RING;                                    // iy >= -1
+        const bool rok = iy >= 0 && iy < a.h;
+        const int soff = rok ? iy * (int)row_bytes : 0;
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(irsrc, (__attribute__((address_space(3))) void *)(ring + slot * ROWF + (wave_u * 2 + k) * 256),
+                                                     16, rok ? col_off[k] : OOB, soff, 0, 0);
+    };
+    f8 w[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) w[k] = ld8f(a.filt + (long)k * a.ch + c0 + q * 8);
+    const f8 one = f8{ 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f }, zero = one - one;
+    const f8 sc = a.scale ? ld8f(a.scale + c0 + q * 8) : one;
+    const f8 sh = a.shift ? ld8f(a.shift + c0 + q * 8) : zero;
+    // outputs of this lane: centre pixels 2 pi + p (p = 0, 1); window columns 2 pi - 1 .. 2 pi + 2 (clamped: the clamped ones feed invalid outputs only)
+    unsigned st_off[2];
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        const int sp = 2 * pi + p, g = sp / a.SW, ox = sp % a.SW - a.pad_left;
+        const bool ok = g < a.G && n0 + g < a.batch && ox >= 0 && ox < a.w;
+        st_off[p] = ok ? (unsigned)(n0 + g) * img_bytes + (unsigned)((ox * a.ch + c0 + q * 8) * 2) : OOB;
+    }
+    int rd[4];                                                                      // word offsets of the four window columns inside a ring row
+#pragma unroll
+    for (int j = 0; j < 4; j++) rd[j] = min(max(2 * pi - 1 + j, 0), 63) * 32 + q * 4;
+    auto read_row = [&](int iy, f8 (&r)[4]) __attribute__((always_inline)) {
+        const float *rp = ring + ((iy + 2 * RING) % RING) * ROWF;
+#pragma unroll
+        for (int j = 0; j < 4; j++) r[j] = widen8(*reinterpret_cast<const u4v *>(rp + rd[j]));
+    };
+    const int iy_first = oy0 - a.pad_top;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                // the tap / scale loads: keep the counted waits exact
+    for (int r = 0; r < 3 + (LAO - 1); r++) issue_row(iy_first + r);
+    f8 r0[4], r1[4], r2[4];
+    for (int oy = oy0; oy < oy1; oy++) {
+        const int iy = oy - a.pad_top;
+        const int t = oy - oy0;
+#define MBN_DWB_WAIT(N) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((N) > 63 ? 63 : (N)) : "memory")
+        if (t >= LAO) MBN_DWB_WAIT(2 + (LAO - 1) * 4);
+        else if (t == 0) MBN_DWB_WAIT((LAO - 1) * 2);
+        else if (t == 1) MBN_DWB_WAIT((LAO - 1) * 2 + 2);
+        else if (t == 2) MBN_DWB_WAIT((LAO - 1) * 2 + 4);
+        else MBN_DWB_WAIT((LAO - 1) * 2 + 6);
+#undef MBN_DWB_WAIT
+        static_assert(LAO <= 4, "the chain above covers t < LAO <= 4");
+        issue_row(iy + 2 + LAO);                                                    // the new row of output row oy + LAO
+        if (t == 0) { read_row(iy, r0); read_row(iy + 1, r1); }
+        read_row(iy + 2, r2);
+        const unsigned orow = (unsigned)oy * row_bytes;
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            f8 acc = zero;                                                         // same tap order as dw3x3_nhwc_bf16x8
+            acc = __builtin_elementwise_fma(r0[p], w[0], acc);
+            acc = __builtin_elementwise_fma(r0[p + 1], w[1], acc);
+            acc = __builtin_elementwise_fma(r0[p + 2], w[2], acc);
+            acc = __builtin_elementwise_fma(r1[p], w[3], acc);
+            acc = __builtin_elementwise_fma(r1[p + 1], w[4], acc);
+            acc = __builtin_elementwise_fma(r1[p + 2], w[5], acc);
+            acc = __builtin_elementwise_fma(r2[p], w[6], acc);
+            acc = __builtin_elementwise_fma(r2[p + 1], w[7], acc);
+            acc = __builtin_elementwise_fma(r2[p + 2], w[8], acc);
+            acc = __builtin_elementwise_fma(acc, sc, sh);
+            const f4 lo = act4(f4{ acc[0], acc[1], acc[2], acc[3] }, a.act), hi = act4(f4{ acc[4], acc[5], acc[6], acc[7] }, a.act);
+            typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
+            const bf8v o = bf8v{ (__bf16)lo.x, (__bf16)lo.y, (__bf16)lo.z, (__bf16)lo.w, (__bf16)hi.x, (__bf16)hi.y, (__bf16)hi.z, (__bf16)hi.w };   // RNE
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, o), orsrc, st_off[p] == OOB ? OOB : st_off[p] + orow, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) { r0[j] = r1[j]; r1[j] = r2[j]; }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
+static int launch_dw_lds_bf16(const mbn_call &c, const DwArgs &a, int channels, int nseg_force)
+{
+    DwLdsBfArgs l;
+    l.out = (__bf16 *)a.out; l.in = (const __bf16 *)a.in; l.filt = a.filt; l.scale = a.scale; l.shift = a.shift;
+    l.batch = a.batch; l.h = a.rows; l.w = a.cols; l.ch = a.ch; l.pad_top = a.pad_top; l.pad_left = a.pad_left; l.act = a.act;
+    l.SW = (a.cols + 2 + 1) & ~1;
+    if (l.SW > 64 || a.pad_left < 0 || a.pad_left > 1 || a.pad_top < 0 || a.pad_top > 1) return MBN_EUNSUPPORTED;
+    l.G = 64 / l.SW;
+    l.nslab = channels / 64;
+    const double bytes = (double)a.batch * a.rows * a.cols * channels * 2;
+    if (bytes >= 3.5e9) return MBN_EUNSUPPORTED;
+    l.tensor_bytes = (unsigned)bytes;
+    const long groups = (a.batch + l.G - 1) / l.G, base = groups * l.nslab;
+    const long slots = 2L * c.ctx->num_cus;                          // ~200 VGPRs: two workgroups per CU (56 KB of LDS each: 7 ring rows, 4 rows ahead)
+    int ns = 1;
+    if (nseg_force > 0) ns = nseg_force;
+    else if (base * 10 < slots * 6) {                                 // under-filled: whole rounds with the fewest segments
+        ns = (int)((slots + base - 1) / base);
+        if (ns > a.rows / 2) ns = a.rows / 2 > 0 ? a.rows / 2 : 1;
+    }
+    l.seg_rows = (a.rows + ns - 1) / ns;
+    l.nseg = (a.rows + l.seg_rows - 1) / l.seg_rows;
+    if ((double)base * l.nseg >= 2147483647.0) return MBN_EUNSUPPORTED;
+    hipLaunchKernelGGL(dw3x3_lds_bf16<4>, dim3((unsigned)(base * l.nseg)), dim3(256), 0, c.stream, l);
+    return MBN_OK;
+}
+#endif
+
 // Generic fallback (any stride / filtersize / channel count): one lane per output element.
 template <typename T>
 __global__ __launch_bounds__(256) void dw_generic_nhwc(DwArgs a, int fs, int stride)
@@ -625,6 +774,14 @@ int launch_dw(const mbn_call &c, DwArgs &a, int rows, int cols, int fs, int stri
         a.nseg = (rows + a.seg_rows - 1) / a.seg_rows;
         a.total = row_lanes * a.nseg;
         dim3 grid((unsigned)((a.total + 255) / 256));
+#ifdef MBN_LAB
+        // LAB: the LDS-staged bf16 form (exp0 = 8): stride 1, C % 64 == 0, maps up to 62 pixels wide (same bits as the kernel below)
+        if (stride == 1 && (channels % 64) == 0 && a.in_rows == rows && a.in_cols == cols && g_mbn_tune.exp0 == 8) {
+            const int forced_seg = g_mbn_tune.dw_nseg;
+            const int rc = launch_dw_lds_bf16(c, a, channels, forced_seg);
+            if (rc != MBN_EUNSUPPORTED) return rc;
+        }
+#endif
 #ifdef MBN_LAB
         if (tw8 == 1) {
             if (stride == 1) hipLaunchKernelGGL((dw3x3_nhwc_bf16x8<1, 1>), grid, dim3(256), 0, c.stream, a);

@@ -618,6 +618,43 @@ def test_bf16_depthwise(pkg, orc, ctx, shape):
     assert_close(_bf16_get(pkg, d_o, want.shape), want, TOL_BF16, "bf16 dw %s" % (shape,))
 
 
+@pytest.mark.parametrize("shape", [(9, 14, 512), (4, 14, 64), (5, 28, 256), (13, 7, 1024), (2, 56, 128), (3, 9, 64), (1, 62, 64), (7, 3, 128)])
+def test_bf16_depthwise_lds_staged_form(pkg, orc, ctx, shape):
+    """LAB (exp0=8 forces it): dw3x3_lds_bf16 — G images side by side in 64-pixel LDS ring rows filled by LDS-DMA, dw3x3_nhwc_bf16x8's arithmetic from
+    ds_read_b128: against the oracle and bit for bit against the register kernel (exp0=1); images per workgroup 1 ... 6, batches that do not
+    fill the last group, odd widths (even-rounded pixel slots), row segments, no store outside the output."""
+    _tune_lab(ctx, b"exp0", 8)
+    n, h, ch = shape
+    rng = np.random.default_rng(n + h + ch)
+    x = orc.bf16_round(rng.uniform(-1, 1, (n, h, h, ch)))
+    f = rng.normal(0, 0.5, (3, 3, ch)).astype(np.float32)
+    sc, sh = rng.uniform(0.5, 1.5, ch).astype(np.float32), rng.normal(0, 0.1, ch).astype(np.float32)
+    want = orc.bf16_round(orc.f32_depthwise(x, f, sc, sh, 1, 2))
+    d_x, d_f, d_sc, d_sh = _bf16_dev(pkg, ctx, x), ctx.to_device(f), ctx.to_device(sc), ctx.to_device(sh)
+    d_o, d_p = ctx.alloc(want.size * 2 + 64), ctx.alloc(want.size * 2)
+    ext = pkg.make_ext(batch=n, dtype=pkg.DT_BF16, act=2, in_rows=h, in_cols=h, scale=d_sc.ptr, shift=d_sh.ptr)
+    try:
+        for nseg in (0, 1, 2, 3):
+            ctx.lib.mbn_tune_set(b"dw_nseg", nseg)
+            ctx.lib.mbn_memset(ctx.h, d_o.ptr, 0xFF, want.size * 2 + 64)
+            ctx.depthwise(d_o.ptr, d_x.ptr, d_f.ptr, h, h, 3, 1, ch, ext)
+            ctx.sync()
+            raw = d_o.download((want.size + 32,), np.uint16)
+            assert np.all(raw[want.size:] == 0xFFFF), "stores past the output"
+            got = _bf16_get(pkg, d_o, want.shape)
+            assert_close(got, want, TOL_BF16, "bf16 dw lds %s nseg %d" % (shape, nseg))
+        ctx.lib.mbn_tune_set(b"dw_nseg", 0)
+        ctx.lib.mbn_tune_set(b"exp0", 1)
+        ctx.depthwise(d_p.ptr, d_x.ptr, d_f.ptr, h, h, 3, 1, ch, ext)
+        ctx.sync()
+        assert np.array_equal(got, _bf16_get(pkg, d_p, want.shape)), "LDS-staged bf16 form differs from the register kernel"
+    finally:
+        ctx.lib.mbn_tune_set(b"dw_nseg", 0)
+        ctx.lib.mbn_tune_set(b"exp0", 0)
+        for b in (d_x, d_f, d_sc, d_sh, d_o, d_p):
+            b.free()
+
+
 @pytest.mark.parametrize("shape", [(2 * 56 * 56, 64, 128), (2 * 14 * 14, 512, 512), (3 * 49, 1024, 1024), (12544, 32, 64),
                                    (130, 8, 24), (77, 72, 40), (5, 1024, 1000), (64, 6, 10)])
 def test_bf16_pointwise(pkg, orc, ctx, shape):
