@@ -87,7 +87,8 @@ __device__ __forceinline__ void lds_dma_rows(const void *gbase, unsigned gbytes,
                                                  16, voff[p], soff, 0, 0);
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int NBUF, bool KFULL, bool GLDS>
+// ABL (lab, timing only — results are wrong with any bit set): 1 = no LDS-DMA inside the k-loop, 2 = no barriers inside the k-loop, 4 = no epilogue stores
+template <typename T, int BM, int BN, int WM, int WN, int NBUF, bool KFULL, bool GLDS, int ABL = 0>
 __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void pw_gemm(PwArgs a)
 {
     constexpr bool BF = sizeof(T) == 2;
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void pw_gemm(PwArgs a)
             // between the two halves in the kernel body itself: a lambda may not call __syncthreads in the host pass.)
             auto ktile_head = [&](const int CUR, const bool NEXT, int kt) __attribute__((always_inline)) {
                 const float *base = lds + CUR * (BM + BN) * BKF;
-                if (NEXT) stage_glds2((kt + 1) * BKE, CUR ^ 1);
+                if (NEXT && !(ABL & 1)) stage_glds2((kt + 1) * BKE, CUR ^ 1);
 #pragma unroll
                 for (int g = 0; g < 3; g++) {
                     ldfrag(base, g + 1, (g + 1) & 1);
@@ -353,17 +354,17 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void pw_gemm(PwArgs a)
             int kt = 0;
             for (; kt + 2 < nk; kt += 2) {
                 ktile_head(0, true, kt);
-                __syncthreads();
+                if (!(ABL & 2)) __syncthreads();
                 ktile_tail(0, true);
                 ktile_head(1, true, kt + 1);
-                __syncthreads();
+                if (!(ABL & 2)) __syncthreads();
                 ktile_tail(1, true);
             }
             ktile_head(0, true, kt);
-            __syncthreads();
+            if (!(ABL & 2)) __syncthreads();
             ktile_tail(0, true);
             ktile_head(1, false, kt + 1);
-            __syncthreads();
+            if (!(ABL & 2)) __syncthreads();
             ktile_tail(1, false);
         } else if (GLDS) {
             for (int kt = 0; kt < nk; kt++) {
@@ -418,7 +419,9 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void pw_gemm(PwArgs a)
                 if (ss_lds) mbn_store_relu6_bf16_pair<MI, NI, 0>(orsrc, (unsigned)a.n, (unsigned)cm0 + wm_u, cn0 + wn_u, lane, acc, sc_s, sh_s);
                 else mbn_store_relu6_bf16_pair<MI, NI, 0>(orsrc, (unsigned)a.n, (unsigned)cm0 + wm_u, cn0 + wn_u, lane, acc, a.scale, a.shift);
             } else {
-                if (ss_lds) mbn_store_relu6_f32<MI, NI, 0, T>(orsrc, (unsigned)a.n, (unsigned)cm0 + wm_u, cn0 + wn_u, lane, acc, sc_s, sh_s, (unsigned)a.m, a.n);
+                if (ABL & 4) { float t_ = 0.f; for (int mi = 0; mi < MI; mi++) for (int ni = 0; ni < NI; ni++) for (int r = 0; r < 16; r++) t_ += acc[mi][ni][r];
+                               if (t_ == 123.456f) reinterpret_cast<float *>(a.out)[lane] = t_; }
+                else if (ss_lds) mbn_store_relu6_f32<MI, NI, 0, T>(orsrc, (unsigned)a.n, (unsigned)cm0 + wm_u, cn0 + wn_u, lane, acc, sc_s, sh_s, (unsigned)a.m, a.n);
                 else mbn_store_relu6_f32<MI, NI, 0, T>(orsrc, (unsigned)a.n, (unsigned)cm0 + wm_u, cn0 + wn_u, lane, acc, a.scale,
                                                        a.shift, (unsigned)a.m, a.n);
             }
@@ -532,6 +535,18 @@ void launch_cfg(PwArgs &a, hipStream_t s, int num_cus)
         if (kfull) hipLaunchKernelGGL((pw_gemm<T, BM, BN, WM, WN, 1, true, false>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((pw_gemm<T, BM, BN, WM, WN, 1, false, false>), grid, block, 0, s, a);
     } else {
+#ifdef MBN_LAB
+        if (glds && sizeof(T) == 4 && g_mbn_tune.exp1 > 0 && ((BM == 64 && BN == 64) || (BM == 128 && BN == 64 && WM == 32) || (BM == 128 && BN == 128 && WM == 32))) {
+            switch (g_mbn_tune.exp1) {                                 // ablations of the fp32 GEMM (timing only)
+            case 1: hipLaunchKernelGGL((pw_gemm<T, BM, BN, WM, WN, 2, true, true, 1>), grid, block, 0, s, a); return;
+            case 2: hipLaunchKernelGGL((pw_gemm<T, BM, BN, WM, WN, 2, true, true, 2>), grid, block, 0, s, a); return;
+            case 3: hipLaunchKernelGGL((pw_gemm<T, BM, BN, WM, WN, 2, true, true, 3>), grid, block, 0, s, a); return;
+            case 4: hipLaunchKernelGGL((pw_gemm<T, BM, BN, WM, WN, 2, true, true, 4>), grid, block, 0, s, a); return;
+            case 7: hipLaunchKernelGGL((pw_gemm<T, BM, BN, WM, WN, 2, true, true, 7>), grid, block, 0, s, a); return;
+            default: break;
+            }
+        }
+#endif
         if (glds) hipLaunchKernelGGL((pw_gemm<T, BM, BN, WM, WN, 2, true, true>), grid, block, 0, s, a);
 #ifdef MBN_LAB
         else if (kfull) hipLaunchKernelGGL((pw_gemm<T, BM, BN, WM, WN, 2, true, false>), grid, block, 0, s, a);      // pw_stage = 1 only
