@@ -2,6 +2,7 @@
 """bench.py — images/sec of the MobileNet-V1 hot path on MI355X (BASELINE.json metric).
 
   python bench.py --gpus 1 --steps K --warmup W            one GPU
+  python bench.py --gpus N --steps K --warmup W            N > 1 without a launcher: starts the line below as a child process
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W            one rank per GPU (RCCL)
 
@@ -176,15 +177,42 @@ def parse_args(argv=None):
     return args
 
 
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no rank environment: start the N ranks ourselves, exactly as the driver's own
+    command line would (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`), as a CHILD
+    process — never os.exec*, and before this process has touched HIP or torch.cuda (torch.cuda.device_count() does not
+    initialise the GPU on this image). Rank 0's JSON line goes to our stdout through the inherited descriptor; the child's
+    return code is ours. A rank count above the visible devices is refused here with a plain message instead of N ranks
+    failing in hipSetDevice (the reference has one device, MobileNet.c:155)."""
+    import socket
+    import subprocess
+    if args.device_override < 0:
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.stderr.write("bench.py: --gpus %d but this node shows %d GPU(s) (MBN_ENODEVICE); for a rehearsal on one card use "
+                             "--dist-backend gloo --device-override 0\n" % (args.gpus, have))
+            return 19       # ENODEV
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    sys.stdout.flush()
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args, sys.argv[1:]))
     from mbn_amd import import_package
     pkg = import_package()
     from mbn_amd_pkg import dist as mdist      # the protocol rehearsed on gloo in tests/test_dist_cpu.py
     rank, local_rank, world = mdist.env_rank_world()
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
         args.gpus = world
 
     import torch   # device plumbing only: RCCL broadcast, barrier, device-wide synchronize
@@ -198,6 +226,8 @@ def main():
         sys.exit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
     if args.device_override >= 0:
         local_rank = args.device_override
+    if local_rank >= torch.cuda.device_count():
+        sys.exit("bench.py: rank %d wants GPU %d but this node shows %d (MBN_ENODEVICE)" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     mdist.init(args.dist_backend, dev)         # nccl == RCCL on ROCm; no-op for one process

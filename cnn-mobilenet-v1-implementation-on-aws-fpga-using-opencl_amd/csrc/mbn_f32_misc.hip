@@ -294,8 +294,11 @@ __global__ __launch_bounds__(256) void poolfc_f32(PoolFcArgs a)
             if (q == 0 && ok && b < a.batch) __hip_atomic_store(a.ws + ((long)ks * 4 + b) * a.classes + n, p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    // hand-over: the write-through stores of every wave have been acknowledged (vmcnt(0) at the barrier) before the arrival is counted;
-    // the counter and the reads of the last workgroup are agent-scope accesses too, so no cache is written back or invalidated
+    // hand-over: every wave waits for the acknowledgement of its own write-through stores (explicit s_waitcnt vmcnt(0): the workgroup-scope
+    // fence + barrier lower to `s_waitcnt lgkmcnt(0); s_barrier` only, which would let the arrival be counted with partials still in flight —
+    // ADVICE r3) before the barrier that precedes the counter atomic; the counter and the reads of the last workgroup are agent-scope
+    // accesses too, so no cache is written back or invalidated
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (tid == 0) s_last = __hip_atomic_fetch_add(a.cnt + ns, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -87,7 +87,8 @@ __device__ __forceinline__ void lds_dma_rows(const void *gbase, unsigned gbytes,
                                                  16, voff[p], soff, 0, 0);
 }
 
-// ABL (lab, timing only — results are wrong with any bit set): 1 = no LDS-DMA inside the k-loop, 2 = no barriers inside the k-loop, 4 = no epilogue stores
+// ABL (lab, timing only — results are wrong with any bit set): 1 = no LDS-DMA inside the k-loop, 2 = no barriers inside the k-loop, 4 = no epilogue stores,
+// 8 = no LDS fragment reads inside the k-loop
 template <typename T, int BM, int BN, int WM, int WN, int NBUF, bool KFULL, bool GLDS, int ABL = 0>
 __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void pw_gemm(PwArgs a)
 {
@@ -304,12 +305,16 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void pw_gemm(PwArgs a)
             // turns every fragment address into per-lane base + immediate: no VALU in the loop (VALU time does not
             // overlap fp32 MFMA time on a SIMD, tools/micro/).
             f4 fa[2][MI], fb[2][NI];
-            auto ldfrag = [&](const float *base, int g, int slot) __attribute__((always_inline)) {
+            auto ldfrag_do = [&](const float *base, int g, int slot) __attribute__((always_inline)) {
 #pragma unroll
                 for (int mi = 0; mi < MI; mi++) fa[slot][mi] = *reinterpret_cast<const f4 *>(base + fr_a[g] + mi * 32 * BKF);
 #pragma unroll
                 for (int ni = 0; ni < NI; ni++) fb[slot][ni] = *reinterpret_cast<const f4 *>(base + BM * BKF + fr_b[g] + ni * 32 * BKF);
             };
+            auto ldfrag = [&](const float *base, int g, int slot) __attribute__((always_inline)) {
+                if (!(ABL & 8)) ldfrag_do(base, g, slot);          // ABL & 8: the fragment registers keep what they were given once, below
+            };
+            if (ABL & 8) { ldfrag_do(lds, 0, 0); ldfrag_do(lds, 1, 1); }
             auto mfma_group = [&](int slot) __attribute__((always_inline)) {
                 if constexpr (BF) {
 #pragma unroll
@@ -536,13 +541,11 @@ void launch_cfg(PwArgs &a, hipStream_t s, int num_cus)
         else hipLaunchKernelGGL((pw_gemm<T, BM, BN, WM, WN, 1, false, false>), grid, block, 0, s, a);
     } else {
 #ifdef MBN_LAB
-        if (glds && sizeof(T) == 4 && g_mbn_tune.exp1 > 0 && ((BM == 64 && BN == 64) || (BM == 128 && BN == 64 && WM == 32) || (BM == 128 && BN == 128 && WM == 32))) {
-            switch (g_mbn_tune.exp1) {                                 // ablations of the fp32 GEMM (timing only)
-            case 1: hipLaunchKernelGGL((pw_gemm<T, BM, BN, WM, WN, 2, true, true, 1>), grid, block, 0, s, a); return;
-            case 2: hipLaunchKernelGGL((pw_gemm<T, BM, BN, WM, WN, 2, true, true, 2>), grid, block, 0, s, a); return;
-            case 3: hipLaunchKernelGGL((pw_gemm<T, BM, BN, WM, WN, 2, true, true, 3>), grid, block, 0, s, a); return;
-            case 4: hipLaunchKernelGGL((pw_gemm<T, BM, BN, WM, WN, 2, true, true, 4>), grid, block, 0, s, a); return;
-            case 7: hipLaunchKernelGGL((pw_gemm<T, BM, BN, WM, WN, 2, true, true, 7>), grid, block, 0, s, a); return;
+        if (glds && sizeof(T) == 4 && g_mbn_tune.exp1 > 0 && ((BM == 64 && BN == 64) || (BM == 128 && BN == 128))) {
+            switch (g_mbn_tune.exp1) {                                 // ablations of the fp32 GEMM (timing only): bits of ABL
+#define MBN_ABL_CASE(v) case v: hipLaunchKernelGGL((pw_gemm<T, BM, BN, WM, WN, 2, true, true, v>), grid, block, 0, s, a); return;
+            MBN_ABL_CASE(1) MBN_ABL_CASE(2) MBN_ABL_CASE(3) MBN_ABL_CASE(4) MBN_ABL_CASE(7) MBN_ABL_CASE(8) MBN_ABL_CASE(9) MBN_ABL_CASE(10) MBN_ABL_CASE(12) MBN_ABL_CASE(15)
+#undef MBN_ABL_CASE
             default: break;
             }
         }

@@ -255,7 +255,11 @@ static int run_multi(int gpus, int batch, int res, int steps, int warmup, const 
     mbn_dist *dist = NULL;
     int bad = 1;
     int rc = mbn_dist_init(gpus, NULL, &dist);
-    if (rc != MBN_OK) { fprintf(stderr, "Error: mbn_dist_init(%d) -> %s\n", gpus, mbn_strerror(rc)); return 1; }
+    if (rc != MBN_OK) {
+        fprintf(stderr, "Error: mbn_dist_init(%d) -> %s%s\n", gpus, mbn_strerror(rc),
+                rc == MBN_ENODEVICE ? " (MBN_ENODEVICE: --gpus asks for more GPUs than this node shows)" : "");
+        return 1;
+    }
     const size_t blob_bytes = (size_t)w->plan.blob_floats * sizeof(float);
     void **blobs = calloc((size_t)gpus, sizeof(void *));
     gpu_job *jobs = calloc((size_t)gpus, sizeof(gpu_job));
@@ -292,19 +296,22 @@ static int run_multi(int gpus, int batch, int res, int steps, int warmup, const 
     if (verify) {
         /* every shard again on GPU 0 — same images (global index), same call size, GPU 0's own copy of the blob — compared bit for
          * bit with what the shard's GPU produced: a wrong broadcast, a wrong shard offset or a GPU that computes differently shows */
+        int differ = 0;
+        bad = 1;                                                /* until every shard has compared identical (a failed TRY below left 0) */
         TRY(mbn_dist_context(dist, 0, &ctx));
         for (int r = 0; r < gpus; r++) {
             if (jobs[r].count <= 0) continue;
             const size_t nb = (size_t)jobs[r].count * w->plan.classes * sizeof(float);
             float *again = malloc(nb);
-            if (!again) { bad = 1; goto done; }
+            if (!again) goto done;
             rc = shard_forward(ctx, &w->plan, blobs[0], res, jobs[r].first, jobs[r].count, 0, 1, again, NULL, NULL, NULL);
             const int same = rc == MBN_OK && memcmp(again, jobs[r].logits, nb) == 0;
             printf("verify: shard %d (GPU %d) vs the same images on GPU 0: %s (fnv1a %016llx)\n", r, r,
                    rc != MBN_OK ? mbn_strerror(rc) : same ? "identical" : "DIFFERENT", rc == MBN_OK ? fnv1a(again, nb) : 0ULL);
             free(again);
-            if (!same) bad = 1;
+            if (!same) differ = 1;
         }
+        bad = differ;
     }
 #undef TRY
 done:

@@ -107,3 +107,16 @@ def test_rank_thread_skeleton_with_fake_jobs():
     assert lib.mbn_run_ranks(3, pkg.RANK_FN(failing), None, -1, rcs) != 0
     assert rcs[1] == pkg.EIO and rcs[0] == pkg.EDEVICE and rcs[2] == pkg.EDEVICE and time.time() - t0 < 5.0
     assert lib.mbn_run_ranks(0, fn, None, -1, None) == pkg.EINVAL
+
+
+def test_bench_refuses_more_ranks_than_gpus_before_touching_a_device():
+    """`python bench.py --gpus N` (no launcher in front) starts its own ranks as a child process; with fewer than N visible GPUs
+    and no rehearsal override it must say so and leave with ENODEV instead of spawning ranks that die in hipSetDevice. Here
+    (no GPU at all) that is the whole observable behaviour; the launch itself is a GPU test."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer than 2 GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 19 and "MBN_ENODEVICE" in r.stderr and r.stdout.strip() == ""

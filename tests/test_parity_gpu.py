@@ -1767,7 +1767,7 @@ def test_dist_single_gpu_path_and_c_host_gpus_mode(pkg, ctx, tmp_path):
     # asking the host for more GPUs than the box has fails cleanly
     out = subprocess.run([exe, "--gpus", str(have.value + 1), "--batch", "8", "--synthetic", "3", "--alpha", "0.25", "--res", "64"],
                          capture_output=True, text=True, timeout=300)
-    assert out.returncode != 0 and "mbn_dist_init" in out.stderr
+    assert out.returncode != 0 and "mbn_dist_init" in out.stderr and "no HIP device" in out.stderr      # MBN_ENODEVICE, not a hang
 
 
 def _lab(ctx):
@@ -2295,6 +2295,30 @@ def test_bench_multi_rank_branch_on_one_gpu(pkg):
     assert out["parity_check"]["ok"] and out["parity_check"]["images"] == 8
     assert "cpu_baseline" not in out and "configs_alt" not in out
     assert out["profiled_steps"] == 5 and out["event_overhead_us"]["empty_pair"] >= 0
+
+
+def test_bench_self_launches_its_ranks(pkg):
+    """`python bench.py --gpus 2` started the way the driver starts `--gpus 1` — no torch.distributed.run in
+    front — must start its own ranks as a child process (before touching the GPU) and print rank 0's line, instead of exiting.
+    Rehearsed with both ranks on this box's one card over gloo; without --device-override the same command is refused with the
+    MBN_ENODEVICE text because the box has fewer than 2 GPUs (the reference has one device, MobileNet.c:155)."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(pkg.REPO_ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--device-override", "0",
+           "--steps", "5", "--warmup", "1", "--batch", "16", "--alpha", "0.5", "--res", "96"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                              # ONE line, rank 0's
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 32 and out["value"] > 0 and out["parity_check"]["ok"]
+    import torch
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run([sys.executable, os.path.join(pkg.REPO_ROOT, "bench.py"), "--gpus", "2", "--steps", "2"], env=env,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 19 and "MBN_ENODEVICE" in r.stderr and not r.stdout.strip()
 
 
 def test_graft_entry_smoke_runs():
