@@ -239,6 +239,12 @@ def main():
                     and not args.pw_emul and not args.graph and not args.tune)
         if headline and not args.no_configs_alt:
             out["configs_alt"] = configs_alt(args, env)
+            if "roofline" in out:
+                out["roofline"]["configs_alt"] = {
+                    name: {"value": round(c["value"], 1), "ms_per_step": round(c["ms_per_step"], 4), "bound": (c.get("roofline") or {}).get("bound"),
+                           "frac": (c.get("roofline") or {}).get("frac"), "parity_ok": (c.get("parity_check") or {}).get("ok"),
+                           "parity_max_rel_err": (c.get("parity_check") or {}).get("max_rel_err")}
+                    for name, c in out["configs_alt"].items()}
         print(json.dumps(out))
         sys.stdout.flush()
         if "parity_check" in out and not out["parity_check"]["ok"]:
@@ -396,6 +402,17 @@ def run_one(args, env):
     if not np.isfinite(logits).all():
         sys.exit("non-finite logits")
 
+    # ---- the same K steps once more WITHOUT the per-kernel events (and without the single-stream steps they need): never `value`, reported
+    # beside it so that what the instrumentation costs the headline is visible in the record
+    value_no_profile = None
+    if profile and world == 1:
+        torch.cuda.synchronize()
+        n0 = time.perf_counter()
+        for _ in range(args.steps):
+            net.forward(d_in.ptr, d_out.ptr, args.batch)
+        torch.cuda.synchronize()
+        value_no_profile = args.batch * args.steps / (time.perf_counter() - n0)
+
     # ---- the opt-in split form of the pointwise GEMM beside the default line (N = 1, fp32): same net, same buffers, same
     # stream configuration, 3 warm-up + 10 timed steps without per-kernel events. Never part of `value`.
     alt = None
@@ -481,6 +498,14 @@ def run_one(args, env):
                     "algorithmic_flops_per_launch": flops_per_launch,
                     "algorithmic_bytes_per_launch": bytes_per_launch,
                 }
+            # the driver's record keeps `roofline` and `cpu_baseline` of this line: the per-stage fractions go inside `roofline` as well
+            out["roofline"]["stages_frac"] = {k: {"ms": v["ms"], "launches": v["launches"], "frac_hbm": v["frac_hbm"], "frac_mfma": v["frac_mfma"]}
+                                              for k, v in stages.items()}
+            if value_no_profile is not None:
+                out["roofline"]["value_no_profile"] = round(value_no_profile, 1)
+                out["value_no_profile"] = {"value": round(value_no_profile, 1), "unit": "images/sec", "steps": args.steps,
+                                           "how": "the same K steps again after the timed region with no per-kernel events and every step on "
+                                                  "the default stream configuration; `value` above includes %d profiled single-stream steps" % len(sampled)}
             out["stages"] = stages
             out["layers"] = per_layer
             out["sum_kernel_ms"] = round(float(layer_ms.sum()), 4)
@@ -516,6 +541,11 @@ def run_one(args, env):
             out["unfused_stages"] = {"note": "untimed: %d forwards with one launch per layer (mbn_net_set_fuse_stem(0), "
                                              "mbn_net_set_fuse_blocks(0)); same batch, same buffers" % reps,
                                      "stages": ust, "layers": ulayers, "sum_kernel_ms": round(float(ums.sum()), 4)}
+            if "roofline" in out:
+                for k in ("depthwise", "pointwise"):
+                    if k in ust:
+                        out["roofline"]["stages_frac"]["unfused_%s_x%d" % (k, ust[k]["launches"])] = {
+                            "ms": ust[k]["ms"], "launches": ust[k]["launches"], "frac_hbm": ust[k]["frac_hbm"], "frac_mfma": ust[k]["frac_mfma"]}
             net.set_fuse_stem(not args.no_fuse_stem)
             net.set_fuse_tail(args.fuse_tail)
             if args.fuse_blocks is not None:

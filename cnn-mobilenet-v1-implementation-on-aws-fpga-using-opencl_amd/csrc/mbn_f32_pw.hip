@@ -409,6 +409,9 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void pw_gemm(PwArgs a)
             if (GLDS) { if (a.loop2) stage_glds2(0, 0); else stage_glds(0, 0); }      // both buffers are free after the K loop's last barrier
             else stage_load(0);
         }
+        // the counted wait at the top of the next tile (vmcnt(NSTF)) is right only if this DMA is OLDER than every epilogue store in the ISA:
+        // pin the order (tests/test_host_cpu.py checks the instruction stream of the built kernel)
+        __builtin_amdgcn_sched_barrier(0);
 
         // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
         // fp32: one store instruction writes two 128-B row segments (full cache lines). bf16 with an even number of column
@@ -477,6 +480,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void pw_gemm(PwArgs a)
                 }
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
         if (!more) break;
         vb = nvb;
     }
