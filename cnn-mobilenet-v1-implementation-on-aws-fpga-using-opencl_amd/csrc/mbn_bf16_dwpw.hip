@@ -269,7 +269,7 @@ int mbn_bf16_dwpw_check(const void *out, const void *in, const float *wd, const 
         return MBN_EUNSUPPORTED;
     if (2.0 * batch * in_rows * in_cols * cin >= (double)OOB) return MBN_EUNSUPPORTED;
     if ((long)batch * out_rows * out_cols > 0x7fffff00L) return MBN_EUNSUPPORTED;
-    if (2.0 * batch * out_rows * out_cols * cout >= 4294967296.0) return MBN_EUNSUPPORTED;
+    if (2.0 * ((double)batch * out_rows * out_cols + 256.0) * cout >= 4294967296.0) return MBN_EUNSUPPORTED;   // + a row tile of head room: ragged rows must not wrap (32-bit offsets)
     for (const void *p : ptrs)
         if (((uintptr_t)p % 16) != 0) return MBN_EUNSUPPORTED;
     return MBN_OK;

@@ -91,7 +91,13 @@ __device__ __forceinline__ void dma_filter(__amdgpu_buffer_rsrc_t rsrc, float *l
 }
 
 // DBG = false: the shipped kernel, the experiment switches (a.dbg) fold away; DBG = true only for tune dwpw_variant >= 100
-template <int S, int BN, bool DBG>
+// M16 = true (LAB, round 4, tune misc = 32): the pointwise products on v_mfma_f32_16x16x32_bf16 — the same LDS image and the same bytes read per chunk
+// (a lane's 16-byte fragment is k = 32 kg + 8 q .. + 7 of row r: chunk 4 kg + q of the 128-byte row), two k-groups of 32 per 64-channel chunk; the
+// shape the chip holds a higher clock under in MFMA-dense loops (profiles/r03/x_bf16_mfma_shape.txt). Measured here (profiles/r04/c_bf16_mfma_shape_blocks.txt,
+// bf16 1.0x224 batch 512, alternating runs): blocks 4-11 0.746-0.754 ms against 0.739-0.749 with 32x32x16 — equal within the run-to-run spread, 0.8 % worse
+// on the means: a block's matrix work is a sixteenth of the fp32 kernel's, too thin to pull the clock down, and the 16 x 16 form holds 24-32 more
+// fragment registers. Parity-tested (oracle + exact integers, tests/test_parity_gpu.py::test_bf16_dwpw_fused under MBN_LAB=1), not shipped.
+template <int S, int BN, bool DBG, bool M16>
 __global__ __launch_bounds__(NT) void dwpw2_bf16(DwPw2Args a)
 {
     const int dbg = DBG ? a.dbg : 0;
@@ -206,29 +212,63 @@ __global__ __launch_bounds__(NT) void dwpw2_bf16(DwPw2Args a)
         *reinterpret_cast<bf8 *>(a_s0 + buf * ABUF + aw1) = o1;
     };
 
-    f16v acc[MI][NI];
-    f4 fa[2][MI], fb[2][NI];
+    constexpr int MI16 = WM / 16, NI16 = WN / 16;
+    // 64 x 64 wave tiles in the 16x16x32 form hold 32 fragment registers per k-group: read behind the depthwise part, not ahead of it (no spills)
+    constexpr bool LATEFRAG = M16 && BN == 256;
+    [[maybe_unused]] f16v acc[M16 ? 1 : MI][M16 ? 1 : NI];
+    [[maybe_unused]] f4 acc16[M16 ? MI16 : 1][M16 ? NI16 : 1];
+    // fragment slots: 32x32x16 — four k-groups of 16, group g in slot g & 1; 16x16x32 — two k-groups of 32, group kg in slot kg
+    f4 fa[2][M16 ? MI16 : MI], fb[2][M16 ? NI16 : NI];
+    [[maybe_unused]] int fr16_a[2], fr16_b[2];
+#pragma unroll
+    for (int kg = 0; kg < 2; kg++) {
+        fr16_a[kg] = swz(wm + (lane & 15), 4 * kg + (lane >> 4));
+        fr16_b[kg] = swz(wn + (lane & 15), 4 * kg + (lane >> 4));
+    }
     auto ldfrag = [&](const int buf, int g, int slot) __attribute__((always_inline)) {
+        if constexpr (M16) {
+#pragma unroll
+            for (int i = 0; i < MI16; i++) fa[slot][i] = *reinterpret_cast<const f4 *>(a_s0 + buf * ABUF + fr16_a[g] + i * 16 * BKF);
+#pragma unroll
+            for (int j = 0; j < NI16; j++) fb[slot][j] = *reinterpret_cast<const f4 *>(b_s0 + buf * BBUF + fr16_b[g] + j * 16 * BKF);
+        } else {
 #pragma unroll
         for (int mi = 0; mi < MI; mi++) fa[slot][mi] = *reinterpret_cast<const f4 *>(a_s0 + buf * ABUF + fr_a[g] + mi * 32 * BKF);
 #pragma unroll
         for (int ni = 0; ni < NI; ni++) fb[slot][ni] = *reinterpret_cast<const f4 *>(b_s0 + buf * BBUF + fr_b[g] + ni * 32 * BKF);
+        }
     };
     auto mfma_group = [&](int slot) __attribute__((always_inline)) {
+        if constexpr (M16) {
+#pragma unroll
+            for (int i = 0; i < MI16; i++)
+#pragma unroll
+                for (int j = 0; j < NI16; j++)
+                    acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, fa[slot][i]), __builtin_bit_cast(bf8, fb[slot][j]),
+                                                                          acc16[i][j], 0, 0, 0);
+        } else {
 #pragma unroll
         for (int mi = 0; mi < MI; mi++)
 #pragma unroll
             for (int ni = 0; ni < NI; ni++)
                 acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, fa[slot][mi]), __builtin_bit_cast(bf8, fb[slot][ni]),
                                                                       acc[mi][ni], 0, 0, 0);
+        }
     };
     auto zero_acc = [&]() __attribute__((always_inline)) {
+        if constexpr (M16) {
+#pragma unroll
+            for (int i = 0; i < MI16; i++)
+#pragma unroll
+                for (int j = 0; j < NI16; j++) acc16[i][j] = f4{ 0.f, 0.f, 0.f, 0.f };
+        } else {
 #pragma unroll
         for (int mi = 0; mi < MI; mi++)
 #pragma unroll
             for (int ni = 0; ni < NI; ni++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[mi][ni][r] = 0.f;
+        }
     };
 
     // ---- three cursors over the flattened (tile, chunk) sequence of this workgroup: L (x loads) one chunk ahead of
@@ -266,7 +306,7 @@ __global__ __launch_bounds__(NT) void dwpw2_bf16(DwPw2Args a)
     // Returns false when the sequence is finished.
 #define MBN_DWPW2_STEP(P)                                                                                               \
     {                                                                                                                   \
-        ldfrag(P, 0, 0);                                                                                                \
+        if (!LATEFRAG) ldfrag(P, 0, 0);                                                                                 \
         bool validL = false;                                                                                            \
         int vbL = vbD, kL = kD + 1, n0L = n0D;                                                                          \
         unsigned m0L = m0D;                                                                                             \
@@ -281,6 +321,14 @@ __global__ __launch_bounds__(NT) void dwpw2_bf16(DwPw2Args a)
             if (validL && !(dbg & 1)) ldx(kL);                                                                        \
         }                                                                                                               \
         if (!(dbg & 16)) {                                                                                            \
+        if constexpr (M16) {                                                                                            \
+            if (LATEFRAG) ldfrag(P, 0, 0);                                                                              \
+            ldfrag(P, 1, 1);                                                                                            \
+            __builtin_amdgcn_sched_barrier(0);                                                                          \
+            mfma_group(0);                                                                                              \
+            __builtin_amdgcn_sched_barrier(0);                                                                          \
+            mfma_group(1);                                                                                              \
+        } else {                                                                                                        \
         _Pragma("unroll") for (int g = 0; g < 3; g++) {                                                                 \
             ldfrag(P, g + 1, (g + 1) & 1);                                                                              \
             __builtin_amdgcn_sched_barrier(0);                                                                          \
@@ -289,11 +337,17 @@ __global__ __launch_bounds__(NT) void dwpw2_bf16(DwPw2Args a)
         }                                                                                                               \
         mfma_group(1);                                                                                                  \
         }                                                                                                               \
+        }                                                                                                               \
         if (validL) lds_barrier<NX>();                                                                                  \
         else lds_barrier<0>();                                                                                          \
         if (kM == nk - 1 && !(dbg & 4)) {                                                                             \
+            if constexpr (M16) {                                                                                        \
+            if (m0M + BM <= mtot) mbn_store_relu6_bf16_pair16<MI16, NI16, 0>(orsrc, (unsigned)a.cout, m0M + wm, n0M + wn, lane, acc16, sc3_s, sh3_s); \
+            else mbn_store_relu6_bf16_pair16<MI16, NI16, 1>(orsrc, (unsigned)a.cout, m0M + wm, n0M + wn, lane, acc16, sc3_s, sh3_s);               \
+            } else {                                                                                                    \
             if (m0M + BM <= mtot) mbn_store_relu6_bf16_pair<MI, NI, 0>(orsrc, (unsigned)a.cout, m0M + wm, n0M + wn, lane, acc, sc3_s, sh3_s); \
             else mbn_store_relu6_bf16_pair<MI, NI, 1>(orsrc, (unsigned)a.cout, m0M + wm, n0M + wn, lane, acc, sc3_s, sh3_s);               \
+            }                                                                                                           \
             zero_acc();                                                                                                 \
         }                                                                                                               \
         if (!validD) break;                                                                                             \
@@ -317,9 +371,10 @@ void launch2(DwPw2Args &a, hipStream_t s, int num_cus)
     long grid = num_cus;
     if (grid > nwg) grid = nwg;
 #ifdef MBN_LAB
-    if (a.dbg) { hipLaunchKernelGGL((dwpw2_bf16<S, BN, true>), dim3((unsigned)grid), dim3(NT), 0, s, a); return; }
+    if (a.dbg) { hipLaunchKernelGGL((dwpw2_bf16<S, BN, true, false>), dim3((unsigned)grid), dim3(NT), 0, s, a); return; }
+    if (g_mbn_tune.misc == 32) { hipLaunchKernelGGL((dwpw2_bf16<S, BN, false, true>), dim3((unsigned)grid), dim3(NT), 0, s, a); return; }   // A/B: the 16x16x32 form
 #endif
-    hipLaunchKernelGGL((dwpw2_bf16<S, BN, false>), dim3((unsigned)grid), dim3(NT), 0, s, a);
+    hipLaunchKernelGGL((dwpw2_bf16<S, BN, false, false>), dim3((unsigned)grid), dim3(NT), 0, s, a);
 }
 
 }   // namespace

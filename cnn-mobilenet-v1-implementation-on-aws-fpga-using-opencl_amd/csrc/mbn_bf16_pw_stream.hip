@@ -416,7 +416,9 @@ static bool stream_common_ok(const mbn_call &c, const void *out, const void *in,
     if (((uintptr_t)in % 16) != 0 || ((uintptr_t)filt % 16) != 0 || ((uintptr_t)out % 4) != 0 || ((uintptr_t)c.scale % 8) != 0 ||
         ((uintptr_t)c.shift % 8) != 0)
         return false;
-    if ((double)m * cin * 2 >= (double)OOB || (double)m * op_size * 2 >= 4294967296.0 || (double)op_size * cin * 2 >= (double)OOB) return false;
+    // the output bound leaves a whole 256-row tile of head room: a ragged last tile's rows past M reach the range check as 32-bit byte offsets
+    // (row * N + col) * 2, which must not wrap into the first rows of the output
+    if ((double)m * cin * 2 >= (double)OOB || ((double)m + 256.0) * op_size * 2 >= 4294967296.0 || (double)op_size * cin * 2 >= (double)OOB) return false;
     return true;
 }
 

@@ -125,3 +125,40 @@ __device__ __forceinline__ void mbn_store_relu6_bf16_pair(__amdgpu_buffer_rsrc_t
             }
     }
 }
+
+// The same channel-paired bf16 store for accumulators of v_mfma_f32_16x16x32_bf16 blocks (the shape the chip holds a higher clock under,
+// profiles/r03/x_bf16_mfma_shape.txt). C/D of a 16 x 16 block: lane (c = l & 15, q = l >> 4) holds column c, rows 4 q .. 4 q + 3. With the filter
+// rows staged channel-paired (mbn_pair_channel), the 16-row LDS blocks j and j + 2 of a 64-column group hold channels 2 (16 j + c) and
+// 2 (16 j + c) + 1 (j = 0, 1): packed 4-byte stores, 64 contiguous bytes per pixel row and instruction, four rows per instruction.
+// acc[i][j]: i = 16-row block of the wave tile (MI16 of them), j = 16-column LDS block (NI16 = 4 per 64-column group, NI16 % 4 == 0).
+typedef float mbn_f4v __attribute__((ext_vector_type(4)));
+template <int MI16, int NI16, int MODE>
+__device__ __forceinline__ void mbn_store_relu6_bf16_pair16(__amdgpu_buffer_rsrc_t out, unsigned ldc, unsigned row0, int col0, int lane,
+                                                            const mbn_f4v (&acc)[MI16][NI16], const float *__restrict__ scale,
+                                                            const float *__restrict__ shift)
+{
+    static_assert((NI16 & 3) == 0, "channel-paired 16x16 epilogue needs whole 64-column groups");
+    typedef float f2e __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf2e __attribute__((ext_vector_type(2)));
+    const int c16 = lane & 15, q16 = lane >> 4;
+    const unsigned lane_off = ((unsigned)(4 * q16) * ldc + (unsigned)(2 * c16)) * 2u;      // bytes
+#pragma unroll
+    for (int t = 0; t < NI16 / 4; t++)
+#pragma unroll
+        for (int jp = 0; jp < 2; jp++) {
+            const f2e sc = *reinterpret_cast<const f2e *>(scale + col0 + 64 * t + 32 * jp + 2 * c16);
+            const f2e sh = *reinterpret_cast<const f2e *>(shift + col0 + 64 * t + 32 * jp + 2 * c16);
+#pragma unroll
+            for (int i = 0; i < MI16; i++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const unsigned ro = row0 + 16 * i + r;                                 // + 4 * q16 per lane
+                    const float v0 = fminf(fmaxf(fmaf(acc[i][4 * t + jp][r], sc.x, sh.x), 0.f), 6.f);
+                    const float v1 = fminf(fmaxf(fmaf(acc[i][4 * t + jp + 2][r], sc.y, sh.y), 0.f), 6.f);
+                    const unsigned v = __builtin_bit_cast(unsigned, bf2e{ (__bf16)v0, (__bf16)v1 });
+                    const unsigned soff = (ro * ldc + (unsigned)(col0 + 64 * t + 32 * jp)) * 2u;   // wave-uniform bytes
+                    if (MODE == 0) __builtin_amdgcn_raw_buffer_store_b32(v, out, lane_off, soff, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b32(v, out, lane_off + soff, 0, 0);
+                }
+        }
+}

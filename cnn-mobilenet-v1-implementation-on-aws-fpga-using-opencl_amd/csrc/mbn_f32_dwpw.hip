@@ -276,7 +276,7 @@ int mbn_f32_dwpw_check(const float *out, const float *in, const float *wd, const
         return MBN_EUNSUPPORTED;
     if (4.0 * batch * in_rows * in_cols * cin >= (double)OOB) return MBN_EUNSUPPORTED;
     if ((long)batch * out_rows * out_cols > 0x7fffff00L) return MBN_EUNSUPPORTED;                 // 32-bit pixel index
-    if (4.0 * batch * out_rows * out_cols * cout >= 4294967296.0) return MBN_EUNSUPPORTED;          // buffer stores
+    if (4.0 * ((double)batch * out_rows * out_cols + 256.0) * cout >= 4294967296.0) return MBN_EUNSUPPORTED;          // buffer stores; + a row tile of head room: ragged rows must not wrap (32-bit offsets)
     for (const float *p : ptrs)
         if (((uintptr_t)p % 16) != 0) return MBN_EUNSUPPORTED;
     return MBN_OK;

@@ -1381,6 +1381,21 @@ def test_net_full_size_fused_equals_unfused(pkg, ctx, tmp_path, n):
 def test_bf16_dwpw_fused(pkg, orc, ctx, shape):
     """mbn_dwpw_fused_bf16 vs the oracle's bf16 emulation of the pair (depthwise output rounded to bf16, bf16 pointwise
     filter, output rounded) and vs the two separate bf16 launches; bf16 tolerance (the pointwise summation order differs)."""
+    _bf16_dwpw_fused_body(pkg, orc, ctx, shape)
+
+
+@pytest.mark.parametrize("shape", [(2, 112, 64, 128, 2), (2, 56, 128, 128, 1), (2, 56, 128, 256, 2), (2, 28, 256, 256, 1), (3, 14, 64, 128, 1)])
+def test_bf16_dwpw_fused_16x16x32_form(pkg, orc, ctx, shape):
+    """LAB (misc = 32): the same block kernel with its pointwise products on v_mfma_f32_16x16x32_bf16 (round 4; measured equal to the shipped
+    32x32x16 form, profiles/r04/c_bf16_mfma_shape_blocks.txt): same checks, the exact-integer part pins its lane maps and channel pairing."""
+    _tune_lab(ctx, b"misc", 32)
+    try:
+        _bf16_dwpw_fused_body(pkg, orc, ctx, shape)
+    finally:
+        ctx.lib.mbn_tune_set(b"misc", 0)
+
+
+def _bf16_dwpw_fused_body(pkg, orc, ctx, shape):
     n, h, cin, cout, stride = shape
     rng = np.random.default_rng(h * 13 + cin + cout + stride)
     x = orc.bf16_round(rng.uniform(0, 4, (n, h, h, cin)).astype(np.float32))
@@ -1405,6 +1420,27 @@ def test_bf16_dwpw_fused(pkg, orc, ctx, shape):
     fused, sep = _bf16_get(pkg, d_f, want.shape), _bf16_get(pkg, d_u, want.shape)
     assert_close(fused, want, TOL_BF16, "bf16 fused block %s vs oracle" % (shape,))
     assert_close(fused, sep, TOL_BF16, "bf16 fused block %s vs separate launches" % (shape,))
+    # exact small integers: a centre-tap depthwise filter with
+    # identity BN hands the window's centre pixel through, an asymmetric integer pointwise filter then makes every output an exact small
+    # integer — any mix-up of the operand lane maps (k = 32 kg + 8 q), of the 16 x 16 C/D map or of the channel pairing across LDS blocks
+    # j and j + 2 shows as a wrong integer
+    xi = rng.integers(0, 4, (n, h, h, cin)).astype(np.float32)
+    wdi = np.zeros((3, 3, cin), np.float32)
+    wdi[1, 1, :] = 1.0
+    wpi = rng.integers(-2, 3, (cout, cin)).astype(np.float32)
+    wpi[:, 0] = np.arange(cout) % 5
+    wpi[:, cin - 1] = np.arange(cout) % 3
+    one2, zero2, one3, zero3 = (ctx.to_device(a) for a in (np.ones(cin, np.float32), np.zeros(cin, np.float32), np.ones(cout, np.float32), np.zeros(cout, np.float32)))
+    d_xi, d_wdi, d_wpi = _bf16_dev(pkg, ctx, xi), ctx.to_device(wdi), _bf16_dev(pkg, ctx, wpi)
+    rc = ctx.lib.mbn_dwpw_fused_bf16(ctx.h, d_f.ptr, d_xi.ptr, d_wdi.ptr, one2.ptr, zero2.ptr, d_wpi.ptr, one3.ptr, zero3.ptr,
+                                     n, h, h, oh, oh, cin, cout, stride, pad, pad, None)
+    assert rc == 0, rc
+    ctx.sync()
+    midi = orc.f32_depthwise(xi, wdi, np.ones(cin, np.float32), np.zeros(cin, np.float32), stride, 2, pad_top=pad, pad_left=pad)
+    wanti = np.clip(midi.reshape(-1, cin).astype(np.float64) @ wpi.astype(np.float64).T, 0, 6).reshape(n, oh, oh, cout)
+    assert np.array_equal(_bf16_get(pkg, d_f, want.shape).astype(np.float64), wanti), "bf16 fused block %s: exact integers" % (shape,)
+    for b in (one2, zero2, one3, zero3, d_xi, d_wdi, d_wpi):
+        b.free()
 
 
 # =========================================================================== headline workloads
@@ -1904,11 +1940,14 @@ def test_bf16_pointwise_wide_kernel(pkg, orc, ctx, shape):
         b.free()
 
 
-@pytest.mark.parametrize("shape", [(49, 1024, 1024), (196, 512, 512), (5, 512, 1024), (3 * 196 + 1, 512, 512), (12544, 1024, 1024)])
-def test_bf16_pointwise_k512_up_is_one_kernel_at_every_m(pkg, orc, ctx, shape):
-    """bf16 pointwise layers with K >= 512 (layers 15 ... 27) run on the streaming kernel's 16x16x32 form at EVERY M — one image or 512 —
-    so that an image's result does not depend on the batch: against the oracle, and the first rows of a call bit for bit equal to a call
-    with those rows alone (M = 1, 49, 196 included: fewer rows than one tile)."""
+@pytest.mark.parametrize("shape", [(49, 1024, 1024), (196, 512, 512), (5, 512, 1024), (3 * 196 + 1, 512, 512), (12544, 1024, 1024),
+                                   (196, 256, 512), (2 * 3136 + 5, 256, 256), (25600 + 77, 256, 512), (400, 256, 128)])
+def test_bf16_pointwise_k256_up_is_one_kernel_at_every_m(pkg, orc, ctx, shape):
+    """bf16 pointwise layers with K >= 256 (1.0x224: layers 13 ... 27; 0.5x160: 15 ... 27; round 3: K >= 512) run on the streaming kernel's
+    16x16x32 form at EVERY M — one image or 512 — so that an image's result does not depend on the batch: against the oracle, the first rows
+    of a call bit for bit equal to a call with those rows alone (M = 1, 49, 196 included: fewer rows than one tile), and — on this SHIPPED
+    path, not a lab knob — exact small integers through an asymmetric filter (operand lane maps k = 32 kg + 8 q, the 16 x 16 C/D map, channel
+    pairing across LDS blocks j and j + 2, ragged M)."""
     m, cin, cout = shape
     rng = np.random.default_rng(m + cin + cout)
     x = orc.bf16_round(rng.uniform(-1, 1, (m, cin)))
@@ -1928,6 +1967,19 @@ def test_bf16_pointwise_k512_up_is_one_kernel_at_every_m(pkg, orc, ctx, shape):
         ctx.pointwise(d_o.ptr, d_x.ptr, d_f.ptr, k, 1, cin, cout, ext)
         ctx.sync()
         assert np.array_equal(_bf16_get(pkg, d_o, (k, cout)), got[:k]), "rows depend on M (%d of %d)" % (k, m)
+    xi = rng.integers(-3, 4, (m, cin)).astype(np.float32)
+    fi = rng.integers(-2, 3, (cout, cin)).astype(np.float32)
+    fi[:, 0] = np.arange(cout) % 5
+    fi[:, cin - 1] = np.arange(cout) % 3
+    one, zero = ctx.to_device(np.ones(cout, np.float32)), ctx.to_device(np.zeros(cout, np.float32))
+    d_x.upload(pkg.f32_to_bf16_bits(xi)); d_f.upload(pkg.f32_to_bf16_bits(fi))
+    ctx.pointwise(d_o.ptr, d_x.ptr, d_f.ptr, m, 1, cin, cout, pkg.make_ext(dtype=pkg.DT_BF16, act=2, scale=one.ptr, shift=zero.ptr))
+    ctx.sync()
+    goti = _bf16_get(pkg, d_o, (m, cout))
+    for lo in (0, max(0, m - 4096)):
+        want = np.clip(xi[lo:lo + 4096].astype(np.float64) @ fi.astype(np.float64).T, 0, 6)
+        assert np.array_equal(goti[lo:lo + 4096].astype(np.float64), orc.bf16_round(want.astype(np.float32)).astype(np.float64)), "exact integers %s" % (shape,)
+    one.free(); zero.free()
     for b in (d_x, d_f, d_sc, d_sh, d_o):
         b.free()
 
