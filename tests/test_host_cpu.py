@@ -543,3 +543,18 @@ def test_udiv_magic_formula():
         for v in vals:
             if 0 <= v < (1 << 31):
                 assert ((v * m) >> 32) >> s == v // d, (v, d)
+
+
+def test_pw_gemm_counted_waits_match_the_isa():
+    """`s_waitcnt vmcnt(NSTF); s_barrier` at the top of a pw_gemm tile is right only if the previous tile's fast epilogue is
+    EXACTLY NSTF buffer stores, all behind the next tile's first LDS-DMA, in the instruction stream the compiler produced. The source
+    pins that with sched_barrier(0); tools/check_counted_waits.py reads the gfx950 ISA of csrc/mbn_f32_pw.hip (hipcc -S, ~10 s, no GPU
+    needed) and fails if a compiler change merges, splits or interleaves them."""
+    import subprocess
+    import sys
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_counted_waits.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "kernels with a counted wait checked" in r.stdout
