@@ -104,9 +104,15 @@ __device__ __forceinline__ void dma_filter(__amdgpu_buffer_rsrc_t rsrc, float *l
 // DBG = false: the shipped kernel — every experiment switch (a.dbg) folds away at compile time, which takes ~40 scalar branches and the
 // conservative waits around them out of the step. DBG = true is launched only for tune dwpw_variant >= 100.
 // NW = 16 (lab, BN = 128 only): the same kernel on a 256-row tile with 16 waves = 4 per SIMD at <= 128 VGPRs (taps read from LDS inside the step)
-template <int S, int BN, bool PRE, bool DBG, int NW = 8>
+// XA2 (round 4): the x window of a chunk is requested TWO steps ahead of the depthwise part that consumes it, into a second register set. In the one-ahead
+// form the window's four load groups are issued under the MFMA groups of the step BEFORE the one that needs them — the last group a few hundred cycles
+// ahead of the barrier behind which the depthwise part starts — so part of every window waits out its HBM latency inside D (stamps, profiles/r02/g_*:
+// D 1283 cycles for ~54 VALU instructions). Two ahead, every load has a whole step (~7 k cycles) before the barrier that (vmcnt in order) completes it.
+// Costs 4 NX VGPRs: fits next to the taps (PRE) for S = 1 / BN = 128, with the taps read inside the step (PRE = false) for S = 1 / BN = 256 and S = 2 / BN = 128.
+template <int S, int BN, bool PRE, bool DBG, int NW = 8, bool XA2 = false>
 __global__ __launch_bounds__(64 * NW) void dwpw2_f32(DwPw2Args a)
 {
+    static_assert(!XA2 || (!DBG && NW == 8), "XA2: shipped 8-wave form only");
     const int dbg = DBG ? a.dbg : 0;
     constexpr int NT = 64 * NW, BM = 16 * NW;
     constexpr int WN = 64, WM = BN == 256 ? 64 : 32;   // wave tile: 8 waves as 2 x 4 (BN 256) or 4 x 2 (BN 128)
@@ -195,23 +201,25 @@ __global__ __launch_bounds__(64 * NW) void dwpw2_f32(DwPw2Args a)
             }
         }
     };
-    f4 xr[3][XC];
-    auto ldx = [&](int kc) __attribute__((always_inline)) {
+    f4 xr[XA2 ? 2 : 1][3][XC];
+    auto ldx_set = [&](int kc, const int set) __attribute__((always_inline)) {
 #pragma unroll
         for (int dy = 0; dy < 3; dy++)
 #pragma unroll
             for (int j = 0; j < XC; j++)
-                xr[dy][j] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(irsrc, off[dy][j], kc * 128, 0));
+                xr[set][dy][j] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(irsrc, off[dy][j], kc * 128, 0));
     };
+    auto ldx = [&](int kc) __attribute__((always_inline)) { ldx_set(kc, 0); };
     // the same loads in four parts (3+3+3+3 or 4+4+4+3), one in front of each MFMA group of the step: issued as one burst
     // right after D, the 8 waves' 96-120 loads queue up behind each other in the CU's one address unit — ~800 cycles of issue
     // stall per wave and step in the stamps (profiles/r02/g_dwpw2_stamps.txt); spread out they issue under the MFMAs
-    auto ldx_part = [&](int kc, const int part) __attribute__((always_inline)) {
+    auto ldx_part_set = [&](int kc, const int part, const int set) __attribute__((always_inline)) {
         constexpr int PER = (NX + 3) / 4;
 #pragma unroll
         for (int i = part * PER; i < (part + 1) * PER && i < NX; i++)
-            xr[i / XC][i % XC] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(irsrc, off[i / XC][i % XC], kc * 128, 0));
+            xr[set][i / XC][i % XC] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(irsrc, off[i / XC][i % XC], kc * 128, 0));
     };
+    auto ldx_part = [&](int kc, const int part) __attribute__((always_inline)) { ldx_part_set(kc, part, 0); };
     f4 wreg[11];                                                               // 9 taps, scale, shift of the chunk D works on
     auto ldw = [&](int kc) __attribute__((always_inline)) {
 #pragma unroll
@@ -220,7 +228,7 @@ __global__ __launch_bounds__(64 * NW) void dwpw2_f32(DwPw2Args a)
         wreg[10] = *reinterpret_cast<const f4 *>(sk + a.cin + kc * 32);
     };
     // depthwise + BN + ReLU6 of the chunk in xr/wreg into A buffer `buf` (same fma order as mbn_f32_dw.hip: bit-identical)
-    auto dw = [&](int kc, const int buf) __attribute__((always_inline)) {
+    auto dw_set = [&](int kc, const int buf, const int set) __attribute__((always_inline)) {
         f4 acc0 = f4{ 0.f, 0.f, 0.f, 0.f }, acc1 = acc0;
         if constexpr (NW > 8) {
             // register-lean forms (> 2 waves per SIMD): one filter row of taps at a time, read where it is used (same fma order: same bits)
@@ -232,8 +240,8 @@ __global__ __launch_bounds__(64 * NW) void dwpw2_f32(DwPw2Args a)
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int dx = 0; dx < 3; dx++) {
-                    acc0 = __builtin_elementwise_fma(xr[dy][dx], t3[dx], acc0);
-                    acc1 = __builtin_elementwise_fma(xr[dy][dx + S], t3[dx], acc1);
+                    acc0 = __builtin_elementwise_fma(xr[set][dy][dx], t3[dx], acc0);
+                    acc1 = __builtin_elementwise_fma(xr[set][dy][dx + S], t3[dx], acc1);
                 }
             }
             const f4 sc2 = *reinterpret_cast<const f4 *>(sk + kc * 32), sh2 = *reinterpret_cast<const f4 *>(sk + a.cin + kc * 32);
@@ -246,12 +254,13 @@ __global__ __launch_bounds__(64 * NW) void dwpw2_f32(DwPw2Args a)
         for (int dy = 0; dy < 3; dy++)
 #pragma unroll
             for (int dx = 0; dx < 3; dx++) {
-                acc0 = __builtin_elementwise_fma(xr[dy][dx], wreg[dy * 3 + dx], acc0);
-                acc1 = __builtin_elementwise_fma(xr[dy][dx + S], wreg[dy * 3 + dx], acc1);
+                acc0 = __builtin_elementwise_fma(xr[set][dy][dx], wreg[dy * 3 + dx], acc0);
+                acc1 = __builtin_elementwise_fma(xr[set][dy][dx + S], wreg[dy * 3 + dx], acc1);
             }
         *reinterpret_cast<f4 *>(a_s0 + buf * ABUF + aw0) = bn_relu6(acc0, wreg[9], wreg[10]);
         *reinterpret_cast<f4 *>(a_s0 + buf * ABUF + aw1) = bn_relu6(acc1, wreg[9], wreg[10]);
     };
+    auto dw = [&](int kc, const int buf) __attribute__((always_inline)) { dw_set(kc, buf, 0); };
 
     f16v acc[MI][NI];
     f4 fa[2][MI], fb[2][NI];
@@ -290,11 +299,15 @@ __global__ __launch_bounds__(64 * NW) void dwpw2_f32(DwPw2Args a)
         m0 = (unsigned)(lid / a.nt) * BM;
     };
 
-    // prologue: L(0), D(0) into buffer 0, L(1)
+    // XA2: a third persistent cursor, L = successor of D (its window is already in flight / in registers: set (chunk ordinal) & 1)
+    [[maybe_unused]] int vbL = 0, kL = 0, n0L = 0; [[maybe_unused]] unsigned m0L = 0;
+    [[maybe_unused]] bool validL1 = false;
+
+    // prologue: L(0), D(0) into buffer 0, L(1)  [XA2: and L(2)]
     vbM = blockIdx.x; kM = 0;
     origin(vbM, m0M, n0M);
     set_offsets(m0M);
-    ldx(0);
+    ldx(0);                                   // chunk 0 -> x set 0
     if (PRE) ldw(0);
     dma_filter<B_LD, NT, BN>(wrsrc, b_s0, b_vo, (n0M * a.cin + 0) * 4, wave_u);
     dw(0, 0);
@@ -305,12 +318,26 @@ __global__ __launch_bounds__(64 * NW) void dwpw2_f32(DwPw2Args a)
         if (validD) { origin(vbD, m0D, n0D); set_offsets(m0D); }
     }
     if (validD) {
-        ldx(kD);
+        ldx_set(kD, XA2 ? 1 : 0);             // chunk 1 -> x set 1 (XA2) / the one set
         if (PRE) ldw(kD);
     }
+    if constexpr (XA2) {
+        vbL = vbD; kL = kD + 1; m0L = m0D; n0L = n0D; validL1 = validD;
+        if (validL1 && kL >= nk) {
+            kL = 0; vbL += gridDim.x; validL1 = vbL < nwg;
+            if (validL1) { origin(vbL, m0L, n0L); set_offsets(m0L); }
+        }
+        if (validL1) ldx_set(kL, 0);          // chunk 2 -> x set 0 (chunk 0's window has been consumed by dw(0, 0))
+    }
     zero_acc();
+    if constexpr (XA2) {
+        if (validL1) lds_barrier<2 * NX>();   // filter chunk 0 landed; the two newer windows may fly
+        else if (validD) lds_barrier<NX>();
+        else lds_barrier<0>();
+    } else {
     if (validD) lds_barrier<NX>();        // filter chunk 0 landed; the NX newer loads may fly
     else lds_barrier<0>();
+    }
 
     // The finished tile's epilogue is issued in the NEXT step, behind that step's depthwise part and filter DMA and ahead of its MFMAs
     // (round 3). vmcnt retires in order: with the 16 / 32 stores issued right behind the barrier — ahead of the next step's filter DMA —
@@ -393,12 +420,68 @@ __global__ __launch_bounds__(64 * NW) void dwpw2_f32(DwPw2Args a)
         vbD = vbL; kD = kL; m0D = m0L; n0D = n0L; validD = validL;                                                      \
     }
 
+    // XA2 step with the MFMA chunk in buffer P: M(c_s) from A/B buffers P; D(c_s+1) from x set P^1 into buffers P^1; the window of c_s+3 is
+    // requested into x set P^1 (just consumed) under the MFMA groups; taps (PRE) of c_s+2 behind the MFMAs. Barrier: the filter DMA of this step has
+    // landed — everything older has too (vmcnt in order: c_s+2's window, requested a whole step ago) — the NX (+ NST) younger operations may fly.
+#define MBN_DWPW2_STEP2(P)                                                                                              \
+    {                                                                                                                   \
+        __builtin_amdgcn_s_setprio(3);                                                                                  \
+        ldfrag(P, 0, 0);                                                                                                \
+        bool validL2 = false;                                                                                           \
+        int vbL2 = vbL, kL2 = kL + 1, n0L2 = n0L;                                                                       \
+        unsigned m0L2 = m0L;                                                                                            \
+        if (validD) {                                                                                                   \
+            dw_set(kD, P ^ 1, P ^ 1);                                                                                   \
+            dma_filter<B_LD, NT, BN>(wrsrc, b_s0 + (P ^ 1) * BBUF, b_vo, (n0D * a.cin + kD * 32) * 4, wave_u);          \
+            if (validL1) {                                                                                              \
+                validL2 = true;                                                                                         \
+                if (kL2 >= nk) {                                                                                        \
+                    kL2 = 0; vbL2 += gridDim.x; validL2 = vbL2 < nwg;                                                   \
+                    if (validL2) { origin(vbL2, m0L2, n0L2); set_offsets(m0L2); }                                       \
+                }                                                                                                       \
+            }                                                                                                           \
+        }                                                                                                               \
+        const bool didE = pendE;                               /* exactly NST stores are in flight behind the DMA */      \
+        if (pendE) {                                                                                                    \
+            epilogue(m0E, n0E);                                                                                         \
+            zero_acc();                                                                                                 \
+            pendE = false;                                                                                              \
+        }                                                                                                               \
+        __builtin_amdgcn_s_setprio(0);                                                                                  \
+        _Pragma("unroll") for (int g = 0; g < 3; g++) {                                                                 \
+            ldfrag(P, g + 1, (g + 1) & 1);                                                                              \
+            if (validL2) ldx_part_set(kL2, g, P ^ 1);                                                                   \
+            __builtin_amdgcn_sched_barrier(0);                                                                          \
+            mfma_group(g & 1);                                                                                          \
+            __builtin_amdgcn_sched_barrier(0);                                                                          \
+        }                                                                                                               \
+        if (validL2) ldx_part_set(kL2, 3, P ^ 1);                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+        mfma_group(1);                                                                                                  \
+        if (PRE && validL1) ldw(kL);                                                                                    \
+        if (validL2) { if (didE) lds_barrier<NX + NST>(); else lds_barrier<NX>(); }                                     \
+        else { if (didE) lds_barrier<NST>(); else lds_barrier<0>(); }                                                   \
+        if (kM == nk - 1) { pendE = true; m0E = m0M; n0E = n0M; }                                                       \
+        if (!validD) break;                                                                                             \
+        vbM = vbD; kM = kD; m0M = m0D; n0M = n0D;                                                                       \
+        vbD = vbL; kD = kL; m0D = m0L; n0D = n0L; validD = validL1;                                                     \
+        vbL = vbL2; kL = kL2; m0L = m0L2; n0L = n0L2; validL1 = validL2;                                                \
+    }
+
+    if constexpr (XA2) {
+        for (;;) {
+            MBN_DWPW2_STEP2(0)
+            MBN_DWPW2_STEP2(1)
+        }
+    } else {
     for (;;) {
         MBN_DWPW2_STEP(0)
         MBN_DWPW2_STEP(1)
     }
+    }
     if (pendE && !(dbg & 4)) epilogue(m0E, n0E);               // the workgroup's last tile
 #undef MBN_DWPW2_STEP
+#undef MBN_DWPW2_STEP2
 #undef STAMP
 }
 
@@ -424,6 +507,12 @@ void launch2(DwPw2Args &a, hipStream_t s, int num_cus, bool pre)
     long grid = num_cus;
     if (grid > nwg) grid = nwg;
 #ifdef MBN_LAB                                                       // ablation / stamp builds and the taps-inside-the-step form: dwpw_variant
+    if (g_mbn_tune.dwpw_variant == 7 || g_mbn_tune.dwpw_variant == 8) {      // r4 A/B: x window two steps ahead (7: where it fits with the taps in registers; 8: also the PRE = false forms)
+        if constexpr (S == 1 && BN == 128) { hipLaunchKernelGGL((dwpw2_f32<S, BN, true, false, 8, true>), dim3((unsigned)grid), dim3(NT), 0, s, a); return; }
+        else if constexpr (!(S == 2 && BN == 256)) {
+            if (g_mbn_tune.dwpw_variant == 8) { hipLaunchKernelGGL((dwpw2_f32<S, BN, false, false, 8, true>), dim3((unsigned)grid), dim3(NT), 0, s, a); return; }
+        }
+    }
     if (a.dbg) {
         if (pre) hipLaunchKernelGGL((dwpw2_f32<S, BN, true, true>), dim3((unsigned)grid), dim3(NT), 0, s, a);
         else hipLaunchKernelGGL((dwpw2_f32<S, BN, false, true>), dim3((unsigned)grid), dim3(NT), 0, s, a);

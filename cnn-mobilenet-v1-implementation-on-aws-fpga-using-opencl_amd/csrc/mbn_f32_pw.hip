@@ -7,8 +7,11 @@
 // NHWC makes `in` a row-major [M][K] matrix and `out` a row-major [M][Cout] matrix with no data movement;
 // `filt` keeps kernel.cl's own order [oc][ic] = [Cout][K]. Both operands are therefore K-contiguous ("NT" GEMM).
 //
-// MFMA, fp32: v_mfma_f32_32x32x2_f32 — exact fp32 (bit-identical to an fmaf chain over k), 64 FLOP/clk/SIMD, the fp32
-// matrix peak of 157.3 TFLOP/s. Lane l feeds A[i=l&31][k=l>>5] and B[k=l>>5][j=l&31], one float each. K order inside
+// MFMA, fp32: v_mfma_f32_32x32x2_f32 — fp32 products, fp32 accumulate, 64 FLOP/clk/SIMD, the fp32 matrix peak of 157.3 TFLOP/s. NOT
+// bit-identical to a sequential fmaf chain over k (round 4, tools/mfma_vs_fma_chain.py, profiles/r04/d_mfma_vs_fmaf_chain.txt: against pw_generic's
+// chain 26-37 % of the elements differ in the last bits, both equally far from float64): the two products of an instruction are not chained through
+// single-rounding fmas. What IS fixed is the k order and the grouping, so every kernel built on this instruction with the same k order agrees bit
+// for bit (pw_gemm tiles, the fused block kernels, the stem's pointwise phase). Lane l feeds A[i=l&31][k=l>>5] and B[k=l>>5][j=l&31], one float each. K order inside
 // an 8-wide k-group is permuted so that ONE ds_read_b128 per lane feeds four MFMAs: lane half h=l>>5 owns
 // k = 8g+4h .. 8g+4h+3 and MFMA step s consumes element s of both operands' float4 (the same k on both sides).
 // MFMA, bf16: v_mfma_f32_32x32x16_bf16 — lane (r=l&31, h=l>>5) holds A[r][k=8h+j], j=0..7 = the same 16-byte chunk

@@ -947,11 +947,13 @@ DWPW_SHAPES = [  # (batch, in side, Cin, Cout, stride)
 ]
 
 
-@pytest.mark.parametrize("variant", [0, 6, 5])
+@pytest.mark.parametrize("variant", [0, 6, 5, 7, 8])
 @pytest.mark.parametrize("shape", DWPW_SHAPES)
 def test_f32_dwpw_fused(pkg, orc, ctx, shape, variant):
     """mbn_dwpw_fused vs mbn_depthwise + mbn_pointwise (same arithmetic order -> bit-identical) and vs the oracle.
-    variant 6 / 5 (lab build): the unified kernel with 12 / 16 waves on 192- / 256-row tiles (128-column tiles only)."""
+    variant 6 / 5 (lab build): the unified kernel with 12 / 16 waves on 192- / 256-row tiles (128-column tiles only);
+    7 / 8 (lab build, round 4): the x window requested two steps ahead into a second register set (7: stride 1 with 128-column tiles;
+    8: also stride 2 with 128-column tiles and the taps read inside the step)."""
     n, h, cin, cout, stride = shape
     if variant:
         _tune_lab(ctx, b"dwpw_variant", variant)
