@@ -172,6 +172,65 @@ __global__ __launch_bounds__(256) void conv3x3s2c3_f32_nhwc(ConvArgs a)
     }
 }
 
+// Round 4: the network's first layer at 32 output channels in fp32 (alpha = 1) as a K = 27 -> 28 GEMM on v_mfma_f32_16x16x4_f32 — the arithmetic of
+// the fused stem's conv1 phase (mbn_f32_stem.hip, MCF), instruction for instruction, so that the stem stays bit-identical to the three separate
+// launches: a wave = 16 adjacent output pixels of one row; lane (pc = l & 15, kg = l >> 4) supplies tap k = 4 t + kg of pixel pc as the B operand
+// and w[k][16 h + pc] as the A operand of step t = 0..6, one accumulator chain per 16-channel half h, and receives channels 16 h + 4 kg .. + 3 of
+// pixel pc (one float4 of BN + ReLU6, one 16-byte store: 128 contiguous bytes per pixel across h and kg). Taps outside the image and k = 27 are 0.
+// The fmaf-chain kernel above stays for every other shape (and, as the comment there says, was 8 % faster than a 32x32x2 gather form in round 1;
+// this one is off the default path — the fused stem runs layers 1-3 — and within a few percent of it: profiles/r04/f_stem_conv1_mfma.txt).
+__global__ __launch_bounds__(256) void conv1_mfma_f32(ConvArgs a)
+{
+    const int lane = threadIdx.x & 63, kg = lane >> 4, pc = lane & 15;
+    const int bpr = a.ocol >> 4;                                          // 16-pixel blocks per output row
+    const long nblk = (long)a.batch * a.orow * bpr;
+    const long nwave = ((long)gridDim.x * blockDim.x) >> 6;
+    float w[2][7];
+    int dk[7], drem[7];
+#pragma unroll
+    for (int t = 0; t < 7; t++) {
+        const int k = 4 * t + kg;
+        dk[t] = k / 9;                                                    // filter row (3: the padding tap k = 27)
+        drem[t] = k % 9;                                                  // 3 kx + ci
+#pragma unroll
+        for (int h = 0; h < 2; h++) w[h][t] = k < 27 ? a.filt[k * 32 + 16 * h + pc] : 0.f;
+    }
+    f4 s1[2], b1[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        s1[h] = *reinterpret_cast<const f4 *>(a.scale + 16 * h + 4 * kg);
+        b1[h] = *reinterpret_cast<const f4 *>(a.shift + 16 * h + 4 * kg);
+    }
+    for (long blk = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; blk < nblk; blk += nwave) {
+        const int bx = (int)(blk % bpr);
+        const long q = blk / bpr;
+        const int oy = (int)(q % a.orow);
+        const long n = q / a.orow;
+        const int ox = bx * 16 + pc;
+        const long img = n * a.rows * a.cols * 3;
+        float xv[7];
+#pragma unroll
+        for (int t = 0; t < 7; t++) {
+            const int iy = oy * 2 + dk[t] - a.pad_top;
+            const int fx = ox * 6 + drem[t];                              // pad_left == 0 on this path: float index inside the row
+            const bool ok = dk[t] < 3 && iy >= 0 && iy < a.rows && fx < a.cols * 3;
+            const long idx = img + (long)iy * a.cols * 3 + fx;
+            xv[t] = ok ? (a.in8 ? norm_u8(a.in8[idx]) : a.in[idx]) : 0.f;
+        }
+        float *op = reinterpret_cast<float *>(a.out) + (((n * a.orow + oy) * a.ocol + ox) * 32) + 4 * kg;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            f4 acc = f4{ 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+            for (int t = 0; t < 7; t++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[h][t], xv[t], acc, 0, 0, 0);
+            f4 r = f4{ fmaf(acc.x, s1[h].x, b1[h].x), fmaf(acc.y, s1[h].y, b1[h].y), fmaf(acc.z, s1[h].z, b1[h].z), fmaf(acc.w, s1[h].w, b1[h].w) };
+            r.x = fminf(fmaxf(r.x, 0.f), 6.f); r.y = fminf(fmaxf(r.y, 0.f), 6.f);
+            r.z = fminf(fmaxf(r.z, 0.f), 6.f); r.w = fminf(fmaxf(r.w, 0.f), 6.f);
+            *reinterpret_cast<f4 *>(op + 16 * h) = r;
+        }
+    }
+}
+
 // any cout / unaligned: one lane per output element, filter from global memory
 template <typename TO>
 __global__ __launch_bounds__(256) void conv_generic_f32_nhwc(ConvArgs a)
@@ -472,7 +531,16 @@ int mbn_launch_f32_conv(const mbn_call &c, void *out, const void *in_v, const fl
     const bool first_layer = fast && fs == 3 && c.cin == 3 && stride == 2 && a.pad_left == 0 && (cols % 4) == 0 &&
                              (a.ocol % 4) == 0 && 2 * a.ocol == cols && ((uintptr_t)in % (u8in ? 4 : 16)) == 0 &&
                              g_mbn_tune.conv_variant != 1;
-    if (first_layer) {
+    // alpha = 1 in fp32: the MFMA form — the fused stem's conv1 arithmetic (see conv1_mfma_f32); lab conv_variant = 6: the fmaf-chain kernel instead (A/B)
+    if (first_layer && !bf && op_size == 32 && (a.ocol % 16) == 0 && c.act == MBN_ACT_RELU6 && c.scale && c.shift && g_mbn_tune.conv_variant != 6 &&
+        (double)c.batch * rows * cols * 3 < 9.0e18) {
+        const long nblk = (long)c.batch * a.orow * (a.ocol / 16);
+        long wgs = (nblk + 3) / 4;                                        // 4 waves per workgroup, one block per wave and trip
+        const long cap = (long)c.ctx->num_cus * 8;
+        if (wgs > cap) wgs = cap;
+        a.total = nblk;
+        hipLaunchKernelGGL(conv1_mfma_f32, dim3((unsigned)wgs), dim3(256), 0, c.stream, a);
+    } else if (first_layer) {
         a.total = (long)c.batch * a.orow * (a.ocol / 4) * (op_size / 4);
         const dim3 grid((unsigned)((a.total + 255) / 256));
         if (bf) hipLaunchKernelGGL(conv3x3s2c3_f32_nhwc<__bf16>, grid, dim3(256), wbytes, c.stream, a);

@@ -168,7 +168,8 @@ __device__ __forceinline__ void x6_split8(f4 v0, f4 v1, unsigned (&h)[4], unsign
 template <int C1, int C3, bool BF, int WPE, bool MC = false, int X6 = 0>
 __global__ __launch_bounds__(256, WPE) void stem_fused_f32(StemArgs a)
 {
-    static_assert(!MC || BF, "conv1 on the bf16 MFMA: bf16 mode");
+    static_assert(!MC || BF || C1 == 32, "conv1 on the MFMA: bf16 mode (16x16x32 bf16, split operands), or fp32 alpha = 1 (16x16x4 fp32)");
+    constexpr bool MCF = MC && !BF;                // round 4: conv1 as a K = 27 -> 28 GEMM on v_mfma_f32_16x16x4_f32 (fp32 products, fp32 sums)
     static_assert(X6 == 0 || (!BF && (X6 == 6 || X6 == 9)), "split products: fp32 mode, 6 or 9 of them");
     constexpr int APL = TH * TW * C1 / 2, BPL = C3 * C1 / 2;       // X6: floats per bf16 plane of the A / B tile
     constexpr int MH = C1 / 16;                    // MC: 16-channel halves (2 / 1)
@@ -265,7 +266,31 @@ __global__ __launch_bounds__(256, WPE) void stem_fused_f32(StemArgs a)
     [[maybe_unused]] unsigned mc_kok = 0;                                     // bit j: tap k = 8 kg + j exists (k < 27)
     [[maybe_unused]] bf8 mc_wh[MH], mc_wl[MH];
     [[maybe_unused]] f4 mc_s1[MH], mc_b1[MH];                                    // BN of the lane's 4 output channels 16h + 4kg .. +3
-    if constexpr (MC) {
+    // ---- MCF (fp32 mode, C1 = 32): the same GEMM view on v_mfma_f32_16x16x4_f32, K = 27 taps padded to 28 = 7 instructions deep. Weights are the
+    // A operand (rows = 16 channels of half h, k = 4 t + kg), the 16 pixels of a block the B operand: C/D puts channels 16 h + 4 kg .. + 3 of pixel pc
+    // into this lane — one float4 of BN, one 16-byte LDS store, as in the bf16 form. 42 MFMAs of 32 cycles per wave and tile replace 324 v_pk_fma_f32 +
+    // 57 ds_read_b128: on a SIMD whose fp32 MFMA and VALU issue times add (profiles/r04/b_pmc_fp32_step_all_passes.txt: the stem is issue-bound, 763
+    // vector instructions per wave and tile) the matrix form is the cheaper instruction stream. Its sums are NOT those of the fmaf chain of the VALU
+    // form (profiles/r04/d_mfma_vs_fmaf_chain.txt), so the stand-alone conv1 kernel uses the same instruction and k order when this form ships.
+    [[maybe_unused]] int mcf_dl[7];
+    [[maybe_unused]] float mcf_w[2][7];
+    [[maybe_unused]] f4 mcf_s1[2], mcf_b1[2];
+    if constexpr (MCF) {
+        const int kg = lane >> 4, pc = lane & 15;
+#pragma unroll
+        for (int t = 0; t < 7; t++) {
+            const int k = 4 * t + kg;
+            mcf_dl[t] = k < 27 ? (k / 9) * PROW + (k % 9) : 0;
+#pragma unroll
+            for (int h = 0; h < 2; h++) mcf_w[h][t] = k < 27 ? w1_s[k * C1 + 16 * h + pc] : 0.f;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            mcf_s1[h] = *reinterpret_cast<const f4 *>(sb_s + 16 * h + 4 * kg);
+            mcf_b1[h] = *reinterpret_cast<const f4 *>(sb_s + C1 + 16 * h + 4 * kg);
+        }
+    }
+    if constexpr (MC && BF) {
         const int kg = lane >> 4, pc = lane & 15;
         unsigned whb[MH][8], wlb[MH][8];
 #pragma unroll
@@ -312,6 +337,32 @@ __global__ __launch_bounds__(256, WPE) void stem_fused_f32(StemArgs a)
 
         // ---- B. conv1 (3x3x3, stride 2, pad 0 top/left) + BN + ReLU6 over the 10 x 18 region, 6 pixels x 4 ch per lane
         __builtin_amdgcn_s_setprio(2);                              // VALU phases ahead of the co-resident workgroups' MFMA phase (-3 % / -5 %: profiles/r02/j_stem_occupancy.txt)
+        if constexpr (MCF) {
+            // one 16-pixel block at a time (measured: the three blocks interleaved — 21 gathers first, six accumulator chains — is 2 % SLOWER, 0.282-0.284
+            // against 0.277-0.279 ms: it holds 20 more VGPRs live through the phase, and the co-resident workgroup fills the chain's gaps anyway)
+            const int kg = lane >> 4, pc = lane & 15;
+#pragma unroll 1
+            for (int bi = 0; bi < 3; bi++) {
+                const int blk = wave * 3 + bi;                            // 16-pixel block 0..11 of the region (pixels 180..191 do not exist)
+                const int q = 16 * blk + pc, p = min(q, CR * CC - 1);
+                const int r = (p * 3641) >> 16, c = p - r * CC;           // p / 18 for p < 192
+                const float *src = in_s + (2 * r) * PROW + 6 * c;
+                float xv[7];
+#pragma unroll
+                for (int t = 0; t < 7; t++) xv[t] = src[mcf_dl[t]];
+                if (kg == 3) xv[6] = 0.f;                                 // k = 27 does not exist (its weight is 0 too)
+                const int oy = TH * ty - 1 + r, ox = TW * tx - 1 + c;     // position of THIS lane's pixel in the conv1 map
+                const bool inside = oy >= 0 && oy < a.h && ox >= 0 && ox < a.h;
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    f4 acc = f4{ 0.f, 0.f, 0.f, 0.f };                    // same instruction, same k order as conv1_mfma_f32 (mbn_f32_misc.hip): same bits
+#pragma unroll
+                    for (int t = 0; t < 7; t++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(mcf_w[h][t], xv[t], acc, 0, 0, 0);
+                    const f4 v = inside ? bn_relu6(acc, mcf_s1[h], mcf_b1[h]) : f4{ 0.f, 0.f, 0.f, 0.f };   // outside: the depthwise zero padding
+                    if (q < CR * CC) *reinterpret_cast<f4 *>(c1_s + q * C1 + 16 * h + 4 * kg) = v;
+                }
+            }
+        } else
         if constexpr (MC) {
             typedef unsigned u4 __attribute__((ext_vector_type(4)));
             const int kg = lane >> 4, pc = lane & 15;
@@ -573,8 +624,8 @@ int mbn_launch_f32_stem(mbn_context *ctx, hipStream_t stream, float *out, const 
         else
 #endif
         if (bf16) hipLaunchKernelGGL((stem_fused_f32<32, 64, true, 3, true>), g, b, 0, stream, a);   // conv1 on the bf16 MFMA, three workgroups per CU
-        else if (g_mbn_tune.pw_emul == 6) hipLaunchKernelGGL((stem_fused_f32<32, 64, false, 2, false, 6>), g, b, 0, stream, a);   // opt-in split products in phase D
-        else if (g_mbn_tune.pw_emul == 9) hipLaunchKernelGGL((stem_fused_f32<32, 64, false, 2, false, 9>), g, b, 0, stream, a);
+        else if (g_mbn_tune.pw_emul == 6) hipLaunchKernelGGL((stem_fused_f32<32, 64, false, 2, true, 6>), g, b, 0, stream, a);   // opt-in split products in phase D
+        else if (g_mbn_tune.pw_emul == 9) hipLaunchKernelGGL((stem_fused_f32<32, 64, false, 2, true, 9>), g, b, 0, stream, a);
 #ifdef MBN_LAB
         // r3 A/B (profiles/r03/k_stem_three_workgroups.txt): the fp32 alpha = 1 stem at three workgroups per CU — filter fragments in 32 VGPRs instead of
         // the 8 KB LDS tile, taps in LDS, buffer stores: 52.7 KB, 156 VGPRs. SLOWER: 0.370 ms against 0.307 (that kernel on a 2-per-CU grid,
@@ -585,7 +636,11 @@ int mbn_launch_f32_stem(mbn_context *ctx, hipStream_t stream, float *out, const 
             hipLaunchKernelGGL((stem_fused_f32<32, 64, false, 3>), dim3((unsigned)g3), b, 0, stream, a);
         }
 #endif
-        else hipLaunchKernelGGL((stem_fused_f32<32, 64, false, 2>), g, b, 0, stream, a);
+#ifdef MBN_LAB
+        else if (g_mbn_tune.conv_variant == 5) hipLaunchKernelGGL((stem_fused_f32<32, 64, false, 2>), g, b, 0, stream, a);   // r4 A/B: conv1 on the VALU (round 3's form; timing only: its bits are the fmaf chain's, not conv1_mfma_f32's)
+#endif
+        // round 4: conv1 on v_mfma_f32_16x16x4_f32 (profiles/r04/f_stem_conv1_mfma.txt: 0.291-0.297 -> 0.277-0.279 ms at batch 256)
+        else hipLaunchKernelGGL((stem_fused_f32<32, 64, false, 2, true>), g, b, 0, stream, a);
     } else {
 #ifdef MBN_LAB
         if (bf16 && g_mbn_tune.conv_variant == 2) hipLaunchKernelGGL((stem_fused_f32<16, 32, true, 4>), g, b, 0, stream, a);     // conv1 on the VALU (A/B)

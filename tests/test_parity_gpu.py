@@ -352,8 +352,11 @@ def test_f32_pointwise_exact_integers(pkg, ctx):
     assert np.array_equal(got.astype(np.float64), want)
 
 
-@pytest.mark.parametrize("shape", [(2, 224, 32), (1, 160, 16), (2, 33, 8), (1, 64, 6)])
+@pytest.mark.parametrize("shape", [(2, 224, 32), (1, 160, 16), (2, 33, 8), (1, 64, 6), (3, 32, 32), (2, 96, 32), (1, 200, 32)])
 def test_f32_conv1(pkg, orc, ctx, shape):
+    """First layer (kernel.cl:2-60 in the mode the metric measures). Round 4: 32 output channels with an output width that is a multiple of 16
+    (224, 32, 96 here) run conv1_mfma_f32 — v_mfma_f32_16x16x4_f32, the fused stem's arithmetic — every other shape the fmaf-chain kernels
+    (200 -> 100 columns: the chain kernel at 32 channels); both within 1e-5 of the oracle's float64 sums."""
     n, h, cout = shape
     rng = np.random.default_rng(h + cout)
     x = rng.uniform(-1, 1, (n, h, h, 3)).astype(np.float32)
