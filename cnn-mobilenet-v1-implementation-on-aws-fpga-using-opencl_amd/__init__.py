@@ -19,7 +19,9 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(PKG_DIR)
 # MBN_LAB=1 in the environment selects the lab build (every A/B variant and mbn_tune_set knob: `make lab`); tools/*.py set it,
 # bench.py and the tests run the shipped library unless the caller exports it
-LIB_PATH = os.path.join(PKG_DIR, "libmbn_lab.so" if os.environ.get("MBN_LAB") == "1" else "libmbn.so")
+# (MBN_LAB=<file name>: another build of the lab library in the package directory — tools' A/B of two source states in one GPU call)
+_lab = os.environ.get("MBN_LAB", "")
+LIB_PATH = os.path.join(PKG_DIR, "libmbn_lab.so" if _lab == "1" else _lab if (_lab.startswith("libmbn") and _lab.endswith(".so")) else "libmbn.so")
 HOST_LIB_PATH = os.path.join(PKG_DIR, "libmbn_host.so")
 HEADER = os.path.join(REPO_ROOT, "include", "mbn.h")
 

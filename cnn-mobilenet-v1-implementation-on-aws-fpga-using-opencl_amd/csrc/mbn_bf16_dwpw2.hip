@@ -255,6 +255,34 @@ __global__ __launch_bounds__(NT) void dwpw2_bf16(DwPw2Args a)
                                                                       acc[mi][ni], 0, 0, 0);
         }
     };
+    // first MFMA group of a step; fresh (wave-uniform: the chunk is its tile's first): C = the inline-constant zero instead of zeroing the accumulators per tile
+    auto mfma_group_first = [&](int slot, bool fresh) __attribute__((always_inline)) {
+        if constexpr (M16) {
+            const f4 z4 = f4{ 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+            for (int i = 0; i < MI16; i++)
+#pragma unroll
+                for (int j = 0; j < NI16; j++) {
+                    if (fresh) acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, fa[slot][i]), __builtin_bit_cast(bf8, fb[slot][j]), z4, 0, 0, 0);
+                    else acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, fa[slot][i]), __builtin_bit_cast(bf8, fb[slot][j]), acc16[i][j], 0, 0, 0);
+                }
+        } else {
+            const f16v z = f16v{ 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
+            if (fresh) {
+#pragma unroll
+                for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ni++)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, fa[slot][mi]), __builtin_bit_cast(bf8, fb[slot][ni]), z, 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ni++)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, fa[slot][mi]), __builtin_bit_cast(bf8, fb[slot][ni]), acc[mi][ni], 0, 0, 0);
+            }
+        }
+    };
     auto zero_acc = [&]() __attribute__((always_inline)) {
         if constexpr (M16) {
 #pragma unroll
@@ -325,14 +353,14 @@ __global__ __launch_bounds__(NT) void dwpw2_bf16(DwPw2Args a)
             if (LATEFRAG) ldfrag(P, 0, 0);                                                                              \
             ldfrag(P, 1, 1);                                                                                            \
             __builtin_amdgcn_sched_barrier(0);                                                                          \
-            mfma_group(0);                                                                                              \
+            mfma_group_first(0, kM == 0);                                                                               \
             __builtin_amdgcn_sched_barrier(0);                                                                          \
             mfma_group(1);                                                                                              \
         } else {                                                                                                        \
         _Pragma("unroll") for (int g = 0; g < 3; g++) {                                                                 \
             ldfrag(P, g + 1, (g + 1) & 1);                                                                              \
             __builtin_amdgcn_sched_barrier(0);                                                                          \
-            mfma_group(g & 1);                                                                                          \
+            if (g == 0) mfma_group_first(0, kM == 0); else mfma_group(g & 1);                                           \
             __builtin_amdgcn_sched_barrier(0);                                                                          \
         }                                                                                                               \
         mfma_group(1);                                                                                                  \
@@ -348,7 +376,6 @@ __global__ __launch_bounds__(NT) void dwpw2_bf16(DwPw2Args a)
             if (m0M + BM <= mtot) mbn_store_relu6_bf16_pair<MI, NI, 0>(orsrc, (unsigned)a.cout, m0M + wm, n0M + wn, lane, acc, sc3_s, sh3_s); \
             else mbn_store_relu6_bf16_pair<MI, NI, 1>(orsrc, (unsigned)a.cout, m0M + wm, n0M + wn, lane, acc, sc3_s, sh3_s);               \
             }                                                                                                           \
-            zero_acc();                                                                                                 \
         }                                                                                                               \
         if (!validD) break;                                                                                             \
         vbM = vbD; kM = kD; m0M = m0D; n0M = n0D;                                                                       \
