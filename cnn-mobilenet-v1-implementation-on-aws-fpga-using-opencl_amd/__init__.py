@@ -187,6 +187,7 @@ def load():
         lib.mbn_pool_fc_workspace_bytes.argtypes = [ci, ci]
         lib.mbn_pool_fc_workspace_bytes.restype = C.c_size_t
         lib.mbn_pool_fc.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, C.c_size_t, vp]
+        lib.mbn_classifier_tail_fused.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, C.c_size_t, vp]
         lib.mbn_forget.argtypes = [vp, vp, C.c_size_t]
         lib.mbn_net_classify.argtypes = [vp, vp, ci, ci, vp, vp]
         lib.mbn_net_launches.argtypes = [vp, ci, ci, C.POINTER(ci), C.POINTER(ci), ci, C.POINTER(ci)]

@@ -739,7 +739,26 @@ int mbn_pool_fc(mbn_context *ctx, void *logits, const void *in, const void *fc_w
               { fc_w, 4.0 * classes * channels, "pool_fc filter" }, { workspace, (double)mbn_pool_fc_ws_bytes(channels, classes), "pool_fc workspace" });
     Scope sc(ctx, s);
     return sc.finish(mbn_launch_f32_pool_fc(ctx, s, (float *)logits, (const float *)in, (const float *)fc_w, (const float *)fc_bias, workspace,
-                                            batch, rows * cols, channels, classes));
+                                            batch, rows * cols, channels, classes, 0, nullptr, nullptr, nullptr));
+}
+
+int mbn_classifier_tail_fused(mbn_context *ctx, void *topk_idx_i32, void *topk_prob_f32, void *probs, void *logits, const void *in, const void *fc_w,
+                              const void *fc_bias, int batch, int rows, int cols, int channels, int classes, int k, void *workspace,
+                              size_t workspace_bytes, void *stream)
+{
+    if (!ctx || !topk_idx_i32 || !topk_prob_f32 || !logits || !in || !fc_w || !workspace || batch <= 0 || rows <= 0 || cols <= 0 || channels <= 0 ||
+        classes <= 0 || k < 1 || k > 8)
+        return MBN_EINVAL;
+    if (batch > 4 || channels < 64 || channels > 1024 || (channels % 64) != 0 || classes > 1024) return MBN_EUNSUPPORTED;
+    if (workspace_bytes < mbn_pool_fc_ws_bytes(channels, classes)) return MBN_EINVAL;
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    MBN_SPANS(ctx, { in, 4.0 * batch * rows * cols * channels, "classifier_tail_fused input" }, { logits, 4.0 * batch * classes, "classifier_tail_fused logits" },
+              { fc_w, 4.0 * classes * channels, "classifier_tail_fused filter" }, { workspace, (double)mbn_pool_fc_ws_bytes(channels, classes), "classifier_tail_fused workspace" },
+              { probs, 4.0 * batch * classes, "classifier_tail_fused probs" }, { topk_idx_i32, 4.0 * batch * k, "classifier_tail_fused idx" },
+              { topk_prob_f32, 4.0 * batch * k, "classifier_tail_fused prob" });
+    Scope sc(ctx, s);
+    return sc.finish(mbn_launch_f32_pool_fc(ctx, s, (float *)logits, (const float *)in, (const float *)fc_w, (const float *)fc_bias, workspace,
+                                            batch, rows * cols, channels, classes, k, (float *)probs, (int32_t *)topk_idx_i32, (float *)topk_prob_f32));
 }
 
 static int stem_fused_impl(mbn_context *ctx, void *out, const void *image, const void *w1, const void *s1, const void *b1,

@@ -303,9 +303,19 @@ struct PoolFcArgs {
     const float *in;         // [batch][pix][ch]
     const float *w, *bias;   // [classes][ch], [classes] or null
     float *ws;               // [nks][4][classes] partial sums
-    unsigned *cnt;           // [nns] arrival counters, zero between launches
+    unsigned *cnt;           // [nns <= 64] arrival counters + [64] the range counter of the one-launch tail, zero between launches
     int batch, pix, ch, classes, nks, nns, npc;
+    // k > 0: the whole classifier tail in this launch (MobileNet.c:2601-2792; SURVEY 8f-3 as written): the LAST class range to finish
+    // (a second counter, cnt[64]) reads the complete logits back into LDS and runs softmax + top-k for every image
+    int k;
+    float *probs;            // [batch][classes] or null
+    int *topk_idx;           // [batch][k]
+    float *topk_prob;        // [batch][k]
 };
+constexpr int TAIL_CLASSES_MAX = 1024;      // one image's logits in LDS (4 KB)
+
+__device__ __forceinline__ void softmax_topk_wave(float *__restrict__ probs, int *__restrict__ topk_idx, float *__restrict__ topk_prob,
+                                                  const float *l, long n, int classes, int k);
 
 __global__ __launch_bounds__(256) void poolfc_f32(PoolFcArgs a)
 {
@@ -373,9 +383,28 @@ __global__ __launch_bounds__(256) void poolfc_f32(PoolFcArgs a)
         float v = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; k++) v += k < a.nks ? pt[k] : 0.f;
-        a.out[(long)b * a.classes + n] = v + (a.bias ? a.bias[n] : 0.f);
+        const float lg = v + (a.bias ? a.bias[n] : 0.f);
+        // with the tail in this launch the logits are read back by another workgroup (possibly on another XCD): agent-scope stores, like the partials
+        if (a.k > 0) __hip_atomic_store(a.out + (long)b * a.classes + n, lg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else a.out[(long)b * a.classes + n] = lg;
     }
     if (tid == 0) __hip_atomic_store(a.cnt + ns, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch on this workspace (stream order)
+    if (a.k <= 0) return;
+    // ---- second hand-over: this range's logits are acknowledged (explicit vmcnt(0) in every wave, then the barrier) before it is counted as done;
+    // the range that counts nns - 1 is the last one and owns the softmax + top-k of every image
+    __shared__ float s_logits[4][TAIL_CLASSES_MAX];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) s_last = __hip_atomic_fetch_add(a.cnt + 64, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_last != (unsigned)a.nns - 1u) return;
+    for (int i = tid; i < a.batch * a.classes; i += 256)
+        s_logits[i / a.classes][i % a.classes] = __hip_atomic_load(a.out + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_store(a.cnt + 64, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    // one WAVE per image (the images side by side instead of one after the other: 18 / 27 / 45 us for 1 / 2 / 4 images with the block form, measured)
+    const int wv = tid >> 6;
+    if (wv < a.batch) softmax_topk_wave(a.probs, a.topk_idx, a.topk_prob, s_logits[wv], wv, a.classes, a.k);
 }
 
 // softmax + argmax: one 256-lane workgroup per image; wave shuffles then a 4-entry LDS combine.
@@ -418,14 +447,11 @@ __global__ __launch_bounds__(256) void softmax_f32(float *__restrict__ probs, in
 // over the logits in the total order (value descending, index ascending) — pass j only admits entries strictly after
 // pass j-1's winner in that order, so ties resolve to the lowest index like the oracle's strict '>' scan and no
 // "taken" list is needed. probs (may be NULL) gets the full distribution; topk_prob the winners' probabilities.
-__global__ __launch_bounds__(256) void softmax_topk_f32(float *__restrict__ probs, int *__restrict__ topk_idx,
-                                                        float *__restrict__ topk_prob, const float *__restrict__ logits,
-                                                        int classes, int k)
+// One image by one 256-lane workgroup; `l` may point to global memory or to an LDS copy of the image's logits (the one-launch classifier tail).
+__device__ __forceinline__ void softmax_topk_block(float *__restrict__ probs, int *__restrict__ topk_idx, float *__restrict__ topk_prob,
+                                                   const float *l, long n, int classes, int k, float *s_val, int *s_idx)
 {
-    __shared__ float s_val[4];
-    __shared__ int s_idx[4];
-    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float *l = logits + (long)n * classes;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float pv = INFINITY, mx = 0.f, sum = 0.f;     // previous winner (value, index); +inf admits everything
     int pi = -1;
     for (int j = 0; j < k; j++) {
@@ -465,6 +491,69 @@ __global__ __launch_bounds__(256) void softmax_topk_f32(float *__restrict__ prob
         }
         pv = bv; pi = bi;
     }
+}
+
+// The same result by ONE wave, bit for bit: lane L plays lanes L of the block form's four waves — four partial sums per lane over the classes
+// c = 64 w + L + 256 j in the same order, each reduced by the same xor tree, added left to right — and the winners come from a total order, which
+// no summation order can change. `l` is an LDS copy of the image's logits. No workgroup barrier: the images of a call run side by side, one per wave.
+__device__ __forceinline__ void softmax_topk_wave(float *__restrict__ probs, int *__restrict__ topk_idx, float *__restrict__ topk_prob,
+                                                  const float *l, long n, int classes, int k)
+{
+    // the lane's classes c = lane + 64 i (i < 16: classes <= TAIL_CLASSES_MAX) live in registers: the k ranking passes and the softmax are then
+    // straight-line VALU (with the logits re-read from LDS in every pass a wave took 16 us per image: one dependent LDS round trip per class and pass)
+    constexpr int PL = TAIL_CLASSES_MAX / 64;
+    const int lane = threadIdx.x & 63;
+    float v[PL];
+#pragma unroll
+    for (int i = 0; i < PL; i++) v[i] = lane + 64 * i < classes ? l[lane + 64 * i] : -INFINITY;
+    float pv = INFINITY, mx = 0.f, sum = 0.f;
+    int pi = -1;
+    for (int j = 0; j < k; j++) {
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int i = 0; i < PL; i++) {
+            const int c = lane + 64 * i;
+            const bool admitted = c < classes && (v[i] < pv || (v[i] == pv && c > pi));
+            if (admitted && (v[i] > bv || (v[i] == bv && c < bi))) { bv = v[i]; bi = c; }
+        }
+        for (int d = 32; d >= 1; d >>= 1) {
+            const float ov = __shfl_xor(bv, d, 64);
+            const int oi = __shfl_xor(bi, d, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (j == 0) {
+            mx = bv;
+            float ps[4] = { 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+            for (int i = 0; i < PL; i++)                                   // class 64 i + lane = 64 (i & 3) + lane + 256 (i >> 2): wave i & 3, trip i >> 2 of the block form
+                if (lane + 64 * i < classes) ps[i & 3] += expf(v[i] - mx);
+#pragma unroll
+            for (int w = 0; w < 4; w++)
+                for (int d = 32; d >= 1; d >>= 1) ps[w] += __shfl_xor(ps[w], d, 64);
+            sum = ps[0] + ps[1] + ps[2] + ps[3];
+            if (probs) {
+#pragma unroll
+                for (int i = 0; i < PL; i++)
+                    if (lane + 64 * i < classes) probs[n * classes + lane + 64 * i] = expf(v[i] - mx) / sum;
+            }
+        }
+        if (lane == 0) {
+            const bool found = bi != 0x7fffffff;   // fewer than k classes
+            topk_idx[n * k + j] = found ? bi : -1;
+            topk_prob[n * k + j] = found ? expf(bv - mx) / sum : 0.f;
+        }
+        pv = bv; pi = bi;
+    }
+}
+
+__global__ __launch_bounds__(256) void softmax_topk_f32(float *__restrict__ probs, int *__restrict__ topk_idx,
+                                                        float *__restrict__ topk_prob, const float *__restrict__ logits,
+                                                        int classes, int k)
+{
+    __shared__ float s_val[4];
+    __shared__ int s_idx[4];
+    softmax_topk_block(probs, topk_idx, topk_prob, logits + (long)blockIdx.x * classes, blockIdx.x, classes, k, s_val, s_idx);
 }
 
 __global__ __launch_bounds__(256) void normalize_u8_f32(float *__restrict__ out, const uint8_t *__restrict__ in,
@@ -574,21 +663,24 @@ int mbn_launch_f32_pool(const mbn_call &c, void *out, const void *in, int rows, 
     return MBN_OK;
 }
 
-// workspace: [ch/64][4][classes] floats + 64 counters (256 bytes, at the front); zeroed once by the caller
+// workspace: 64 range-arrival counters + the tail's counter (512 bytes at the front), then [ch/64][4][classes] floats; zeroed once by the caller
 size_t mbn_pool_fc_ws_bytes(int channels, int classes)
 {
-    return 256 + (size_t)(channels / 64) * 4 * (size_t)classes * sizeof(float);
+    return 512 + (size_t)(channels / 64) * 4 * (size_t)classes * sizeof(float);
 }
 
+// k > 0: softmax + top-k of every image in the same launch (probs may be null); k = 0: pool + FC only
 int mbn_launch_f32_pool_fc(mbn_context *ctx, hipStream_t s, float *out, const float *in, const float *w, const float *bias, void *ws,
-                           int batch, int pix, int channels, int classes)
+                           int batch, int pix, int channels, int classes, int k, float *probs, int32_t *topk_idx, float *topk_prob)
 {
     if (batch < 1 || batch > 4 || channels < 64 || channels > 1024 || (channels % 64) != 0 || pix <= 0 || classes <= 0) return MBN_EUNSUPPORTED;
     if (((uintptr_t)w % 16) != 0 || ((uintptr_t)ws % 16) != 0) return MBN_EUNSUPPORTED;
+    if (k < 0 || k > 8 || (k > 0 && (classes > TAIL_CLASSES_MAX || !topk_idx || !topk_prob))) return k > 0 && classes > TAIL_CLASSES_MAX ? MBN_EUNSUPPORTED : MBN_EINVAL;
     PoolFcArgs a;
     a.out = out; a.in = in; a.w = w; a.bias = bias;
+    a.k = k; a.probs = probs; a.topk_idx = (int *)topk_idx; a.topk_prob = topk_prob;
     a.cnt = (unsigned *)ws;
-    a.ws = (float *)((char *)ws + 256);
+    a.ws = (float *)((char *)ws + 512);
     a.batch = batch; a.pix = pix; a.ch = channels; a.classes = classes;
     a.nks = channels / 64;
     // class ranges: enough workgroups for every CU to hold one (the filter slice of a workgroup is npc x 256 bytes), at most 64 ranges

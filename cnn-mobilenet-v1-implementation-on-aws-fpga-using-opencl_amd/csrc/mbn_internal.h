@@ -145,7 +145,7 @@ int mbn_launch_bf16_pw_big(const mbn_call &c, void *out, const void *in, const v
 int mbn_launch_f32_pool(const mbn_call &c, void *out, const void *in, int rows, int cols, int fs, int channels);
 size_t mbn_pool_fc_ws_bytes(int channels, int classes);
 int mbn_launch_f32_pool_fc(mbn_context *ctx, hipStream_t s, float *out, const float *in, const float *w, const float *bias, void *ws,
-                           int batch, int pix, int channels, int classes);
+                           int batch, int pix, int channels, int classes, int k, float *probs, int32_t *topk_idx, float *topk_prob);
 // floor(v / d) == umulhi(v, *m) >> *s for every v < 2^31 (d >= 2); d == 1 gives *m = 0 (callers skip the multiply)
 static inline void mbn_udiv_magic(unsigned d, unsigned *m, unsigned *s)
 {

@@ -310,6 +310,16 @@ int mbn_classifier_tail(mbn_context *ctx, void *topk_idx_i32, void *topk_prob_f3
 size_t mbn_pool_fc_workspace_bytes(int channels, int classes);
 int mbn_pool_fc(mbn_context *ctx, void *logits, const void *in, const void *fc_w, const void *fc_bias, int batch, int rows, int cols,
                 int channels, int classes, void *workspace, size_t workspace_bytes, void *stream);
+/* The WHOLE classifier tail as ONE launch for 1...4 images (SURVEY 8f-3 as written; MobileNet.c:2601-2792: the `pool` launch, the FC
+ * `pointwise` launch with its blocking read-back of 1000 logits, the host softmax loop :2771-2779 and the host arg-max :2781-2792): global
+ * average pool -> FC + bias -> softmax -> top-k, results identical to mbn_pool_fc followed by mbn_softmax_topk_f32 bit for bit. The class
+ * range that finishes last (a second arrival counter in the workspace) reads the complete logits back and normalises / ranks them. Same
+ * workspace and envelope as mbn_pool_fc, plus classes <= 1024; `logits` [batch][classes] stay readable, `probs` may be NULL.
+ * Measured on MI355X (profiles/r04/h_classifier_tail_one_launch.txt): see there — at 1...4 images the tail is launch-latency bound and the
+ * one launch is offered as an option, not taken by default. */
+int mbn_classifier_tail_fused(mbn_context *ctx, void *topk_idx_i32, void *topk_prob_f32, void *probs, void *logits, const void *in, const void *fc_w,
+                              const void *fc_bias, int batch, int rows, int cols, int channels, int classes, int k, void *workspace,
+                              size_t workspace_bytes, void *stream);
 
 /* Input front-end on device: uint8 HWC [N][rows][cols][3] -> fp32 NHWC x*scale+bias
  * (Keras MobileNet preprocessing is scale=1/127.5, bias=-1). */

@@ -1182,7 +1182,7 @@ def test_pool_fc_one_launch(pkg, orc, ctx, shape):
     b = rng.normal(0, 0.5, classes).astype(np.float32)
     ref = orc.f32_pointwise(orc.f32_pool(x).reshape(n, ch), w, None, b, 0)
     nb = ctx.lib.mbn_pool_fc_workspace_bytes(ch, classes)
-    assert nb >= 256 + (ch // 64) * 4 * classes * 4
+    assert nb >= 512 + (ch // 64) * 4 * classes * 4
     d_x, d_w, d_b, d_o, d_ws = ctx.to_device(x), ctx.to_device(w), ctx.to_device(b), ctx.alloc(n * classes * 4 + 64), ctx.alloc(nb)
     ctx.lib.mbn_memset(ctx.h, d_ws.ptr, 0, nb)
     ctx.lib.mbn_memset(ctx.h, d_o.ptr, 0xFF, n * classes * 4 + 64)
@@ -1195,9 +1195,34 @@ def test_pool_fc_one_launch(pkg, orc, ctx, shape):
     assert np.all(d_o.download((n * classes + 16,), np.uint32)[n * classes:] == 0xFFFFFFFF), "stores past the output"
     assert_close(got, ref, TOL_PW, "pool_fc %s vs oracle" % (shape,))
     assert np.array_equal(got, run(n)), "not repeatable on the same workspace"
-    assert np.all(d_ws.download((64,), np.uint32) == 0), "arrival counters not back to zero"
+    assert np.all(d_ws.download((128,), np.uint32) == 0), "arrival counters not back to zero"
     for k in range(1, n):
         assert np.array_equal(run(k), got[:k]), "logits depend on the batch (%d of %d)" % (k, n)
+    # the WHOLE tail in one launch (round 4, mbn_classifier_tail_fused: + softmax + top-k by the last class range to finish): logits, probabilities
+    # and winners bit for bit those of mbn_pool_fc + mbn_softmax_topk_f32, against the oracle's softmax, repeatable, counters back to zero
+    if classes <= 1024:
+        kk = min(5, classes)
+        d_p, d_i, d_v = ctx.alloc(n * classes * 4), ctx.alloc(n * 8 * 4), ctx.alloc(n * 8 * 4)
+        d_p2, d_i2, d_v2, d_o2 = ctx.alloc(n * classes * 4), ctx.alloc(n * 8 * 4), ctx.alloc(n * 8 * 4), ctx.alloc(n * classes * 4)
+        assert ctx.lib.mbn_softmax_topk_f32(ctx.h, d_p.ptr, d_i.ptr, d_v.ptr, d_o.ptr, n, classes, kk, None) == 0
+        for rep in range(2):
+            assert ctx.lib.mbn_classifier_tail_fused(ctx.h, d_i2.ptr, d_v2.ptr, d_p2.ptr, d_o2.ptr, d_x.ptr, d_w.ptr, d_b.ptr, n, h, h, ch, classes, kk,
+                                                     d_ws.ptr, nb, None) == 0
+            ctx.sync()
+            assert np.array_equal(d_o2.download((n, classes), np.float32), got), "one-launch tail: logits"
+            assert np.array_equal(d_i2.download((n, kk), np.int32), d_i.download((n, kk), np.int32)), "one-launch tail: winners"
+            assert np.array_equal(d_v2.download((n, kk), np.float32), d_v.download((n, kk), np.float32)), "one-launch tail: winners' probabilities"
+            assert np.array_equal(d_p2.download((n, classes), np.float32), d_p.download((n, classes), np.float32)), "one-launch tail: distribution"
+            assert np.all(d_ws.download((128,), np.uint32) == 0), "arrival counters not back to zero"
+        e = np.exp(ref.astype(np.float64) - ref.max(1, keepdims=True))
+        assert_close(d_p2.download((n, classes), np.float32), e / e.sum(1, keepdims=True), 1e-4, "one-launch tail vs float64 softmax")
+        assert np.array_equal(d_i2.download((n, kk), np.int32)[:, 0], ref.argmax(1))
+        assert ctx.lib.mbn_classifier_tail_fused(ctx.h, d_i2.ptr, d_v2.ptr, None, d_o2.ptr, d_x.ptr, d_w.ptr, None, 1, h, h, ch, classes, 1, d_ws.ptr, nb, None) == 0
+        assert ctx.lib.mbn_classifier_tail_fused(ctx.h, d_i2.ptr, d_v2.ptr, None, d_o2.ptr, d_x.ptr, d_w.ptr, None, 5, h, h, ch, classes, 1, d_ws.ptr, nb, None) == pkg.EUNSUPPORTED
+        assert ctx.lib.mbn_classifier_tail_fused(ctx.h, d_i2.ptr, d_v2.ptr, None, d_o2.ptr, d_x.ptr, d_w.ptr, None, 1, h, h, ch, classes, 9, d_ws.ptr, nb, None) == pkg.EINVAL
+        ctx.sync()
+        for bfr in (d_p, d_i, d_v, d_p2, d_i2, d_v2, d_o2):
+            bfr.free()
     assert_close(run(n, None), ref - b, TOL_PW, "no bias")
     xi = rng.integers(0, 4, (n, h, h, ch)).astype(np.float32)
     xi[:, 1:] = xi[:, :1]                                        # every row equal: the pooled value is the exact integer mean over columns
