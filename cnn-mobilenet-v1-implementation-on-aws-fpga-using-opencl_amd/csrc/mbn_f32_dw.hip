@@ -824,6 +824,13 @@ int launch_dw(const mbn_call &c, DwArgs &a, int rows, int cols, int fs, int stri
         if (row_lanes * max_seg < (long)c.ctx->num_cus * 64 || cache_resident) max_seg = rows;
         if (nseg > max_seg) nseg = max_seg;
     }
+    // Round 4 (profiles/r04/i_depthwise_stride2_segments.txt): stride 2 on an input of streaming size (>= 512 MB: layer 4 from batch 256 up, 822 MB) runs 5-10 % faster
+    // with TWO output rows per segment although a full-height march already fills the chip — 0.1988 -> 0.1861 ms at batch 256, 0.4194 -> 0.3772 at 512,
+    // 0.2148 -> 0.1923 at 320 x 320 / 128 images — and 1-20 % slower below that size (411 MB at batch 128: +1 %; cache-sized inputs: +10-20 %): a lane's
+    // 56-row march is one dependent HBM round trip per row, and the row a segment re-reads was fetched by its neighbour microseconds earlier.
+    if (g_mbn_tune.dw_nseg <= 0 && sizeof(T) == 4 && stride == 2 && rows >= 8 &&
+        (double)c.batch * a.in_rows * a.in_cols * channels * sizeof(T) >= 512.0 * 1048576)
+        nseg = rows / 2;
     if (nseg > rows) nseg = rows;
     a.seg_rows = (rows + nseg - 1) / nseg;
     a.nseg = (rows + a.seg_rows - 1) / a.seg_rows;
