@@ -78,7 +78,7 @@ static std::atomic<int> *tune_slot(const char *key, bool *lab_only)
     if (!strcmp(key, "pw_emul_static")) return &g_mbn_tune.pw_emul_static;
     if (!strcmp(key, "lit_dot")) return &g_mbn_tune.lit_dot;
     static const char *const lab_keys[] = { "dw_variant", "dw_nseg", "pw_stage", "conv_variant", "misc", "pw_ring", "pw_xn", "dwpw_variant",
-                                            "exp0", "exp1", "exp2" };
+                                            "exp0", "exp1", "exp2", "cu_mask" };
     for (const char *k : lab_keys)
         if (!strcmp(key, k)) *lab_only = true;
 #ifdef MBN_LAB
@@ -93,6 +93,7 @@ static std::atomic<int> *tune_slot(const char *key, bool *lab_only)
     if (!strcmp(key, "exp0")) return &g_mbn_tune.exp0;
     if (!strcmp(key, "exp1")) return &g_mbn_tune.exp1;
     if (!strcmp(key, "exp2")) return &g_mbn_tune.exp2;
+    if (!strcmp(key, "cu_mask")) return &g_mbn_tune.cu_mask;
 #endif
     return nullptr;
 }
@@ -215,6 +216,26 @@ int mbn_stream_create(mbn_context *ctx, void **stream)
     if (!ctx || !stream) return MBN_EINVAL;
     (void)hipSetDevice(ctx->device);
     hipStream_t s;
+    const int cm = g_mbn_tune.cu_mask;
+    if (cm == 1 || cm == 2) {
+        // LAB experiment (round 4, profiles/r04/j_streams_cu_mask.txt: XCD halves equal to the shared chip within 0.2 %, halves of every XCD -2.3 %): sub-batch streams confined to disjoint halves of the chip, so that one stream's HBM-bound kernels run beside the
+        // other's MFMA-bound ones instead of time-slicing the same CUs. CU-mask bit i is CU i / 8 of XCD i % 8 (the driver deals the bits round the XCDs)
+        static std::atomic<int> seq{0};
+        const int half = seq.fetch_add(1) & 1;
+        uint32_t mask[8];
+        for (int w = 0; w < 8; w++) {
+            uint32_t m = 0;
+            for (int b = 0; b < 32; b++) {
+                const int i = 32 * w + b;
+                const bool mine = cm == 1 ? ((i & 7) < 4) == (half == 0) : (i < 128) == (half == 0);
+                if (mine) m |= 1u << b;
+            }
+            mask[w] = m;
+        }
+        MBN_HIP_TRY(ctx, hipExtStreamCreateWithCUMask(&s, 8, mask));
+        *stream = (void *)s;
+        return MBN_OK;
+    }
     MBN_HIP_TRY(ctx, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     *stream = (void *)s;
     return MBN_OK;
