@@ -388,11 +388,15 @@ __global__ __launch_bounds__(64 * NW) void dwpw2_f32(DwPw2Args a)
         }                                                                                                               \
         const bool spreadL = validL && !(dbg & 1) && !(dbg & 128) && !(dbg & 16);                                 \
         const bool didE = pendE && paired && !(dbg & 4);       /* exactly NST stores are in flight behind the DMA */      \
+        /* the counted waits below (vmcnt(NX + NST)) are right only if the NST stores are YOUNGER than this step's filter DMA and older than */ \
+        /* its x loads in the instruction stream: pin the order (tools/check_counted_waits.py reads the ISA) */                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
         if (pendE) {                                                                                                    \
             if (!(dbg & 4)) epilogue(m0E, n0E);                                                                       \
             zero_acc();                                                                                                 \
             pendE = false;                                                                                              \
         }                                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
         __builtin_amdgcn_s_setprio(0);                                                                                  \
         STAMP(2);                                                                                                       \
         if (!(dbg & 16)) {                                                                                            \
@@ -442,11 +446,13 @@ __global__ __launch_bounds__(64 * NW) void dwpw2_f32(DwPw2Args a)
             }                                                                                                           \
         }                                                                                                               \
         const bool didE = pendE;                               /* exactly NST stores are in flight behind the DMA */      \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
         if (pendE) {                                                                                                    \
             epilogue(m0E, n0E);                                                                                         \
             zero_acc();                                                                                                 \
             pendE = false;                                                                                              \
         }                                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
         __builtin_amdgcn_s_setprio(0);                                                                                  \
         _Pragma("unroll") for (int g = 0; g < 3; g++) {                                                                 \
             ldfrag(P, g + 1, (g + 1) & 1);                                                                              \

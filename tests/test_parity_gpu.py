@@ -2396,6 +2396,9 @@ def test_bench_self_launches_its_ranks(pkg):
     assert len(lines) == 1                                              # ONE line, rank 0's
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 32 and out["value"] > 0 and out["parity_check"]["ok"]
+    # the record stays self-sufficient for a reader that keeps only `roofline`: per-stage fractions inside it
+    sf = out["roofline"]["stages_frac"]
+    assert "pointwise" in sf and all(k in sf["pointwise"] for k in ("ms", "launches", "frac_hbm", "frac_mfma"))
     import torch
     if torch.cuda.device_count() < 2:
         r = subprocess.run([sys.executable, os.path.join(pkg.REPO_ROOT, "bench.py"), "--gpus", "2", "--steps", "2"], env=env,
