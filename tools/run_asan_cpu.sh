@@ -6,7 +6,7 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 P="$R/cnn-mobilenet-v1-implementation-on-aws-fpga-using-opencl_amd"
 gcc -O1 -g -std=c11 -fPIC -fsanitize=address,undefined -fno-omit-frame-pointer -I"$R/include" -D_GNU_SOURCE -shared \
     -o /tmp/libmbn_host_asan.so "$P"/host/mbn_status.c "$P"/host/mbn_loaders.c "$P"/host/mbn_plan.c "$P"/host/mbn_h5.c \
-    "$P"/host/mbn_weights.c -lm
+    "$P"/host/mbn_weights.c "$P"/host/mbn_ranks.c -lm -lpthread
 make -C "$R/oracle" asan > /dev/null
 cp "$P/libmbn_host.so" /tmp/libmbn_host_plain.so; cp "$R/oracle/libmbn_oracle.so" /tmp/libmbn_oracle_plain.so
 trap 'cp /tmp/libmbn_host_plain.so "$P/libmbn_host.so"; cp /tmp/libmbn_oracle_plain.so "$R/oracle/libmbn_oracle.so"; rm -f "$R/oracle/libmbn_oracle_asan.so"' EXIT
