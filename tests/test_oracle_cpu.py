@@ -37,9 +37,9 @@ def test_kat_from_kernel_cl(orc, case):
             x = np.array(case["input"], np.uint8)
         got = orc.lit_pool(x, rows, cols, fs, oc, quirks=q)
     else:
-        g = np.full(rows * cols, case["input_g_fill"], np.uint8)
-        b = np.full(rows * cols, case["input_b_fill"], np.uint8)
-        f = np.full(oc * 27, case["filter_fill"], np.int32)
+        g = np.array(case["input_g"], np.uint8) if "input_g" in case else np.full(rows * cols, case["input_g_fill"], np.uint8)
+        b = np.array(case["input_b"], np.uint8) if "input_b" in case else np.full(rows * cols, case["input_b_fill"], np.uint8)
+        f = np.array(case["filter"], np.int32) if "filter" in case else np.full(oc * 27, case["filter_fill"], np.int32)
         got = orc.lit_convolute(case["input_r"], g, b, f, rows, cols, fs, case["stride"], oc, quirks=q)
     assert list(got) == case["expected"], case["why"]
 

@@ -161,6 +161,45 @@ def test_literal_pool(pkg, orc, ctx, quirks, shape):
     assert np.array_equal(d_o.download((ch,), np.uint8), want)
 
 
+def _kat_cases():
+    import json
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kat_literal.json")))["cases"]
+
+
+@pytest.mark.parametrize("case", _kat_cases(), ids=lambda c: c["name"])
+def test_literal_device_kernels_against_hand_derived_kats(pkg, ctx, case):
+    """Round 4: the hand-derived known-answer vectors (tests/golden/kat_literal.json: worked out from the text of kernel.cl:2-132, each with its
+    derivation) run straight through the DEVICE LITERAL kernels by the C-ABI — no oracle in between. The oracle and csrc/mbn_literal.hip are two
+    writings of one reading of kernel.cl; these 23 cases are the check of the device code that does not share that reading's code."""
+    k, q = case["kernel"], case["quirks"]
+    rows, cols, fs, oc = case["rows"], case["cols"], case["filtersize"], case["op_size"]
+    ext = pkg.make_ext(dtype=pkg.DT_U8, quirks=q)
+    want = np.array(case["expected"], np.uint8)
+    if k == "depthwise":
+        x, f = np.array(case["input"], np.uint8), np.array(case["filter"], np.int32)
+        d_x, d_f, d_o = ctx.to_device(x), ctx.to_device(f), ctx.alloc(max(want.size, 4))
+        ctx.depthwise(d_o.ptr, d_x.ptr, d_f.ptr, rows, cols, fs, case["stride"], oc, ext)
+    elif k == "pointwise":
+        x, f = np.array(case["input"], np.uint8), np.array(case["filter"], np.int32)
+        d_x, d_f, d_o = ctx.to_device(x), ctx.to_device(f), ctx.alloc(max(want.size, 4))
+        ctx.pointwise(d_o.ptr, d_x.ptr, d_f.ptr, rows, cols, fs, oc, ext)
+    elif k == "pool":
+        x = (np.concatenate([np.full(rows * cols, v, np.uint8) for v in case["input_fill"]]) if "input_fill" in case
+             else np.array(case["input"], np.uint8))
+        d_x, d_o = ctx.to_device(x), ctx.alloc(max(want.size, 4))
+        ctx.pool(d_o.ptr, d_x.ptr, rows, cols, fs, oc, ext)
+    else:
+        r = np.array(case["input_r"], np.uint8)
+        g = np.array(case["input_g"], np.uint8) if "input_g" in case else np.full(rows * cols, case["input_g_fill"], np.uint8)
+        b = np.array(case["input_b"], np.uint8) if "input_b" in case else np.full(rows * cols, case["input_b_fill"], np.uint8)
+        f = np.array(case["filter"], np.int32) if "filter" in case else np.full(oc * 27, case["filter_fill"], np.int32)
+        d = [ctx.to_device(a) for a in (r, g, b, f)]
+        d_o = ctx.alloc(max(want.size, 4))
+        ctx.convolute(d_o.ptr, d[0].ptr, d[1].ptr, d[2].ptr, d[3].ptr, rows, cols, fs, case["stride"], oc, ext)
+    ctx.sync()
+    assert list(d_o.download((want.size,), np.uint8)) == case["expected"], case["why"]
+
+
 def test_literal_truncation_and_wrap(pkg, orc, ctx):
     """int -> uchar store truncates mod 256 (kernel.cl:112) and int32 products wrap."""
     x = np.full((1, 2, 2), 200, np.uint8)
