@@ -9,6 +9,7 @@
 // it, a single-GPU caller never touches it, and a process that already holds a copy (PyTorch ships one) reuses that copy.
 #include "mbn_internal.h"
 
+#include <cstdlib>
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
@@ -69,7 +70,10 @@ int mbn_dist_init(int n_gpus, const int *device_ordinals, mbn_dist **out)
         if (rc != MBN_OK) { mbn_dist_shutdown(d); return rc; }
         d->ctx.push_back(c);
     }
-    if (n_gpus > 1) {                                                        // a single GPU needs no communicator
+    // a single GPU needs no communicator — unless MBN_DIST_FORCE_RCCL=1 asks for one anyway (round 4 rehearsal on the one-GPU boxes: dlopen, symbol
+    // binding, ncclCommInitAll, the grouped ncclBroadcast on the context's stream and the teardown all run for real, only the xGMI transfer does not)
+    const char *force = getenv("MBN_DIST_FORCE_RCCL");
+    if (n_gpus > 1 || (force && force[0] == '1')) {
         d->lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
         if (!d->lib) d->lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
         if (!d->lib || !bind(d->lib, "ncclCommInitAll", d->CommInitAll) || !bind(d->lib, "ncclCommDestroy", d->CommDestroy) ||
@@ -113,7 +117,7 @@ int mbn_dist_broadcast(mbn_dist *d, void *const *dev_ptrs, size_t bytes, int roo
     if (!d || !dev_ptrs || root < 0 || root >= d->n) return MBN_EINVAL;
     for (int r = 0; r < d->n; r++)
         if (!dev_ptrs[r]) return MBN_EINVAL;
-    if (bytes == 0 || d->n == 1) return MBN_OK;
+    if (bytes == 0 || d->comm.empty()) return MBN_OK;                         // no communicator: one GPU (root's buffer is the only one)
     ncclResult_t r = d->GroupStart();
     if (r != ncclSuccess) return dist_fail(d, r, "ncclGroupStart");
     for (int i = 0; i < d->n && r == ncclSuccess; i++) {

@@ -12,6 +12,12 @@ from __future__ import annotations
 import os
 
 
+def _force_pg() -> bool:
+    """MBN_DIST_FORCE_PG=1: join a process group and run the collectives even with ONE rank (round 4 rehearsal on the one-GPU boxes: backend "nccl" then
+    initialises RCCL, broadcasts the blob, runs the barrier and the MAX all-reduce for real; only the xGMI transfer is missing)."""
+    return os.environ.get("MBN_DIST_FORCE_PG") == "1"
+
+
 def env_rank_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
@@ -20,8 +26,9 @@ def init(backend: str, device=None):
     """Join the job described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT. No-op for a single process."""
     import torch.distributed as dist
     rank, _, world = env_rank_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or _force_pg()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         kw = {"device_id": device} if (device is not None and backend == "nccl") else {}
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, world
@@ -39,14 +46,14 @@ def shard_range(total: int, world: int, rank: int):
 def broadcast_blob(blob, src: int = 0):
     """Rank `src`'s parameter blob (a torch tensor on the rank's device) overwrites everybody else's."""
     import torch.distributed as dist
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized() and (dist.get_world_size() > 1 or _force_pg()):
         dist.broadcast(blob, src=src)
     return blob
 
 
 def barrier():
     import torch.distributed as dist
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized() and (dist.get_world_size() > 1 or _force_pg()):
         dist.barrier()
 
 
@@ -54,7 +61,7 @@ def max_over_ranks(seconds: float, device="cpu") -> float:
     """The job's time for a region is the slowest rank's."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_initialized() and dist.get_world_size() > 1):
+    if not (dist.is_initialized() and (dist.get_world_size() > 1 or _force_pg())):
         return seconds
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

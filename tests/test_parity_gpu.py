@@ -1875,6 +1875,43 @@ def test_dist_single_gpu_path_and_c_host_gpus_mode(pkg, ctx, tmp_path):
     assert out.returncode != 0 and "mbn_dist_init" in out.stderr and "no HIP device" in out.stderr      # MBN_ENODEVICE, not a hang
 
 
+def test_dist_rccl_path_rehearsed_on_one_gpu(pkg):
+    """Round 4: the RCCL leg of the C multi-GPU path (csrc/mbn_dist.hip: dlopen of librccl, symbol binding, ncclCommInitAll, ONE grouped ncclBroadcast on
+    the context's stream, sync, teardown) had never executed anywhere (one-GPU boxes). MBN_DIST_FORCE_RCCL=1 makes mbn_dist_init build the
+    communicator for a single GPU as well, so everything except the xGMI transfer itself runs for real: `mobilenet --gpus 1 --verify` in a child process
+    with that variable set must give the same logits checksum as without it, and say so in --verify."""
+    import re
+    import subprocess
+    exe = os.path.join(pkg.PKG_DIR, "mobilenet")
+    args = [exe, "--gpus", "1", "--batch", "6", "--synthetic", "3", "--alpha", "0.25", "--res", "96", "--steps", "2", "--warmup", "1", "--verify"]
+    sums = []
+    for force in ("0", "1"):
+        env = dict(os.environ, MBN_DIST_FORCE_RCCL=force, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        out = subprocess.run(args, env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, (force, out.stderr[-2000:], out.stdout[-500:])
+        ck = re.search(r"logits fnv1a ([0-9a-f]{16})", out.stdout)
+        assert ck and "identical" in out.stdout, out.stdout
+        sums.append(ck.group(1))
+    assert sums[0] == sums[1]
+
+
+def test_bench_rccl_collectives_rehearsed_with_one_rank(pkg):
+    """The torch.distributed leg of bench.py over the real "nccl" (= RCCL) backend had never run (one-GPU boxes): with MBN_DIST_FORCE_PG=1 a single rank
+    joins a process group and runs the blob broadcast, the barriers and the MAX all-reduce through RCCL for real. The line must be the N = 1 line
+    (cpu_baseline off here for time) with a passing parity check."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(MBN_DIST_FORCE_PG="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(pkg.REPO_ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "1", "--batch", "16", "--alpha", "0.5", "--res", "96",
+           "--no-configs-alt", "--no-cpu-variants", "--no-unfused-stages", "--no-pw-emul-alt"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["parity_check"]["ok"]
+
+
 def _lab(ctx):
     return ctx.lib.mbn_lab_build() == 1
 
