@@ -513,7 +513,8 @@ int  mbn_net_layer_output(mbn_net *net, int index, void **dptr, size_t *floats_p
  * The reference takes exactly one device (MobileNet.c:155 clGetDeviceIDs(..., 1, &device_id, ...)); this is the form a C
  * host uses to drive all GPUs of a node from one process, one thread per GPU:
  *   mbn_dist_init       one mbn_context per GPU (device_ordinals NULL = 0..n-1) + an RCCL communicator over them
- *                       (ncclCommInitAll; RCCL is bound with dlopen at this call, n_gpus = 1 needs none);
+ *                       (ncclCommInitAll; RCCL is bound with dlopen at this call, n_gpus = 1 needs none — with MBN_DIST_FORCE_RCCL=1 in the
+ *                       environment one is built for a single GPU too: a rehearsal of the RCCL leg on a one-GPU box);
  *   mbn_dist_context    rank r's context: every other call of this header works on it, from the thread that owns rank r;
  *   mbn_dist_broadcast  dev_ptrs[r] = rank r's device buffer of `bytes` bytes; root's bytes overwrite the others' (one
  *                       grouped ncclBroadcast on the ranks' context streams; returns when all ranks have it). The one
