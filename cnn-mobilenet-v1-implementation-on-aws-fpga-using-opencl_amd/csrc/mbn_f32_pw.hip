@@ -687,6 +687,8 @@ int mbn_launch_f32_pointwise(const mbn_call &c, void *out, const void *in, const
     case 6: launch_cfg<float, 128, 256, 64, 64>(a, c.stream, cus); break;   // 8 waves, 96 KB LDS
     case 7: launch_cfg<float, 64, 128, 32, 64>(a, c.stream, cus); break;    // 4 waves, 48 KB LDS, 3 WG/CU
     case 8: launch_cfg<float, 128, 64, 32, 64>(a, c.stream, cus); break;    // 4 waves of 32x64
+    case 9: launch_cfg<float, 64, 128, 32, 32>(a, c.stream, cus); break;    // r4: 8 waves of 32x32 on 64x128: the shipped wave tile, 25 % fewer staged bytes per flop, 2 WG/CU
+    case 10: launch_cfg<float, 128, 64, 32, 32>(a, c.stream, cus); break;   // r4: the same on 128x64
 #endif
     default: return MBN_EUNSUPPORTED;
     }
