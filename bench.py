@@ -11,19 +11,23 @@ images that is already resident in HBM. Workload at N=1 = BASELINE.json configs[
 batch 256. With N ranks every rank runs the same per-GPU batch on its own images (weak scaling, independent images:
 no data-path collective); the packed parameter blob is broadcast once from rank 0 over RCCL before timing.
 
-Prints ONE JSON line on rank 0. Extra objects:
-  roofline      the dominant kernel (pw_gemm_f32: the 13 pointwise GEMMs): algorithmic FLOPs per launch / average
-                launch duration measured with HIP events on the kernel's stream over the timed region, vs the fp32
-                MFMA peak 157.3 TFLOP/s (MI355X_MICROARCH.md). `stages` carries the same for every stage group,
-                depthwise against the 8 TB/s HBM peak.
-  cpu_baseline  the oracle's C restatement (kind "port": the reference has no CPU path and cannot be built here)
-                timed on this box's host cores on a bounded sample of the same workload: the FIRST n images of the timed
-                batch. `variants` = SURVEY.md §8d's table (1 thread and all cores, batch 1 and 8, median of 5).
-  parity_check  the oracle's logits for those n images against the logits the timed steps left on the device; the run
-                exits non-zero above the tolerance (fp32 1e-3, bf16 6e-2 of max|ref|: tests/test_parity_gpu.py).
-  step_ms       median / p10 / p90 of the per-step time from one HIP event between steps (no sync inside the region).
-  unfused_stages  per-stage numbers of all 13 depthwise + 13 pointwise layers from a few UNTIMED forwards with one launch
-                per layer (the default runner folds layers 1-11 into fused launches).
+The LAST line of stdout (rank 0) is ONE compact JSON line (< 4 KB: the driver keeps an 8 KB tail): metric, value, unit, n_gpus, steps,
+warmup, ms_per_step, dtype, data, config, roofline, cpu_baseline, parity_check, stages_frac, configs_alt, and `full_record` = the path
+of the side file that holds everything else (per-launch table, unfused per-stage table, CPU variants, pw_emul_alt, every `how` string).
+  value         batch x K / the wall time of EXACTLY K forwards in the default configuration, barrier + device sync on both sides.
+                Nothing else runs inside that region: the steps whose kernels are timed one by one run AFTER it.
+  roofline      the dominant kernel (pw_gemm<float>: the stand-alone pointwise GEMMs): algorithmic FLOPs per launch / average launch
+                duration from HIP events on the kernel's stream over `profiled_steps` untimed single-stream forwards, against the
+                fp32 MFMA peak 157.3 TFLOP/s (MI355X_MICROARCH.md). `held_clock_ghz` = the core clock those launches held
+                (s_memtime / s_memrealtime inside the kernel), `frac_at_held_clock` = achieved / (peak x held / 2.4 GHz): comparable
+                across boxes. Flat scalars beside them: depthwise x13 against 8 TB/s, pointwise x13 against the MFMA peak, blocks, stem.
+  cpu_baseline  the oracle's C restatement (kind "port": the reference has no CPU path and cannot be built here) timed on this box's
+                host cores on a bounded sample of the same workload: the FIRST n images of the timed batch.
+  parity_check  the oracle's logits for those n images against the logits the timed steps left on the device; the run exits
+                non-zero above the tolerance (fp32 1e-3, bf16 2e-2 of max|ref|: SURVEY.md §8c, tests/test_parity_gpu.py).
+  stages_frac   {stage: [ms, frac of 8 TB/s, frac of the MFMA peak]} of the default configuration and of the one-launch-per-layer pass.
+  configs_alt   {name: [images/sec, roofline frac, parity ok]}: BASELINE.json configs[4] (bf16, batch 512) and configs[1] (batch 1).
+  ranks         N > 1: per rank [rank, device ordinal, PCI bus id, images per step, seconds], `collective_world_size`, `backend`.
 """
 import argparse
 import json
@@ -139,9 +143,9 @@ def parse_args(argv=None):
     ap.add_argument("--streams", type=int, default=0,
                     help="0 (default) = 2 in fp32 at batch >= 64, 1 otherwise. n > 1: pipeline each step over n sub-batches on "
                          "separate HIP streams (mbn_net_set_streams, bit-identical logits): the HBM-bound depthwise kernels of one "
-                         "sub-batch overlap the MFMA-bound GEMMs of the other. The steps whose kernels are timed one by one "
-                         "(--profile-every) run on ONE stream, so the per-kernel HIP-event durations behind `roofline` and "
-                         "`stages` are not stretched by a concurrent kernel (profiles/LOG.md, streams)")
+                         "sub-batch overlap the MFMA-bound GEMMs of the other. The untimed steps whose kernels are timed one by one "
+                         "(--profile-steps) run on ONE stream, so the per-kernel HIP-event durations behind `roofline` and "
+                         "`stages_frac` are not stretched by a concurrent kernel (profiles/LOG.md, streams)")
     ap.add_argument("--dist-backend", default="nccl", help="rehearsal only: 'gloo' lets several ranks share one GPU")
     ap.add_argument("--device-override", type=int, default=-1, help="rehearsal only: every rank uses this device")
     ap.add_argument("--graph", action="store_true", help="replay each step as one hipGraph (mbn_net_set_graph)")
@@ -164,44 +168,130 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-variants", action="store_true", help="skip the 1-thread / batch-1 / batch-8 CPU table")
     ap.add_argument("--no-unfused-stages", action="store_true", help="skip the untimed one-launch-per-layer pass")
     ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the CPU baseline (cap; box share is 16)")
-    ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
-    ap.add_argument("--profile-every", type=int, default=0,
-                    help="record the per-kernel HIP event pairs on every Nth timed step (with sub-batch streams those steps run "
-                         "single-stream). 0 (default) = min(10, steps // 5): at least 5 profiled steps whenever steps >= 5 "
-                         "(VERDICT r2: 2 of the driver's 20 steps were too few)")
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event pass that follows the timed region")
+    ap.add_argument("--profile-steps", type=int, default=5,
+                    help="forwards AFTER the timed region whose kernels are timed one by one (HIP event pair per launch, one stream): "
+                         "the evidence behind `roofline` and `stages_frac`. Never inside the region `value` comes from")
+    ap.add_argument("--record", default="", help="path of the full record (default: gpurun_out/bench_full_<workload>.json under the repo)")
     args = ap.parse_args(argv)
     if args.streams <= 0:
         args.streams = 2 if (args.dtype == "f32" and args.batch >= 64 and not args.graph) else 1
-    if args.profile_every <= 0:
-        args.profile_every = max(1, min(10, args.steps // 5))
+    args.profile_steps = max(1, args.profile_steps)
     return args
 
 
+def visible_gpus():
+    """GPUs this node shows, counted in a short-lived CHILD process so that the launcher itself never holds a GPU runtime (when torch
+    cannot use amdsmi, torch.cuda.device_count() falls back to hipGetDeviceCount and initialises HIP: ADVICE r4). -1 = could not tell."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=300)
+        return int(r.stdout.strip().splitlines()[-1])
+    except Exception:
+        return -1
+
+
 def self_launch(args, argv):
-    """`python bench.py --gpus N` with N > 1 and no rank environment: start the N ranks ourselves, exactly as the driver's own
-    command line would (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`), as a CHILD
-    process — never os.exec*, and before this process has touched HIP or torch.cuda (torch.cuda.device_count() does not
-    initialise the GPU on this image). Rank 0's JSON line goes to our stdout through the inherited descriptor; the child's
-    return code is ours. A rank count above the visible devices is refused here with a plain message instead of N ranks
-    failing in hipSetDevice (the reference has one device, MobileNet.c:155)."""
-    import socket
+    """`python bench.py --gpus N` with N > 1 and no rank environment: start the N ranks ourselves, the way the driver's own
+    command line does (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...`), as a CHILD process — never os.exec*,
+    and this process never touches HIP or torch.cuda (the device count comes from another child). The rendezvous is
+    `--standalone --local-addr 127.0.0.1`: torchrun picks a free port itself (no bind-then-close race). Rank 0's JSON line goes to our
+    stdout through the inherited descriptor; the child's return code is ours. A rank count above the visible devices is refused here
+    with a plain message instead of N ranks failing in hipSetDevice (the reference has one device, MobileNet.c:155)."""
     import subprocess
     if args.device_override < 0:
-        import torch
-        have = torch.cuda.device_count()
+        have = visible_gpus()
         if have < args.gpus:
             sys.stderr.write("bench.py: --gpus %d but this node shows %d GPU(s) (MBN_ENODEVICE); for a rehearsal on one card use "
                              "--dist-backend gloo --device-override 0\n" % (args.gpus, have))
             return 19       # ENODEV
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           "--nproc-per-node", str(args.gpus), os.path.abspath(__file__)] + list(argv)
     sys.stdout.flush()
     return subprocess.run(cmd, env=env).returncode
+
+
+LINE_LIMIT = 4096          # bytes of the printed line (VERDICT r4: the 20 KB line of round 4 did not fit the driver's 8 KB stdout tail)
+
+
+def _r(x, n=4):
+    return None if x is None else round(float(x), n)
+
+
+def compact_line(out, record_path=None):
+    """The ONE line bench.py prints, from run_one's full record: the contract's keys, `roofline` and `cpu_baseline` with scalar members
+    only (the driver's parser keeps scalars), flat [ms, frac_hbm, frac_mfma] triples per stage, [value, frac, parity_ok] per alternative
+    configuration. Everything else stays in the side file `full_record` names. Pure function: tests/test_host_cpu.py feeds it a
+    synthetic record and checks length and parse."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    line = {k: out.get(k) for k in keep}
+    line["value"], line["ms_per_step"] = _r(out.get("value"), 1), _r(out.get("ms_per_step"), 4)
+    cfg = out.get("config") or {}
+    line["config"] = {k: cfg[k] for k in ("workload", "global_batch", "per_gpu_batch", "parallelism", "streams", "device", "pw_emul") if k in cfg}
+    rf = out.get("roofline")
+    if rf:
+        line["roofline"] = {k: (v if isinstance(v, (str, int)) or v is None else _r(v, 5 if "ms" in k else 4)) for k, v in rf.items()
+                            if not isinstance(v, (dict, list)) and k not in ("note",)}
+        if isinstance(line["roofline"].get("kernel"), str):
+            line["roofline"]["kernel"] = line["roofline"]["kernel"][:110]
+    sf = {}
+    for name, st in (out.get("stages") or {}).items():
+        sf[name] = [_r(st["ms"]), _r(st["frac_hbm"]), _r(st["frac_mfma"])]
+    for name, st in (((out.get("unfused_stages") or {}).get("stages")) or {}).items():
+        if name in ("depthwise", "pointwise", "conv1"):
+            sf["unfused_%s_x%d" % (name, st["launches"])] = [_r(st["ms"]), _r(st["frac_hbm"]), _r(st["frac_mfma"])]
+    if sf:
+        line["stages_frac"] = sf
+        line["stages_frac_cols"] = "ms,frac_of_8TBps,frac_of_mfma_peak"
+        line["profiled_steps"] = out.get("profiled_steps")
+    cb = out.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {"value": _r(cb["value"], 2), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                                "sample": str(cb.get("sample", ""))[:110]}
+    pc = out.get("parity_check")
+    if pc:
+        line["parity_check"] = {"ok": pc["ok"], "max_rel_err": float("%.3e" % pc["max_rel_err"]), "tolerance": pc["tolerance"], "images": pc["images"]}
+    if out.get("step_ms"):
+        line["step_ms"] = [out["step_ms"]["median"], out["step_ms"]["p10"], out["step_ms"]["p90"]]
+    ca = out.get("configs_alt")
+    if ca:
+        line["configs_alt"] = {name: [_r(c.get("value"), 1), _r((c.get("roofline") or {}).get("frac")), (c.get("parity_check") or {}).get("ok")]
+                               for name, c in ca.items()}
+        line["configs_alt_cols"] = "images_per_sec,roofline_frac(bf16: pointwise of 8 TB/s; f32: of mfma peak),parity_ok"
+    alt = out.get("pw_emul_alt")
+    if alt:
+        line["pw_emul_alt"] = [_r(alt["value"], 1), (alt.get("parity_check") or {}).get("ok")]
+    for k in ("ranks", "ranks_cols", "collective_world_size", "backend"):
+        if k in out:
+            line[k] = out[k]
+    if record_path:
+        line["full_record"] = record_path
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) > LINE_LIMIT:                      # never print a line the driver cannot keep: drop the optional tables, largest first
+        for k in ("stages_frac", "configs_alt", "ranks", "step_ms", "pw_emul_alt"):
+            if k in line:
+                line.pop(k)
+                line.pop(k + "_cols", None)
+                line["dropped"] = line.get("dropped", []) + [k]
+                text = json.dumps(line, separators=(",", ":"))
+                if len(text) <= LINE_LIMIT:
+                    break
+    return text
+
+
+def write_record(args, out):
+    """The full record (everything run_one measured) as a side file; returns the path the line names (relative to the repo when inside it)."""
+    name = args.record or os.path.join(ROOT, "gpurun_out", "bench_full_%s_a%g_r%d_b%d_n%d.json" % (args.dtype, args.alpha, args.res, args.batch, out.get("n_gpus", 1)))
+    try:
+        os.makedirs(os.path.dirname(os.path.abspath(name)), exist_ok=True)
+        with open(name, "w") as f:
+            json.dump(out, f, indent=1)
+    except OSError:
+        fd, name = tempfile.mkstemp(prefix="mbn_bench_full_", suffix=".json")
+        with os.fdopen(fd, "w") as f:
+            json.dump(out, f, indent=1)
+    return os.path.relpath(name, ROOT) if os.path.abspath(name).startswith(ROOT + os.sep) else name
 
 
 def main():
@@ -234,34 +324,34 @@ def main():
     env = {"pkg": pkg, "mdist": mdist, "torch": torch, "lib": lib, "rank": rank, "local_rank": local_rank, "world": world, "dev": dev}
 
     out = run_one(args, env)
+    fail = None
     if rank == 0:
         headline = (world == 1 and args.dtype == "f32" and args.alpha == 1.0 and args.res == 224 and args.batch == 256
                     and not args.pw_emul and not args.graph and not args.tune)
         if headline and not args.no_configs_alt:
             out["configs_alt"] = configs_alt(args, env)
-            if "roofline" in out:
-                out["roofline"]["configs_alt"] = {
-                    name: {"value": round(c["value"], 1), "ms_per_step": round(c["ms_per_step"], 4), "bound": (c.get("roofline") or {}).get("bound"),
-                           "frac": (c.get("roofline") or {}).get("frac"), "parity_ok": (c.get("parity_check") or {}).get("ok"),
-                           "parity_max_rel_err": (c.get("parity_check") or {}).get("max_rel_err")}
-                    for name, c in out["configs_alt"].items()}
-        print(json.dumps(out))
-        sys.stdout.flush()
         if "parity_check" in out and not out["parity_check"]["ok"]:
-            sys.exit("parity check failed: max rel err %.3e > %.1e" % (out["parity_check"]["max_rel_err"],
-                                                                       out["parity_check"]["tolerance"]))
+            fail = "parity check failed: max rel err %.3e > %.1e" % (out["parity_check"]["max_rel_err"], out["parity_check"]["tolerance"])
         for name, c in (out.get("configs_alt") or {}).items():
             pc = c.get("parity_check")
-            if pc and not pc["ok"]:
-                sys.exit("configs_alt %s: parity check failed: max rel err %.3e > %.1e" % (name, pc["max_rel_err"], pc["tolerance"]))
+            if pc and not pc["ok"] and not fail:
+                fail = "configs_alt %s: parity check failed: max rel err %.3e > %.1e" % (name, pc["max_rel_err"], pc["tolerance"])
+        if out.get("ranks_error") and not fail:
+            fail = out["ranks_error"]
+        sys.stderr.flush()
+        print(compact_line(out, write_record(args, out)))       # the LAST line of stdout
+        sys.stdout.flush()
     mdist.shutdown()
+    if fail:
+        sys.exit(fail)
 
 
 def configs_alt(args, env):
     """The other single-GPU configurations BASELINE.json names, measured after the headline line in the same process and
     printed inside it (the driver's record should hold them): configs[4] = bf16 storage at 1.0x224 and
-    0.5x160, batch 512; configs[1] = batch 1 (latency). Each entry is a full bench line of its own workload (value,
-    ms_per_step, stages, roofline with the committed PMC traffic, parity_check against the oracle) minus the CPU tables."""
+    0.5x160, batch 512; configs[1] = batch 1 (latency). Each entry is a full record of its own workload (value, ms_per_step,
+    stages, roofline with the committed PMC traffic, parity_check against the oracle) minus the CPU tables; the printed line
+    carries [value, roofline frac, parity ok] of each, the side file all of it."""
     import copy
     res = {}
     for name, kw in (("bf16_1.0x224_b512", dict(dtype="bf16", alpha=1.0, res=224, batch=512, streams=1)),
@@ -270,10 +360,8 @@ def configs_alt(args, env):
         a = copy.copy(args)
         for k, v in kw.items():
             setattr(a, k, v)
-        # 5 profiled steps each (per-kernel event pairs cost 5-9 us per launch: on these 0.6-1.9 ms steps 5 of 20 profiled steps took 4-9 % off
-        # `value`, profiles/r03/u_profiled_steps_cost.txt; 5 of 60 keep the evidence and 1-2 % of that)
         a.steps, a.warmup = (200, 20) if a.batch == 1 else (60, 8)
-        a.profile_every = max(1, a.steps // 5)
+        a.profile_steps = 5                      # after the timed region, like the headline's
         a.no_cpu_variants = a.no_unfused_stages = a.no_pw_emul_alt = True
         a.cpu_images = 1 if a.batch == 1 else 8
         o = run_one(a, env)
@@ -347,71 +435,62 @@ def run_one(args, env):
         net.forward(d_in.ptr, d_out.ptr, args.batch)
     ctx.sync()
 
-    n_layers = plan.n_layers
     profile = not args.no_profile and not args.graph    # per-kernel events cannot be read back from inside a graph
-    every = max(1, args.profile_every)
-    sampled = [s for s in range(args.steps) if s % every == every // 2] or [0]      # >= 5 steps whenever steps >= 5 (parse_args)
     multi = args.streams > 1 and args.batch >= 2 * args.streams
-    nsub = 1                                    # profiled steps are single-stream: one launch per layer in the event list
-    # launches of one sub-batch pass, in order (mbn_net_launches): the fused stem (layers 1-3, mbn_stem_fused), fused
+    # launches of one single-stream pass, in order (mbn_net_launches): the fused stem (layers 1-3, mbn_stem_fused), fused
     # depthwise->pointwise blocks (mbn_dwpw_fused) and single layers
     launches = [list(range(f - 1, f - 1 + c)) for f, c in net.launches(args.batch)]
     n_launch = len(launches)
-    calls_per_step = n_launch * nsub            # with sub-batch streams every launch is issued once per sub-batch
-    if profile:
-        ctx.profile_begin(calls_per_step * len(sampled))
-        ctx.profile_pause(True)
+
+    # ---- the timed region: EXACTLY K forwards in the default configuration, barrier + device-wide sync on both sides; one HIP event
+    # between steps (no sync) for the per-step median. No per-kernel events, no single-stream steps: `value` is one configuration.
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    ctx.mark()                                  # one HIP event between steps: per-step durations without a sync in the region
+    ctx.mark()
     for step in range(args.steps):
-        if profile and step in sampled:
-            if multi:
-                net.set_streams(1)                  # this step's kernels are timed one by one: no concurrent kernel beside them
-            ctx.profile_pause(False)
-            net.forward(d_in.ptr, d_out.ptr, args.batch)
-            ctx.profile_pause(True)
-            if multi:
-                net.set_streams(args.streams, free_running=True)
-        else:
-            net.forward(d_in.ptr, d_out.ptr, args.batch)
+        net.forward(d_in.ptr, d_out.ptr, args.batch)
         ctx.mark()
     torch.cuda.synchronize()
     barrier()
     t1 = time.perf_counter()
-    elapsed = t1 - t0
-    layer_ms = None
-    if profile:
-        ms = ctx.profile_end(calls_per_step * len(sampled))
-        # launch order inside a step is stream-major: [sub-batch 0: layers 1..29][sub-batch 1: ...]; a layer's time is the
-        # SUM over its sub-batch launches (they overlap other streams' kernels, so this is conservative for GB/s, TFLOP/s)
-        arr = np.asarray(ms, dtype=np.float64).reshape(len(sampled), nsub, n_launch)
-        layer_ms_raw = arr.mean(axis=0).sum(axis=0)
-        # What the event pair itself adds to every reading (VERDICT r2 item 3: stand-alone depthwise read 34.5 us by events, 31.2 us
-        # in the rocprofv3 kernel trace): a pair recorded around NOTHING on the same stream reads the marker-to-marker time that is
-        # also inside every pair with a kernel between them. Measured here, after the timed region, and subtracted from every launch.
-        ov_null_us = ctx.profile_null_us(False)
-        ov_kernel_us = ctx.profile_null_us(True)
-        layer_ms = np.maximum(layer_ms_raw - ov_null_us * 1e-3 * nsub, 1e-6)
-
+    elapsed_rank = t1 - t0
     step_ms = np.asarray(ctx.marks_read(args.steps + 1), dtype=np.float64)
-    elapsed = mdist.max_over_ranks(elapsed, "cpu" if args.dist_backend == "gloo" else dev)
+    elapsed = mdist.max_over_ranks(elapsed_rank, "cpu" if args.dist_backend == "gloo" else dev)
 
-    logits = d_out.download((args.batch, 1000), np.float32)
+    logits = d_out.download((args.batch, 1000), np.float32)      # what the timed steps left on the device
     if not np.isfinite(logits).all():
         sys.exit("non-finite logits")
 
-    # ---- the same K steps once more WITHOUT the per-kernel events (and without the single-stream steps they need): never `value`, reported
-    # beside it so that what the instrumentation costs the headline is visible in the record
-    value_no_profile = None
-    if profile and world == 1:
-        torch.cuda.synchronize()
-        n0 = time.perf_counter()
-        for _ in range(args.steps):
+    # ---- after the region: `profile_steps` forwards on ONE stream with a HIP event pair around every launch (roofline, stages_frac),
+    # the pw_gemm launches also accumulating the core clock they held (tune key pw_clock)
+    layer_ms = None
+    held_ghz, held_launches = None, 0
+    n_prof = args.profile_steps
+    if profile:
+        if multi:
+            net.set_streams(1)
+        net.forward(d_in.ptr, d_out.ptr, args.batch)              # one untimed pass in the single-stream configuration first
+        ctx.sync()
+        clock_ok = lib.mbn_tune_set(b"pw_clock", 1) == 0
+        if clock_ok:
+            ctx.pw_clock(reset=True)
+        ctx.profile_begin(n_launch * n_prof)
+        for _ in range(n_prof):
             net.forward(d_in.ptr, d_out.ptr, args.batch)
-        torch.cuda.synchronize()
-        value_no_profile = args.batch * args.steps / (time.perf_counter() - n0)
+        ms = ctx.profile_end(n_launch * n_prof)
+        if clock_ok:
+            held_ghz, held_launches = ctx.pw_clock(reset=True)
+            lib.mbn_tune_set(b"pw_clock", 0)
+        layer_ms_raw = np.asarray(ms, dtype=np.float64).reshape(n_prof, n_launch).mean(axis=0)
+        # What the event pair itself adds to every reading (VERDICT r2 item 3: stand-alone depthwise read 34.5 us by events, 31.2 us
+        # in the rocprofv3 kernel trace): a pair recorded around NOTHING on the same stream reads the marker-to-marker time that is
+        # also inside every pair with a kernel between them. Measured here and subtracted from every launch.
+        ov_null_us = ctx.profile_null_us(False)
+        ov_kernel_us = ctx.profile_null_us(True)
+        layer_ms = np.maximum(layer_ms_raw - ov_null_us * 1e-3, 1e-6)
+        if multi:
+            net.set_streams(args.streams, free_running=True)
 
     # ---- the opt-in split form of the pointwise GEMM beside the default line (N = 1, fp32): same net, same buffers, same
     # stream configuration, 3 warm-up + 10 timed steps without per-kernel events. Never part of `value`.
@@ -439,6 +518,14 @@ def run_one(args, env):
                        "three are < 2^-24 of it), fp32 accumulate; measured error against float64 <= the fp32 MFMA kernel's "
                        "(profiles/r02/m_pw_emul.txt). Opt-in: `value` above is the fp32-MFMA path"}
 
+    # ---- N > 1: every rank reports which card it held and what it did (off the timed path); rank 0 prints them
+    ranks_info = None
+    if world > 1 or mdist._force_pg():
+        import torch.distributed as tdist
+        mine = [rank, local_rank, ctx.pci_bus_id(), args.batch, round(elapsed_rank, 6)]
+        ranks_info = [None] * tdist.get_world_size()
+        tdist.all_gather_object(ranks_info, mine)
+
     if rank == 0:
         total_images = args.batch * world * args.steps
         out = {
@@ -461,9 +548,9 @@ def run_one(args, env):
                        "global_batch": args.batch * world, "per_gpu_batch": args.batch,
                        "parallelism": "batch-sharded x%d, weights broadcast once over RCCL" % world,
                        "streams": args.streams if multi else 1,
-                       "streams_note": ("sub-batches of %d images on %d forked streams; the %d steps whose kernels are timed one "
-                                        "by one (stages, roofline) run on one stream" % (args.batch // args.streams, args.streams,
-                                                                                          len(sampled) if profile else 0)) if multi else None,
+                       "streams_note": ("sub-batches of %d images on %d forked streams in the timed region; the %d untimed steps whose "
+                                        "kernels are timed one by one (stages, roofline) run on one stream" % (args.batch // args.streams, args.streams,
+                                                                                                            n_prof if profile else 0)) if multi else None,
                        "device": ctx.name()},
         }
         if layer_ms is not None:
@@ -473,7 +560,6 @@ def run_one(args, env):
             dom = "pointwise" if "pointwise" in stages else "block_fused"
             pw = stages[dom]
             pw_idx = [launches[j][-1] for j in range(n_launch) if stage_of[j] == dom]
-            out["launches_per_layer"] = nsub
             flops_per_launch = sum(layer_work(plan.layer[i], args.batch, pkg, act_bytes)[0] for i in pw_idx) / len(pw_idx)
             bytes_per_launch = sum(layer_work(plan.layer[i], args.batch, pkg, act_bytes)[1] for i in pw_idx) / len(pw_idx)
             avg_ms = pw["ms"] / len(pw_idx)           # per LAYER (= per launch when --streams 1)
@@ -498,23 +584,33 @@ def run_one(args, env):
                     "algorithmic_flops_per_launch": flops_per_launch,
                     "algorithmic_bytes_per_launch": bytes_per_launch,
                 }
-            # the driver's record keeps `roofline` and `cpu_baseline` of this line: the per-stage fractions go inside `roofline` as well
-            out["roofline"]["stages_frac"] = {k: {"ms": v["ms"], "launches": v["launches"], "frac_hbm": v["frac_hbm"], "frac_mfma": v["frac_mfma"]}
-                                              for k, v in stages.items()}
-            if value_no_profile is not None:
-                out["roofline"]["value_no_profile"] = round(value_no_profile, 1)
-                out["value_no_profile"] = {"value": round(value_no_profile, 1), "unit": "images/sec", "steps": args.steps,
-                                           "how": "the same K steps again after the timed region with no per-kernel events and every step on "
-                                                  "the default stream configuration; `value` above includes %d profiled single-stream steps" % len(sampled)}
+            out["roofline"]["launches_per_step"] = len(pw_idx)
+            if held_ghz and dom == "pointwise" and not bf16 and not args.pw_emul:
+                # the clock the chip held inside these very launches (DVFS differs by box: 2.1-2.4 GHz); the peak is quoted at 2.4 GHz
+                out["roofline"]["held_clock_ghz"] = round(held_ghz, 3)
+                out["roofline"]["frac_at_held_clock"] = round(out["roofline"]["achieved"] / (MFMA_F32_PEAK_TFLOPS * held_ghz / 2.4), 4)
+                out["roofline"]["held_clock_launches"] = int(held_launches)
             out["stages"] = stages
             out["layers"] = per_layer
             out["sum_kernel_ms"] = round(float(layer_ms.sum()), 4)
-            out["profiled_steps"] = len(sampled)
+            out["profiled_steps"] = n_prof
+            out["profiled_steps_where"] = "after the timed region, one stream"
             out["event_overhead_us"] = {"subtracted_per_launch": round(ov_null_us, 3), "empty_pair": round(ov_null_us, 3),
                                         "pair_around_empty_kernel": round(ov_kernel_us, 3),
                                         "sum_kernel_ms_raw": round(float(layer_ms_raw.sum()), 4),
                                         "how": "median of 200 event pairs recorded like a layer call's (mbn_profile_null) after the timed "
                                                "region; every per-launch time in stages/layers/roofline is the raw pair reading minus empty_pair"}
+        if ranks_info is not None:
+            import torch.distributed as tdist
+            out["ranks"] = ranks_info
+            out["ranks_cols"] = "rank,device_ordinal,pci_bus_id,images_per_step,seconds_for_the_K_steps"
+            out["collective_world_size"] = tdist.get_world_size()
+            out["backend"] = tdist.get_backend()
+            buses = [r[2] for r in ranks_info]
+            if len(set(buses)) != len(buses) and args.device_override < 0:
+                out["ranks_error"] = "two ranks held the same GPU (PCI bus ids %s) without --device-override" % buses
+            if len(ranks_info) != world:
+                out["ranks_error"] = "the process group has %d ranks, the line claims %d" % (len(ranks_info), world)
         out["h2d_ms_per_batch"] = round(h2d_ms, 3)   # PCIe-inclusive rate = batch / (ms_per_step + this)
         if step_ms.size:
             out["step_ms"] = {"median": round(float(np.median(step_ms)), 4), "p10": round(float(np.percentile(step_ms, 10)), 4),
@@ -541,11 +637,15 @@ def run_one(args, env):
             out["unfused_stages"] = {"note": "untimed: %d forwards with one launch per layer (mbn_net_set_fuse_stem(0), "
                                              "mbn_net_set_fuse_blocks(0)); same batch, same buffers" % reps,
                                      "stages": ust, "layers": ulayers, "sum_kernel_ms": round(float(ums.sum()), 4)}
-            if "roofline" in out:
-                for k in ("depthwise", "pointwise"):
-                    if k in ust:
-                        out["roofline"]["stages_frac"]["unfused_%s_x%d" % (k, ust[k]["launches"])] = {
-                            "ms": ust[k]["ms"], "launches": ust[k]["launches"], "frac_hbm": ust[k]["frac_hbm"], "frac_mfma": ust[k]["frac_mfma"]}
+            if "roofline" in out:       # flat scalars the driver's record keeps: north_star's two stage targets, and the fused launches
+                if "depthwise" in ust:
+                    out["roofline"]["dw_x%d_frac_hbm" % ust["depthwise"]["launches"]] = ust["depthwise"]["frac_hbm"]
+                if "pointwise" in ust:
+                    out["roofline"]["pw_x%d_frac_mfma" % ust["pointwise"]["launches"]] = ust["pointwise"]["frac_mfma"]
+                if "block_fused" in stages:
+                    out["roofline"]["blocks_ms"] = stages["block_fused"]["ms"]
+                if "stem_fused" in stages:
+                    out["roofline"]["stem_ms"] = stages["stem_fused"]["ms"]
             net.set_fuse_stem(not args.no_fuse_stem)
             net.set_fuse_tail(args.fuse_tail)
             if args.fuse_blocks is not None:
@@ -587,7 +687,7 @@ def run_one(args, env):
             got = logits[:n_img].astype(np.float64)
             scale = max(float(np.abs(ref).max()), 1e-6)
             err = float(np.abs(got - ref).max()) / scale
-            tol = 6e-2 if bf16 else 1e-3
+            tol = 2e-2 if bf16 else 1e-3
             if alt is not None:
                 aerr = float(np.abs(alt_logits[:n_img].astype(np.float64) - ref).max()) / scale
                 alt["parity_check"] = {"images": n_img, "max_rel_err": aerr, "tolerance": tol, "ok": bool(aerr <= tol),
@@ -626,7 +726,7 @@ def run_one(args, env):
             ref = np.asarray(ref, dtype=np.float64).reshape(n_img, 1000)
             got = logits[:n_img].astype(np.float64)
             err = float(np.abs(got - ref).max()) / max(float(np.abs(ref).max()), 1e-6)
-            tol = 6e-2 if bf16 else 1e-3
+            tol = 2e-2 if bf16 else 1e-3
             out["parity_check"] = {"images": n_img, "max_rel_err": err, "tolerance": tol, "ok": bool(err <= tol),
                                    "argmax_agree": int((got.argmax(1) == ref.argmax(1)).sum()),
                                    "against": "oracle/mbn_oracle.c F32 mode%s, logits of the first %d images of rank 0's shard"

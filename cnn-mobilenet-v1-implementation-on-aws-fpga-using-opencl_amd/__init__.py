@@ -136,6 +136,8 @@ def load():
         lib.mbn_device_count.argtypes = [C.POINTER(ci)]
         lib.mbn_device_name.argtypes = [vp, C.c_char_p, C.c_size_t]
         lib.mbn_device_cus.argtypes = [vp, C.POINTER(C.c_int)]
+        lib.mbn_device_pci_bus_id.argtypes = [vp, C.c_char_p, C.c_size_t]
+        lib.mbn_pw_clock_read.argtypes = [vp, ci, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
         lib.mbn_set_literal_quirks.argtypes = [vp, C.c_uint32]
         lib.mbn_get_stream.argtypes = [vp, C.POINTER(vp)]
         lib.mbn_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
@@ -326,6 +328,17 @@ class Context:
         self.lib.mbn_device_name(self.h, b, 128)
         return b.value.decode()
 
+    def pci_bus_id(self) -> str:
+        b = C.create_string_buffer(64)
+        _chk(self.lib.mbn_device_pci_bus_id(self.h, b, 64), self.last_error())
+        return b.value.decode()
+
+    def pw_clock(self, reset=True):
+        """(GHz, launches): the core clock held inside the pw_gemm launches recorded since the last reset (tune key pw_clock)."""
+        g, n = C.c_double(), C.c_longlong()
+        _chk(self.lib.mbn_pw_clock_read(self.h, int(reset), C.byref(g), C.byref(n)), self.last_error())
+        return g.value, n.value
+
     def alloc(self, nbytes) -> DeviceBuffer:
         b = DeviceBuffer(self, nbytes)
         self._bufs.append(b)
@@ -499,18 +512,23 @@ class Net:
     def keep_activations(self, keep=True):
         _chk(self.ctx.lib.mbn_net_set_keep_activations(self.h, int(keep)))
 
-    def layer_output(self, index, batch) -> np.ndarray:
+    def layer_output(self, index, batch, images=None) -> np.ndarray:
+        """Kept activation of layer `index` (1-based): the whole batch, or only the listed images (full-size batches: a few images
+        of an 800 MB tensor)."""
         p, n = C.c_void_p(), C.c_size_t()
         _chk(self.ctx.lib.mbn_net_layer_output(self.h, index, C.byref(p), C.byref(n)))
         l = self.plan.layer[index - 1]
-        shape = (batch, l.out_rows, l.out_cols, l.out_ch)
-        if getattr(self, "dtype", DT_F32) == DT_BF16 and l.kind != L_FC:
-            raw = np.empty(shape, np.uint16)
+        bf = getattr(self, "dtype", DT_F32) == DT_BF16 and l.kind != L_FC
+        per = (l.out_rows, l.out_cols, l.out_ch)
+        raw = np.empty((batch if images is None else len(images),) + per, np.uint16 if bf else np.float32)
+        if images is None:
             _chk(self.ctx.lib.mbn_download(self.ctx.h, raw.ctypes.data, p, raw.nbytes))
-            return bf16_bits_to_f32(raw)
-        out = np.empty(shape, np.float32)
-        _chk(self.ctx.lib.mbn_download(self.ctx.h, out.ctypes.data, p, out.nbytes))
-        return out
+        else:
+            step = raw[0].nbytes
+            for j, im in enumerate(images):
+                assert 0 <= im < batch
+                _chk(self.ctx.lib.mbn_download(self.ctx.h, raw[j].ctypes.data, p.value + im * step, step))
+        return bf16_bits_to_f32(raw) if bf else raw
 
     def destroy(self):
         if self.h:

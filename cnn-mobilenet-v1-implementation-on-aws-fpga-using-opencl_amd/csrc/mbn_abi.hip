@@ -77,6 +77,7 @@ static std::atomic<int> *tune_slot(const char *key, bool *lab_only)
     if (!strcmp(key, "pw_emul")) return &g_mbn_tune.pw_emul;
     if (!strcmp(key, "pw_emul_static")) return &g_mbn_tune.pw_emul_static;
     if (!strcmp(key, "lit_dot")) return &g_mbn_tune.lit_dot;
+    if (!strcmp(key, "pw_clock")) return &g_mbn_tune.pw_clock;
     static const char *const lab_keys[] = { "dw_variant", "dw_nseg", "pw_stage", "conv_variant", "misc", "pw_ring", "pw_xn", "dwpw_variant",
                                             "exp0", "exp1", "exp2", "cu_mask" };
     for (const char *k : lab_keys)
@@ -185,6 +186,14 @@ int mbn_device_name(mbn_context *ctx, char *buf, size_t buflen)
 {
     if (!ctx || !buf || buflen == 0) return MBN_EINVAL;
     snprintf(buf, buflen, "%s", ctx->name);
+    return MBN_OK;
+}
+
+int mbn_device_pci_bus_id(mbn_context *ctx, char *buf, size_t buflen)
+{
+    if (!ctx || !buf || buflen < 16) return MBN_EINVAL;
+    buf[0] = 0;
+    MBN_HIP_TRY(ctx, hipDeviceGetPCIBusId(buf, (int)buflen, ctx->device));
     return MBN_OK;
 }
 

@@ -48,6 +48,10 @@ typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 __device__ unsigned long long g_pw_clk[8][4];
 #endif
 
+// tune key pw_clock: core-clock cycles (s_memtime) and 100 MHz reference ticks (s_memrealtime) that workgroups 0..7 (one per XCD: the
+// tiles are persistent, so each lives as long as the launch) of every pw_gemm launch were alive, accumulated; [8] = launches
+__device__ unsigned long long g_pw_clk_acc[9][2];
+
 struct PwArgs {
     void *out;
     const void *in, *filt;
@@ -61,6 +65,7 @@ struct PwArgs {
     int no_ss;      // 1 = epilogue reads scale/shift from global memory as in round 1 (A/B hook: tune conv_variant=7)
     int no_cw;      // 1 = __syncthreads() (vmcnt(0)) also at the first barrier behind a fast epilogue (lab A/B: exp0 = 77)
     int xn;         // XCD groups along n (1, 2 or 4): > 1 when the filter does not fit an XCD's L2 next to the streamed A panels
+    int clk;        // 1 = accumulate this launch's held clock into g_pw_clk_acc (tune key pw_clock; bench.py's untimed profiled steps)
 };
 
 constexpr int BKB = 128;            // k-tile in BYTES per row (32 fp32 / 64 bf16)
@@ -247,6 +252,9 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void pw_gemm(PwArgs a)
         vb_end = (cnt << 3) + x;                 // vb = 8 j + x < 8 cnt + x  <=>  j < cnt
     }
     if (vb >= vb_end) return;
+    const bool hclk = a.clk && blockIdx.x < 8 && threadIdx.x == 0;
+    unsigned long long hc0 = 0, hr0 = 0;
+    if (hclk) { hc0 = __builtin_amdgcn_s_memtime(); hr0 = __builtin_amdgcn_s_memrealtime(); }
 #ifdef MBN_LAB
     const bool clk = blockIdx.x < 8 && threadIdx.x == 0;
     if (clk) { g_pw_clk[blockIdx.x][0] = __builtin_amdgcn_s_memtime(); g_pw_clk[blockIdx.x][2] = __builtin_amdgcn_s_memrealtime(); }
@@ -490,6 +498,11 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void pw_gemm(PwArgs a)
 #ifdef MBN_LAB
     if (clk) { g_pw_clk[blockIdx.x][1] = __builtin_amdgcn_s_memtime(); g_pw_clk[blockIdx.x][3] = __builtin_amdgcn_s_memrealtime(); }
 #endif
+    if (hclk) {
+        atomicAdd(&g_pw_clk_acc[blockIdx.x][0], __builtin_amdgcn_s_memtime() - hc0);
+        atomicAdd(&g_pw_clk_acc[blockIdx.x][1], __builtin_amdgcn_s_memrealtime() - hr0);
+        if (blockIdx.x == 0) atomicAdd(&g_pw_clk_acc[8][0], 1ull);
+    }
 }
 
 // Fallback for K not a multiple of the 16-byte chunk or unaligned pointers: one lane per output element.
@@ -580,6 +593,7 @@ int mbn_launch_f32_pointwise(const mbn_call &c, void *out, const void *in, const
                (double)m * cin * (bf ? 2 : 4) >= 4294967296.0 || (double)op_size * cin * (bf ? 2 : 4) >= 4294967296.0) ? 0 : 1;
     a.no_ss = g_mbn_tune.conv_variant == 7 ? 1 : 0;
     a.no_cw = g_mbn_tune.exp0 == 77 ? 1 : 0;
+    a.clk = g_mbn_tune.pw_clock.load(std::memory_order_relaxed) ? 1 : 0;
     a.fast_epi = (g_mbn_tune.conv_variant == 9 || (double)m * op_size * 4.0 >= 4294967296.0) ? 0 : 1;   // buffer stores: < 4 GiB
     if (m <= 0 || (long)((m + 31) / 32) * ((op_size + 31) / 32) > 0x7fffffffL) return MBN_EINVAL;
     const int epc = bf ? 8 : 4;
@@ -691,6 +705,24 @@ int mbn_launch_f32_pointwise(const mbn_call &c, void *out, const void *in, const
     case 10: launch_cfg<float, 128, 64, 32, 32>(a, c.stream, cus); break;   // r4: the same on 128x64
 #endif
     default: return MBN_EUNSUPPORTED;
+    }
+    return MBN_OK;
+}
+
+extern "C" int mbn_pw_clock_read(mbn_context *ctx, int reset, double *ghz, long long *launches)
+{
+    if (!ctx || !ghz) return MBN_EINVAL;
+    unsigned long long h[9][2];
+    MBN_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    MBN_HIP_TRY(ctx, hipDeviceSynchronize());
+    MBN_HIP_TRY(ctx, hipMemcpyFromSymbol(h, HIP_SYMBOL(g_pw_clk_acc), sizeof(h)));
+    double core = 0, real = 0;
+    for (int i = 0; i < 8; i++) { core += (double)h[i][0]; real += (double)h[i][1]; }
+    *ghz = real > 0 ? core / (real / 100.0e6) / 1.0e9 : 0.0;       // s_memrealtime counts at 100 MHz on gfx950
+    if (launches) *launches = (long long)h[8][0];
+    if (reset) {
+        memset(h, 0, sizeof(h));
+        MBN_HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_pw_clk_acc), h, sizeof(h)));
     }
     return MBN_OK;
 }

@@ -79,6 +79,7 @@ struct mbn_tunables {
     std::atomic<int> pw_emul{0};      // fp32 pointwise on the bf16 matrix cores from exact three-way operand splits (mbn_f32_pw_x6.hip): 0 = off, 6 or 9 products
     std::atomic<int> pw_emul_static{0}; // pw_emul: 1 = a filter's image is split once and reused until the filter is rewritten through this library
     std::atomic<int> net_stagger{2};  // layers by which consecutive sub-batch streams are staggered (mbn_net_set_streams)
+    std::atomic<int> pw_clock{0};     // 1 = pw_gemm launches accumulate their held core clock (mbn_pw_clock_read)
     std::atomic<int> cu_mask{0};      // streams made by mbn_stream_create alternate between two halves of the chip: 1 = XCDs 0-3 / 4-7, 2 = the two halves of every XCD (round 4 experiment)
     // ---- lab knobs
     MBN_LAB_KNOB(dw_variant);         // depthwise kernel variant

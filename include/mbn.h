@@ -138,6 +138,9 @@ int  mbn_device_count(int *count);                       /* 0 devices => *count 
 int  mbn_device_name(mbn_context *ctx, char *buf, size_t buflen);
 int  mbn_device_cus(mbn_context *ctx, int *count);       /* compute units of the context's GPU (256 on MI355X): the counterpart of
                                                           * CL_DEVICE_MAX_COMPUTE_UNITS; the net runner sizes its small-batch choices by it */
+int  mbn_device_pci_bus_id(mbn_context *ctx, char *buf, size_t buflen);   /* "0000:05:00.0": which physical GPU this context holds. The
+                                                          * reference picks device 0 of platform 0 (MobileNet.c:155); with one context
+                                                          * per rank the multi-GPU bench line proves its ranks held N cards */
 const char *mbn_last_device_error(mbn_context *ctx);     /* text of the last HIP error seen by this context */
 int  mbn_set_literal_quirks(mbn_context *ctx, uint32_t quirks);
 int  mbn_get_stream(mbn_context *ctx, void **stream);    /* the context's hipStream_t */
@@ -548,7 +551,7 @@ int  mbn_rank_fail(mbn_rank_sync *sync);
 const char *mbn_version(void);
 
 /* Process-wide switches. 0 always means "the shipped default". Two kinds:
- *   PRODUCT switches (every build): pw_tile, net_stagger, lit_dot, pw_splitk, pw_emul, pw_emul_static — they select between code
+ *   PRODUCT switches (every build): pw_tile, net_stagger, lit_dot, pw_splitk, pw_emul, pw_emul_static, pw_clock — they select between code
  *     paths the library always contains (a regime a caller or a test wants to force, the opt-in pw_emul arithmetic).
  *   LAB knobs (dw_variant, dw_nseg, pw_stage, conv_variant, misc, pw_ring, pw_xn, dwpw_variant, exp0..2): A/B hooks of the
  *     experiments recorded in profiles/LOG.md. They exist in the lab build only (make lab -> libmbn_lab.so, loaded by the tools with
@@ -592,8 +595,17 @@ const char *mbn_version(void);
  *                (weights are uploaded once there).
  *   pw_xn        pointwise GEMM tile order: XCD groups along n (0 = by filter size, 1 = single ordering, 2, 4)
  *   dwpw_variant fused block kernel: 0 = shipped choice, 1 = round-1 producer/consumer kernels, 2 = unified-wave kernels,
- *                3 = unified fp32 with the taps read inside the step, 100 + bits = unified with parts switched off */
+ *                3 = unified fp32 with the taps read inside the step, 100 + bits = unified with parts switched off
+ *   pw_clock     1 = every pw_gemm launch adds the core-clock cycles (s_memtime) and the 100 MHz reference ticks (s_memrealtime) its
+ *                first eight workgroups (one per XCD) lived to device counters; mbn_pw_clock_read turns them into the clock the
+ *                chip HELD under the fp32 MFMA stream. Off (default): two scalar compares per launch. bench.py sets it for its
+ *                untimed profiled steps only, so that `roofline.frac` can be compared across boxes (DVFS: 2.1-2.4 GHz by box;
+ *                product switch, every build) */
 int  mbn_tune_set(const char *key, int value);
+/* Mean core clock (GHz) over the pw_gemm launches recorded since the last reset (tune key pw_clock), and how many launches that was.
+ * Waits for the device. reset != 0 clears the counters after reading. No launches recorded => *ghz = 0. The counterpart in the
+ * reference is nothing: its only timing is clGetEventProfilingInfo (MobileNet.c:301-305). */
+int  mbn_pw_clock_read(mbn_context *ctx, int reset, double *ghz, long long *launches);
 int  mbn_lab_build(void);      /* 1 = built with -DMBN_LAB (all A/B variants and knobs), 0 = the shipped library */
 int  mbn_tune_get(const char *key, int *value);
 

@@ -558,3 +558,77 @@ def test_pw_gemm_counted_waits_match_the_isa():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_counted_waits.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "kernels with a counted wait checked" in r.stdout
+
+
+def _fake_bench_record():
+    """run_one's record shape (bench.py), with the sizes of the real headline run: 22 launches, 26 unfused layers, three alternative configs."""
+    st = lambda ms: {"launches": 8, "ms": ms, "GBps": 3501.03, "TFLOPs": 128.312345, "frac_hbm": 0.437612, "frac_mfma": 0.815712, "layers": "x" * 90}
+    stages = {k: st(0.1 * (i + 1)) for i, k in enumerate(("stem_fused", "block_fused", "depthwise", "pointwise", "pool", "fc"))}
+    layers = [{"layers": [i + 1], "stage": "pointwise", "ms": 0.17, "GBps": 1.0, "TFLOPs": 2.0} for i in range(26)]
+    roof = {"kernel": "pw_gemm<float> (8 pointwise 1x1 conv launches per step)" + " padding" * 40, "bound": "mfma", "achieved": 128.3123456, "peak": 157.3,
+            "unit": "TFLOP/s", "frac": 0.81571234, "traffic": 205277161.0, "traffic_source": {"git_sha": "x" * 12, "command": "y" * 300, "date": "2026-10-04"},
+            "avg_launch_ms": 0.1794212, "algorithmic_flops_per_launch": 23018340352.0, "algorithmic_bytes_per_launch": 171704320.0, "launches_per_step": 8,
+            "held_clock_ghz": 2.213, "frac_at_held_clock": 0.8846, "held_clock_launches": 40, "dw_x13_frac_hbm": 0.69, "pw_x13_frac_mfma": 0.72,
+            "blocks_ms": 0.93, "stem_ms": 0.28}
+    base = {"metric": "images/sec MobileNet-V1 1.0x224 fp32, batch 256; per-stage HBM GB/s vs roofline", "value": 89059.123456789, "unit": "images/sec",
+            "n_gpus": 1, "steps": 20, "warmup": 5, "ms_per_step": 2.87451234, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "MobileNet-V1 1x224 fp32, batch 256 per GPU, 29 layers, 1000 classes (BASELINE.json configs[2])", "global_batch": 256,
+                       "per_gpu_batch": 256, "parallelism": "batch-sharded x1, weights broadcast once over RCCL", "streams": 2, "streams_note": "z" * 200,
+                       "device": "AMD Radeon Graphics (gfx950:sramecc+:xnack-)"},
+            "roofline": roof, "stages": stages, "layers": layers, "sum_kernel_ms": 2.9, "profiled_steps": 5,
+            "event_overhead_us": {"empty_pair": 4.6, "how": "h" * 300}, "h2d_ms_per_batch": 55.0,
+            "step_ms": {"median": 2.8, "p10": 2.7, "p90": 2.9, "n": 20, "how": "h" * 100},
+            "unfused_stages": {"note": "n" * 200, "stages": {"depthwise": dict(st(0.96), launches=13), "pointwise": dict(st(2.4), launches=13), "conv1": dict(st(0.2), launches=1)},
+                               "layers": layers, "sum_kernel_ms": 3.6},
+            "pw_emul_alt": {"pw_emul": 6, "value": 115000.0, "what": "w" * 600, "parity_check": {"ok": True}},
+            "cpu_baseline": {"value": 46.655550652782544, "unit": "images/sec", "cores": 16, "kind": "port", "sample": "s" * 250,
+                             "variants": {"threads%d_batch%d" % (t, b): {"ms_per_image": 1.0, "images_per_sec": 2.0} for t in (1, 16) for b in (1, 8)}, "variants_how": "v" * 80},
+            "parity_check": {"images": 64, "max_rel_err": 4.781746733827894e-07, "tolerance": 0.001, "ok": True, "argmax_agree": 64, "against": "a" * 120}}
+    alt = {k: base[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "roofline", "stages", "sum_kernel_ms", "profiled_steps",
+                                "event_overhead_us", "step_ms", "parity_check")}
+    base["configs_alt"] = {"bf16_1.0x224_b512": alt, "bf16_0.5x160_b512": alt, "f32_1.0x224_b1": alt}
+    return base
+
+
+def test_bench_line_is_compact_parseable_and_keeps_the_contract(tmp_path):
+    """round 4's 20 KB line did not fit the driver's 8 KB stdout tail (BENCH_r04 parsed: null). The printer must turn
+    run_one's full record into ONE line under 4 KB that json.loads parses, with the contract's keys, scalar-only `roofline` and
+    `cpu_baseline`, flat per-stage triples, and the side file named; a record with 8 ranks still fits."""
+    import importlib
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    bench = importlib.import_module("bench")
+    rec = _fake_bench_record()
+    assert len(json.dumps(rec)) > 15000                                  # the record itself is the size that broke round 4
+    line = bench.compact_line(rec, "gpurun_out/bench_full.json")
+    assert "\n" not in line and len(line) < bench.LINE_LIMIT <= 4096
+    out = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline", "parity_check", "stages_frac", "configs_alt", "full_record"):
+        assert k in out, k
+    assert out["metric"] == rec["metric"] and out["steps"] == 20 and out["warmup"] == 5 and out["vs_baseline"] is None
+    assert abs(out["value"] - rec["value"]) < 0.1 and abs(out["ms_per_step"] - rec["ms_per_step"]) < 1e-3
+    assert all(not isinstance(v, (dict, list)) for v in out["roofline"].values())
+    for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "algorithmic_flops_per_launch", "held_clock_ghz",
+              "frac_at_held_clock", "dw_x13_frac_hbm", "pw_x13_frac_mfma"):
+        assert k in out["roofline"], k
+    assert abs(out["roofline"]["frac"] - out["roofline"]["achieved"] / out["roofline"]["peak"]) < 1e-3
+    assert set(out["cpu_baseline"]) == {"value", "unit", "cores", "kind", "sample"} and out["cpu_baseline"]["kind"] == "port"
+    assert out["stages_frac"]["pointwise"] == [0.4, 0.4376, 0.8157] and out["stages_frac"]["unfused_depthwise_x13"][0] == 0.96
+    assert out["configs_alt"]["bf16_1.0x224_b512"] == [89059.1, 0.8157, True]
+    assert "layers" not in out and "unfused_stages" not in out and "config" in out and "streams_note" not in out["config"]
+    # N = 8: the per-rank evidence rides along and the line still fits
+    rec8 = dict(rec, n_gpus=8, ranks=[[r, r, "0000:%02x:00.0" % (5 + r), 256, 0.0574123] for r in range(8)], ranks_cols="c" * 70,
+                collective_world_size=8, backend="nccl")
+    line8 = bench.compact_line(rec8, "gpurun_out/bench_full.json")
+    out8 = json.loads(line8)
+    assert len(line8) < bench.LINE_LIMIT and len(out8["ranks"]) == 8 and out8["collective_world_size"] == 8
+    # an oversized record degrades by dropping optional tables, never by printing an unparseable or oversized line
+    rec["stages"] = {"s%d" % i: rec["stages"]["pointwise"] for i in range(150)}
+    big = bench.compact_line(rec, "x.json")
+    assert len(big) < bench.LINE_LIMIT and "stages_frac" in json.loads(big)["dropped"]
+    # the side file round-trips
+    args = bench.parse_args(["--record", str(tmp_path / "full.json")])
+    path = bench.write_record(args, _fake_bench_record())
+    assert json.load(open(path))["layers"][0]["stage"] == "pointwise"

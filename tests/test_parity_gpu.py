@@ -633,6 +633,7 @@ def test_c_host_binary_literal_and_fp32(pkg, orc, tmp_path):
 # Storage bf16, arithmetic fp32. One bf16 ulp is 2^-8 = 0.39 % relative; the GPU sums in fp32 (MFMA / fmaf order), the
 # oracle in double, so a result near a rounding boundary may land on the neighbouring bf16 value.
 TOL_BF16 = 1e-2        # per layer, relative to max|ref| (SURVEY §8c allows 2e-2)
+TOL_BF16_NET = 2e-2    # bf16 logits after 28 layers of storage rounding, relative to max|ref| (observed 4.6-5.2e-3 at full size; 6e-2 until round 4)
 
 
 def _bf16_dev(pkg, ctx, x):
@@ -797,7 +798,7 @@ def test_bf16_net_per_layer(pkg, orc, ctx, tmp_path, cfg):
             assert_close(got, want, TOL_BF16, "bf16 net layer %d" % (i + 1))
         prev = got
     full, _ = orc.net_forward(oplan, hw.blob, imgs, bf16=True)
-    assert_close(logits, full, 6e-2, "bf16 logits vs all-oracle bf16 forward (accumulated rounding flips)")
+    assert_close(logits, full, TOL_BF16_NET, "bf16 logits vs all-oracle bf16 forward (accumulated rounding flips)")
     # and the fp32 net on the same weights agrees with bf16 to bf16 precision (sanity of the whole mode)
     net.set_dtype(pkg.DT_F32)
     net.forward(d_in.ptr, d_out.ptr, n)
@@ -864,6 +865,40 @@ def test_net_graph_replay_equals_eager(pkg, ctx, tmp_path):
     net.forward(d_in.ptr, d_out.ptr, 4)
     ctx.sync()
     assert np.array_equal(d_out.download((4, 30), np.float32), got_b)
+    net.destroy()
+
+
+@pytest.mark.parametrize("cfg", [(1.0, 224), (0.5, 160)])
+def test_bf16_net_full_size_batch512_every_layer(pkg, orc, ctx, tmp_path, cfg):
+    """BASELINE config 5 at its own size, layer by layer (bf16 had per-layer checks on small nets only): bf16 storage, batch
+    512, 1000 classes, one launch per layer (kept activations switch the fusions off, so these are the batch-512 grids of the stand-alone bf16
+    kernels: dw3x3_nhwc_bf16x8, pw_stream_bf16 in both MFMA shapes, pw_gemm<bf16>). Four images spread over the batch; every layer against the
+    oracle applied to the GPU's OWN previous activation of those images (true per-layer error), logits against the all-oracle bf16 forward."""
+    alpha, res = cfg
+    n, pick = 512, [0, 170, 341, 511]
+    hw, net = _make_net(pkg, ctx, tmp_path, alpha, res, 1000, n)
+    net.set_dtype(pkg.DT_BF16)
+    net.keep_activations(True)
+    imgs = _headline_images(n, res, 77 + res)
+    d_in, d_out = ctx.to_device(imgs), ctx.alloc(n * 1000 * 4)
+    net.forward(d_in.ptr, d_out.ptr, n)
+    ctx.sync()
+    logits = d_out.download((n, 1, 1, 1000), np.float32)[pick]
+    oplan = orc.plan_build(alpha, res, 1000)
+    prev = imgs[pick]
+    for i in range(hw.plan.n_layers):
+        got = logits if i == hw.plan.n_layers - 1 else net.layer_output(i + 1, n, images=pick)
+        l = oplan.layer[i]
+        if l.kind == orc.L_FC:
+            w = orc.bf16_round(hw.blob[l.w_offset:l.w_offset + l.w_count]).reshape(l.out_ch, l.in_ch)
+            want = orc.f32_pointwise(prev.reshape(len(pick), -1), w, None, hw.blob[l.shift_offset:l.shift_offset + l.out_ch], orc.ACT_NONE).reshape(len(pick), 1, 1, -1)
+            assert_close(got, want, TOL_PW, "bf16 %gx%d batch-512 FC" % cfg)
+        else:
+            want = _oracle_layer(orc, oplan, hw.blob, i, prev, True)
+            assert_close(got, want, TOL_BF16, "bf16 %gx%d batch-512 layer %d" % (alpha, res, i + 1))
+        prev = got
+    full, _ = orc.net_forward(oplan, hw.blob, imgs[pick], threads=orc.num_threads(), bf16=True)
+    assert_close(logits.reshape(len(pick), 1000), np.asarray(full).reshape(len(pick), 1000), TOL_BF16_NET, "bf16 %gx%d batch-512 logits" % cfg)
     net.destroy()
 
 
@@ -1412,7 +1447,7 @@ def test_bf16_fused_stem_vs_oracle_and_separate_layers(pkg, orc, ctx, tmp_path, 
     net.forward(d_in.ptr, d_l.ptr, n)
     ctx.sync()
     full, _ = orc.net_forward(oplan, hw.blob, imgs, bf16=True)
-    assert_close(d_l.download((n, 20), np.float32), np.asarray(full).reshape(n, 20), 6e-2, "bf16 logits, fused stem")
+    assert_close(d_l.download((n, 20), np.float32), np.asarray(full).reshape(n, 20), TOL_BF16_NET, "bf16 logits, fused stem")
     net.destroy()
 
 
@@ -1727,7 +1762,7 @@ def test_headline_fp32_batch256_vs_oracle(pkg, orc, ctx, tmp_path):
 @pytest.mark.parametrize("cfg", [(1.0, 224), (0.5, 160)])
 def test_headline_bf16_batch512_vs_oracle(pkg, orc, ctx, tmp_path, cfg):
     """BASELINE.json configs[4]: bf16 storage, batch 512, at 1.0x224 and 0.5x160, default runner. Logits of four images
-    spread over the batch against the oracle's bf16-emulating forward of those images alone (6e-2 of max|ref|: rounding
+    spread over the batch against the oracle's bf16-emulating forward of those images alone (TOL_BF16_NET = 2e-2 of max|ref|; observed 4.6-5.2e-3: rounding
     flips accumulate over 28 layers, same bound as the small bf16 net tests), and batch-slot independence at full size:
     forward(512)[:16] == forward(16)."""
     alpha, res = cfg
@@ -1743,7 +1778,7 @@ def test_headline_bf16_batch512_vs_oracle(pkg, orc, ctx, tmp_path, cfg):
     pick = [0, 170, 341, 511]
     oplan = orc.plan_build(alpha, res, 1000)
     want, _ = orc.net_forward(oplan, hw.blob, imgs[pick], threads=orc.num_threads(), bf16=True)
-    assert_close(got[pick], np.asarray(want).reshape(len(pick), 1000), 6e-2, "bf16 batch-512 logits %s" % (cfg,))
+    assert_close(got[pick], np.asarray(want).reshape(len(pick), 1000), TOL_BF16_NET, "bf16 batch-512 logits %s" % (cfg,))
     d_small = ctx.alloc(16 * 1000 * 4)
     net.forward(d_in.ptr, d_small.ptr, 16)
     ctx.sync()
@@ -1908,8 +1943,11 @@ def test_bench_rccl_collectives_rehearsed_with_one_rank(pkg):
            "--no-configs-alt", "--no-cpu-variants", "--no-unfused-stages", "--no-pw-emul-alt"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
-    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    out = json.loads(r.stdout.splitlines()[-1])                         # the LAST stdout line is the record
+    assert len(r.stdout.splitlines()[-1]) < 6000
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["parity_check"]["ok"]
+    # one rank in a real RCCL group: the line proves it
+    assert out["collective_world_size"] == 1 and out["backend"] == "nccl" and len(out["ranks"]) == 1 and out["ranks"][0][2].count(":") == 2
 
 
 def _lab(ctx):
@@ -2447,12 +2485,15 @@ def test_bench_multi_rank_branch_on_one_gpu(pkg):
            "--device-override", "0", "--steps", "5", "--warmup", "1", "--batch", "16", "--alpha", "0.5", "--res", "96"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
-    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    line = r.stdout.splitlines()[-1]
     out = json.loads(line)
+    assert len(line) < 6000
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 32 and out["value"] > 0
     assert out["parity_check"]["ok"] and out["parity_check"]["images"] == 8
     assert "cpu_baseline" not in out and "configs_alt" not in out
-    assert out["profiled_steps"] == 5 and out["event_overhead_us"]["empty_pair"] >= 0
+    assert out["profiled_steps"] == 5
+    full = json.load(open(os.path.join(pkg.REPO_ROOT, out["full_record"])))
+    assert full["event_overhead_us"]["empty_pair"] >= 0 and len(full["layers"]) > 5 and full["profiled_steps_where"].startswith("after")
 
 
 def test_bench_self_launches_its_ranks(pkg):
@@ -2469,12 +2510,15 @@ def test_bench_self_launches_its_ranks(pkg):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1                                              # ONE line, rank 0's
-    out = json.loads(lines[0])
+    assert len(lines) == 1 and lines[0] == r.stdout.splitlines()[-1]    # ONE line, rank 0's, and it is the LAST thing on stdout
+    assert len(lines[0]) < 6000                                         # the 20 KB line did not fit the driver's stdout tail
+    out = json.loads(r.stdout.splitlines()[-1])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 32 and out["value"] > 0 and out["parity_check"]["ok"]
-    # the record stays self-sufficient for a reader that keeps only `roofline`: per-stage fractions inside it
-    sf = out["roofline"]["stages_frac"]
-    assert "pointwise" in sf and all(k in sf["pointwise"] for k in ("ms", "launches", "frac_hbm", "frac_mfma"))
+    # the N > 1 line proves its ranks: one entry per rank, the group's own world size, the backend
+    assert len(out["ranks"]) == 2 and [x[0] for x in out["ranks"]] == [0, 1] and out["collective_world_size"] == 2 and out["backend"] == "gloo"
+    assert out["ranks"][0][2] == out["ranks"][1][2] and all(x[3] == 16 and x[4] > 0 for x in out["ranks"])      # --device-override: the same card, said so
+    # flat per-stage triples [ms, frac_hbm, frac_mfma]; roofline holds scalars only (the driver's parser keeps scalars)
+    assert len(out["stages_frac"]["pointwise"]) == 3 and all(not isinstance(v, (dict, list)) for v in out["roofline"].values())
     import torch
     if torch.cuda.device_count() < 2:
         r = subprocess.run([sys.executable, os.path.join(pkg.REPO_ROOT, "bench.py"), "--gpus", "2", "--steps", "2"], env=env,
