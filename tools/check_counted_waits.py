@@ -2,8 +2,10 @@
 """Build-time check of the counted waits in pw_gemm (csrc/mbn_f32_pw.hip): `s_waitcnt vmcnt(NSTF); s_barrier` at the top of a tile is
 right only if the fast epilogue of the previous tile emitted EXACTLY NSTF vector-memory stores and nothing else between the next tile's
 first LDS-DMA and that wait. The source pins the order with sched_barrier(0); this script reads the ISA the compiler produced
-(tools/isa.sh mbn_f32_pw -> /tmp/isa/mbn_f32_pw.s, ~10 s) and fails when, for a GLDS kernel with a counted wait vmcnt(N):
-  * no basic block consists of exactly N `buffer_store_dword`(x2 for the paired bf16 form: `buffer_store_dword` too) and no other VMEM, or
+(tools/isa.sh mbn_f32_pw -> a temporary directory, ~10 s) and fails when, for a GLDS kernel with a counted wait vmcnt(N):
+  * no basic block consists of exactly N `buffer_store_dword`(x2 for the paired bf16 form: `buffer_store_dword` too) and no other VMEM
+    AND sits where the wait assumes it: the nearest VMEM-carrying block in front of it holds the LDS-DMA (and no store), and a counted wait
+    that leaves >= N operations in flight follows it before the next LDS-DMA (an unrelated block of N stores must not satisfy the check), or
   * some basic block holds both an LDS-DMA (`buffer_load_dwordx4 ... lds`) and a buffer store (the two were interleaved).
 The fused block kernel (csrc/mbn_f32_dwpw2.hip, waits vmcnt(NX + NST)) is checked the same way for its NST = 16 / 32 buffer_store_dwordx2.
 usage: check_counted_waits.py [isa file]   (exit 0 = ok)"""
@@ -30,41 +32,71 @@ def kernels(text, stem="pw_gemm"):
 
 
 def check(path, stem="pw_gemm", nst_of=None):
-    """nst_of: None = the counted wait's own value is the store count (pw_gemm); else a function kernel name -> store count (the fused block
-    kernel waits for NX + NST: the stores are one term of its counts)."""
+    """The invariant behind `s_waitcnt vmcnt(W); s_barrier` with W > 0: the wait must not let the LDS-DMA it guards stay in flight, and should not
+    wait for anything younger. On the kernel's control-flow graph (labels, s_branch / s_cbranch successors — the text order of the blocks is not
+    the execution order: pw_gemm's epilogue sits at the loop's end, its DMA and wait at the head), walk every path from each LDS-DMA instruction
+    forward to the next counted wait, counting the vector-memory instructions issued behind the DMA: for every counted wait W some path must carry exactly W of them (the walk
+    is path-insensitive: the waits are chosen by run-time flags such as "the previous tile took the fast epilogue", so infeasible combinations
+    show up as other counts; what must exist is the path on which the W youngest operations are exactly the ones issued behind the DMA —
+    ADVICE r4: an unrelated block of N stores elsewhere in the kernel no longer satisfies the check), and a DMA's basic block holds no stores. nst_of (fused block kernel): kernel name ->
+    NST; at least one wait must leave >= NST operations in flight, i.e. the deferred-epilogue path exists."""
     text = open(path).read()
     bad, seen = [], 0
+    is_dma = lambda l: bool(re.search(r"buffer_load_dwordx4 .* lds", l) or "global_load_lds" in l)
+    is_vm = lambda l: bool(re.match(r"\s+(buffer_|global_|flat_|scratch_)", l))
     for name, lines in kernels(text, stem):
-        waits = [int(m.group(1)) for i, l in enumerate(lines) if (m := re.search(r"s_waitcnt vmcnt\((\d+)\) lgkmcnt\(0\)", l))
-                 and i > 0 and "ASMSTART" in lines[i - 1]]
-        waits = [w for w in waits if w > 0]
+        def wait_at(k):
+            m = re.search(r"s_waitcnt vmcnt\((\d+)\) lgkmcnt\(0\)", lines[k])
+            return int(m.group(1)) if (m and k > 0 and "ASMSTART" in lines[k - 1]) else None
+        waits = [w for k in range(len(lines)) if (w := wait_at(k))]
         if not waits:
             continue
         seen += 1
-        n = nst_of(name) if nst_of else waits[0]
-        if nst_of and not any(w >= n for w in waits):
-            bad.append("%s: no counted wait leaves %d stores in flight (waits %s)" % (name, n, sorted(set(waits))))
-        blocks, cur = [], []
-        for l in lines:
+        if nst_of and not any(w >= nst_of(name) for w in waits):
+            bad.append("%s: no counted wait leaves %d stores in flight (waits %s)" % (name, nst_of(name), sorted(set(waits))))
+        label = {m.group(1): k for k, l in enumerate(lines) if (m := re.match(r"^(\.LBB\w+):", l))}
+        def succ(k):
+            l = lines[k]
+            m = re.search(r"\bs_(c?)branch\w*\s+(\.LBB\w+)", l)
+            if m:
+                return ([label[m.group(2)]] if m.group(2) in label else []) + ([k + 1] if m.group(1) else [])
+            return [] if "s_endpgm" in l else [k + 1]
+        starts = [k for k, l in enumerate(lines) if is_dma(l)]
+        seen_state, stack, checked, reached = set(), [(k + 1, 0) for k in starts], 0, {}
+        while stack:
+            k, cnt = stack.pop()
+            if k >= len(lines) or (k, cnt) in seen_state or cnt > 200:
+                continue
+            seen_state.add((k, cnt))
+            l = lines[k]
+            if is_dma(l):
+                continue                                    # a younger DMA: its own walk starts there
+            w = wait_at(k)
+            if w is not None:
+                if w > 0:
+                    checked += 1
+                    reached.setdefault(w, set()).add(cnt)
+                continue                                    # this wait ends the DMA's exposure (w == 0 drains everything)
+            if re.search(r"s_waitcnt vmcnt\(0\)", l) or "s_waitcnt_vscnt" in l:
+                continue
+            for nk in succ(k):
+                stack.append((nk, cnt + (1 if is_vm(l) else 0)))
+        if checked == 0:
+            bad.append("%s: no path from an LDS-DMA reaches a counted wait" % name)
+        for w, cnts in reached.items():
+            if w not in cnts:
+                bad.append("%s: no path issues exactly %d vector-memory instructions between an LDS-DMA and `s_waitcnt vmcnt(%d)` (seen: %s)"
+                           % (name, w, w, sorted(cnts)[:8]))
+        blk = []                                            # and the DMA group is never interleaved with stores inside one basic block
+        for l in lines + [".LBB_end:"]:
             if re.match(r"^\.LBB", l) or re.search(r"\bs_c?branch", l):
-                blocks.append(cur)
-                cur = []
-            cur.append(l)
-        blocks.append(cur)
-        exact = False
-        for b in blocks:
-            vm = [l.split()[0] for l in b if re.match(r"\s+(buffer_|global_|flat_|scratch_)", l)]
-            stores = [v for v in vm if v.startswith("buffer_store")]
-            dma = [l for l in b if re.search(r"buffer_load_dwordx4 .* lds", l) or "global_load_lds" in l]
-            if stores and dma:
-                bad.append("%s: a block interleaves LDS-DMA and buffer stores" % name)
-            if stores and len(stores) == n and len(vm) == n:
-                exact = True
-        if not exact:
-            bad.append("%s: counted wait vmcnt(%d) but no block of exactly %d buffer stores" % (name, n, n))
+                if any(is_dma(x) for x in blk) and any(x.split()[0].startswith("buffer_store") for x in blk if is_vm(x)):
+                    bad.append("%s: a block interleaves LDS-DMA and buffer stores" % name)
+                blk = []
+            blk.append(l)
     if seen == 0:
-        bad.append("no pw_gemm kernel with a counted wait found in %s" % path)
-    return seen, bad
+        bad.append("no %s kernel with a counted wait found in %s" % (stem, path))
+    return seen, sorted(set(bad))
 
 
 def dwpw2_nst(name):
@@ -73,13 +105,16 @@ def dwpw2_nst(name):
 
 
 if __name__ == "__main__":
-    path = sys.argv[1] if len(sys.argv) > 1 else "/tmp/isa/mbn_f32_pw.s"
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix="mbn_isa_")
+    path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(tmp, "mbn_f32_pw.s")
     if len(sys.argv) <= 1:
-        subprocess.check_call(["bash", os.path.join(ROOT, "tools", "isa.sh"), "mbn_f32_pw"], stdout=subprocess.DEVNULL)
-        subprocess.check_call(["bash", os.path.join(ROOT, "tools", "isa.sh"), "mbn_f32_dwpw2"], stdout=subprocess.DEVNULL)
+        env = dict(os.environ, ISA_OUT=tmp)
+        subprocess.check_call(["bash", os.path.join(ROOT, "tools", "isa.sh"), "mbn_f32_pw"], stdout=subprocess.DEVNULL, env=env)
+        subprocess.check_call(["bash", os.path.join(ROOT, "tools", "isa.sh"), "mbn_f32_dwpw2"], stdout=subprocess.DEVNULL, env=env)
     seen, bad = check(path)
     if len(sys.argv) <= 1:
-        s2, b2 = check("/tmp/isa/mbn_f32_dwpw2.s", "dwpw2_f32", dwpw2_nst)
+        s2, b2 = check(os.path.join(tmp, "mbn_f32_dwpw2.s"), "dwpw2_f32", dwpw2_nst)
         print("%d fused block kernels with counted waits checked" % s2)
         if s2 == 0:
             b2.append("no dwpw2_f32 kernel with a counted wait found")
