@@ -83,16 +83,24 @@ __device__ __forceinline__ void mbn_store_relu6_f32_pair(__amdgpu_buffer_rsrc_t 
     for (int t = 0; t < NI / 2; t++) {
         const f2e sc = *reinterpret_cast<const f2e *>(scale + col0 + 64 * t + 2 * li);
         const f2e sh = *reinterpret_cast<const f2e *>(shift + col0 + 64 * t + 2 * li);
+        const f2e scx = f2e{ sc.x, sc.x }, scy = f2e{ sc.y, sc.y }, shx = f2e{ sh.x, sh.x }, shy = f2e{ sh.y, sh.y };
 #pragma unroll
         for (int mi = 0; mi < MI; mi++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const unsigned ro = row0 + mi * 32 + (r & 3) + 8 * (r >> 2);               // + 4*lh per lane
-                const f2e v = f2e{ fminf(fmaxf(fmaf(acc[mi][2 * t][r], sc.x, sh.x), 0.f), 6.f),
-                                   fminf(fmaxf(fmaf(acc[mi][2 * t + 1][r], sc.y, sh.y), 0.f), 6.f) };
-                const unsigned soff = (ro * ldc + (unsigned)(col0 + 64 * t)) * 4u;         // wave-uniform bytes
-                if (MODE == 0) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2e, v), out, lane_off, soff, 0);
-                else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2e, v), out, lane_off + soff, 0, 0);
+            for (int r = 0; r < 16; r += 2) {
+                // round 5: the BN of rows r, r + 1 of one channel is ONE v_pk_fma_f32 (the two accumulators are adjacent registers, scale and shift
+                // broadcast); the clamps write each value where its store wants it, so the channel pairing costs nothing. Same fma, same clamp: same bits.
+                const f2e p0 = __builtin_elementwise_fma(f2e{ acc[mi][2 * t][r], acc[mi][2 * t][r + 1] }, scx, shx);
+                const f2e p1 = __builtin_elementwise_fma(f2e{ acc[mi][2 * t + 1][r], acc[mi][2 * t + 1][r + 1] }, scy, shy);
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int rr = r + h;
+                    const unsigned ro = row0 + mi * 32 + (rr & 3) + 8 * (rr >> 2);         // + 4*lh per lane
+                    const f2e v = f2e{ fminf(fmaxf(h ? p0.y : p0.x, 0.f), 6.f), fminf(fmaxf(h ? p1.y : p1.x, 0.f), 6.f) };
+                    const unsigned soff = (ro * ldc + (unsigned)(col0 + 64 * t)) * 4u;     // wave-uniform bytes
+                    if (MODE == 0) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2e, v), out, lane_off, soff, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2e, v), out, lane_off + soff, 0, 0);
+                }
             }
     }
 }

@@ -62,8 +62,11 @@ struct DwPw2Args {
     unsigned in_bytes, wp_bytes;
     int stagger;            // start delay of a workgroup in units of 1024 cycles x its phase (see the kernel): 0 = all workgroups in phase
     int dbg;                // experiments (tune dwpw_variant = 100 + bits): 1 = no x loads after the first, 2 = no depthwise math, 4 = no output stores, 128 = x loads as one burst (before: -2.5 %), 256 = no s_setprio around the depthwise part (-1 %),
-                            // 8 = no filter DMA, 16 = no MFMA, 32 = unpaired column blocks (4-byte stores)
+                            // 8 = no filter DMA, 16 = no MFMA, 32 = unpaired column blocks (4-byte stores); round 5 (timing only): 1024 = no tap reads after the first chunk,
+                            // 2048 = only the first fragment read of a step (the MFMAs reuse registers), 4096 = no barrier (waits only), 8192 = no epilogue arithmetic/zeroing either (with 4)
     unsigned wo_m, wo_s, ho_m, ho_s;   // floor(v / wo) = umulhi(v, wo_m) >> wo_s for v < 2^31 (m == 0: the divisor is 1)
+    int fast_off;           // launcher: 1 = the FO instantiation (set_offsets in its full-rate form: input < 0x70000000 bytes); 0 = the general form (rounds 2-4; lab A/B: exp0 = 51)
+    float inv_wo, inv_ho;   // 1 / wo, 1 / ho
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return (row << 5) + (((chunk ^ (row >> 1)) & 7) << 2); }
@@ -109,10 +112,21 @@ __device__ __forceinline__ void dma_filter(__amdgpu_buffer_rsrc_t rsrc, float *l
 // ahead of the barrier behind which the depthwise part starts — so part of every window waits out its HBM latency inside D (stamps, profiles/r02/g_*:
 // D 1283 cycles for ~54 VALU instructions). Two ahead, every load has a whole step (~7 k cycles) before the barrier that (vmcnt in order) completes it.
 // Costs 4 NX VGPRs: fits next to the taps (PRE) for S = 1 / BN = 128, with the taps read inside the step (PRE = false) for S = 1 / BN = 256 and S = 2 / BN = 128.
-template <int S, int BN, bool PRE, bool DBG, int NW = 8, bool XA2 = false>
+// IL (round 5, the shipped form): the depthwise part of a step is no longer one VALU burst in front of the MFMAs. The stamps (profiles/r02/g_*) show what the
+// burst form does on a SIMD with two waves: both waves run their depthwise parts at the same time right behind the barrier (no MFMA in flight: every LDS /
+// vector-memory / scalar instruction and every wait of that part is exposed), then their MFMA parts one after the other (waves 0-3: M 2300 cycles + 2600-4000
+// waiting at the barrier; waves 4-7 the reverse). A VALU instruction gets no issue slot beside another wave's MFMA stream and costs its issue time on top of
+// the wave's own (tools/micro/mfma_valu_*), so VALU time adds whatever the order — but everything else need not. Here the part is cut by filter row: row dy's
+// 12 v_pk_fma + the reload of the x row they consumed sit in front of MFMA group dy, BN + ReLU6 + the two LDS writes in front of group 3; the filter DMA opens
+// the step. The two waves fall one group apart by themselves (one's MFMA group runs while the other does its loads, LDS reads, scalar work and waits) and the
+// matrix pipe has work at every point of the step. Same fma order: bit-identical. The last step of a workgroup issues its DMA / loads on stale cursors
+// (valid addresses, results unused) instead of branching around them: the counted waits are the same in every step.
+// FO: set_offsets in its full-rate form (see there); the launcher takes the FO = false instantiation for inputs outside that form's range.
+template <int S, int BN, bool PRE, bool DBG, int NW = 8, bool XA2 = false, bool IL = false, bool FO = false>
 __global__ __launch_bounds__(64 * NW) void dwpw2_f32(DwPw2Args a)
 {
     static_assert(!XA2 || (!DBG && NW == 8), "XA2: shipped 8-wave form only");
+    static_assert(!IL || (NW == 8 && !XA2), "IL: 8-wave form only (DBG: stamps, dwpw_variant = 164 + 1024 ... in the lab build)");
     const int dbg = DBG ? a.dbg : 0;
     constexpr int NT = 64 * NW, BM = 16 * NW;
     constexpr int WN = 64, WM = BN == 256 ? 64 : 32;   // wave tile: 8 waves as 2 x 4 (BN 256) or 4 x 2 (BN 128)
@@ -181,7 +195,7 @@ __global__ __launch_bounds__(64 * NW) void dwpw2_f32(DwPw2Args a)
     const float *sk = sb_s + c4 * 4;
 
     unsigned off[3][XC];
-    auto set_offsets = [&](unsigned m0) __attribute__((always_inline)) {
+    auto set_offsets_general = [&](unsigned m0) __attribute__((always_inline)) {
         const unsigned m = m0 + 2 * pair;
         const bool mok = m < mtot;
         const unsigned q = a.wo_m ? __umulhi(m, a.wo_m) >> a.wo_s : m;
@@ -200,6 +214,44 @@ __global__ __launch_bounds__(64 * NW) void dwpw2_f32(DwPw2Args a)
                 off[dy][j] = ok ? base + dy * rs + j * cs : OOB;
             }
         }
+    };
+    // Round 5: the same offsets from full-rate instructions. The stamps of the general form (profiles/r05/d_*) read ~1100-1250 cycles per tile for it on a
+    // SIMD's two waves: two v_mul_hi_u32 and six v_mul_lo_u32 (quarter rate), a 64-bit mad, and 12-15 compare / select pairs under exec-mask branches.
+    // Here: (n, y, x) of the tile's first pixel on the scalar unit (magic division); the lane's own pixel from it by two float reciprocal divisions of
+    // small numbers (r < wo + 128, exact: (r + 0.5) / wo is >= 0.5 / wo away from an integer, the float error is < 2e-5); ONE 32-bit multiply for the
+    // byte offset; validity separable by row and column: off[dy][j] = rowv[dy] + colv[j] where an invalid row is 0x80000000 and an invalid column
+    // 0x70000000, so that any sum with an invalid term lies in [0x70000000, 0xF0005000) — beyond the descriptor's num_records (launch2 takes this form
+    // only for inputs < 0x70000000 bytes) and without wrapping. Same offsets for every valid tap, zeros for every other: bit-identical results.
+    auto set_offsets_fast = [&](unsigned m0) __attribute__((always_inline)) {
+        const unsigned q0 = a.wo_m ? __umulhi(m0, a.wo_m) >> a.wo_s : m0;                    // wave-uniform: scalar unit
+        const unsigned x0 = m0 - q0 * (unsigned)a.wo;
+        const unsigned n0 = a.ho_m ? __umulhi(q0, a.ho_m) >> a.ho_s : q0;
+        const unsigned y0 = q0 - n0 * (unsigned)a.ho;
+        const unsigned r = x0 + 2u * (unsigned)pair;
+        const unsigned q1 = (unsigned)__builtin_fmaf((float)r, a.inv_wo, 0.5f * a.inv_wo);
+        const unsigned x = r - q1 * (unsigned)a.wo;                                       // q1 < 2^8, wo < 2^16: mul24 range
+        const unsigned yy = y0 + q1;
+        const unsigned q2 = (unsigned)__builtin_fmaf((float)yy, a.inv_ho, 0.5f * a.inv_ho);
+        const unsigned y = yy - q2 * (unsigned)a.ho;
+        const unsigned n = n0 + q2;
+        const bool mok = m0 + 2u * (unsigned)pair < mtot;
+        const int iy0 = (int)y * S - a.pad_top, ix0 = (int)x * S - a.pad_left;
+        const unsigned cs = (unsigned)a.cin * 4u, rs = (unsigned)a.w * cs;
+        const int pix = __mul24((int)(n * (unsigned)a.h) + iy0, a.w) + ix0;               // (n h + iy0) < 2^23 (launch2 checks), w < 2^16
+        const unsigned base = (unsigned)pix * cs + (unsigned)(c4 * 4) * 4u;
+        unsigned rowv[3], colv[XC];
+#pragma unroll
+        for (int dy = 0; dy < 3; dy++) rowv[dy] = (mok && (unsigned)(iy0 + dy) < (unsigned)a.h) ? base + dy * rs : 0x80000000u;
+#pragma unroll
+        for (int j = 0; j < XC; j++) colv[j] = ((unsigned)(ix0 + j) < (unsigned)a.w) ? j * cs : 0x70000000u;
+#pragma unroll
+        for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+            for (int j = 0; j < XC; j++) off[dy][j] = rowv[dy] + colv[j];
+    };
+    auto set_offsets = [&](unsigned m0) __attribute__((always_inline)) {
+        if constexpr (FO) set_offsets_fast(m0);
+        else set_offsets_general(m0);
     };
     f4 xr[XA2 ? 2 : 1][3][XC];
     auto ldx_set = [&](int kc, const int set) __attribute__((always_inline)) {
@@ -261,6 +313,43 @@ __global__ __launch_bounds__(64 * NW) void dwpw2_f32(DwPw2Args a)
         *reinterpret_cast<f4 *>(a_s0 + buf * ABUF + aw1) = bn_relu6(acc1, wreg[9], wreg[10]);
     };
     auto dw = [&](int kc, const int buf) __attribute__((always_inline)) { dw_set(kc, buf, 0); };
+    // IL: the same arithmetic in pieces. ldx_row: the XC loads of one window row; dw_row: that row's taps into the two running sums (dy = 0 starts them);
+    // dw_fin: BN + ReLU6 + the two A-tile writes.
+    f4 dacc0 = f4{ 0.f, 0.f, 0.f, 0.f }, dacc1 = dacc0;
+    auto ldx_row = [&](int kc, const int dy) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < XC; j++)
+            xr[0][dy][j] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(irsrc, off[dy][j], kc * 128, 0));
+    };
+    // taps just in time (IL): one filter row (3 x f4) in registers at a time — row dy + 1 is read from LDS right behind the FMAs of row dy and has a
+    // whole MFMA group to arrive; scale / shift behind row 2; row 0 of the next chunk behind dw_fin. 20 VGPRs instead of wreg's 44 (190 instead of 208 for
+    // the 128-column tile). Same 11 ds_read_b128 per step.
+    f4 wrow[3], wss[2];
+    auto ldw_row = [&](int kc, const int dy) __attribute__((always_inline)) {
+#pragma unroll
+        for (int dx = 0; dx < 3; dx++) wrow[dx] = *reinterpret_cast<const f4 *>(wk + kc * 32 + (dy * 3 + dx) * a.cin);
+    };
+    auto ldw_ss = [&](int kc) __attribute__((always_inline)) {
+        wss[0] = *reinterpret_cast<const f4 *>(sk + kc * 32);
+        wss[1] = *reinterpret_cast<const f4 *>(sk + a.cin + kc * 32);
+    };
+    auto dw_row = [&](int kc, const int dy) __attribute__((always_inline)) {
+        if (dy == 0) {
+            dacc0 = f4{ 0.f, 0.f, 0.f, 0.f };
+            dacc1 = dacc0;
+        }
+#pragma unroll
+        for (int dx = 0; dx < 3; dx++) {
+            dacc0 = __builtin_elementwise_fma(xr[0][dy][dx], wrow[dx], dacc0);
+            dacc1 = __builtin_elementwise_fma(xr[0][dy][dx + S], wrow[dx], dacc1);
+        }
+        if (dy < 2) ldw_row(kc, dy + 1);
+        else ldw_ss(kc);
+    };
+    auto dw_fin = [&](const int buf) __attribute__((always_inline)) {
+        *reinterpret_cast<f4 *>(a_s0 + buf * ABUF + aw0) = bn_relu6(dacc0, wss[0], wss[1]);
+        *reinterpret_cast<f4 *>(a_s0 + buf * ABUF + aw1) = bn_relu6(dacc1, wss[0], wss[1]);
+    };
 
     f16v acc[MI][NI];
     f4 fa[2][MI], fb[2][NI];
@@ -319,8 +408,9 @@ __global__ __launch_bounds__(64 * NW) void dwpw2_f32(DwPw2Args a)
     }
     if (validD) {
         ldx_set(kD, XA2 ? 1 : 0);             // chunk 1 -> x set 1 (XA2) / the one set
-        if (PRE) ldw(kD);
+        if (PRE && !IL) ldw(kD);
     }
+    if constexpr (IL) ldw_row(kD, 0);         // IL: filter row 0 of the chunk the first step works on (kD = 0 when there is none: never used)
     if constexpr (XA2) {
         vbL = vbD; kL = kD + 1; m0L = m0D; n0L = n0D; validL1 = validD;
         if (validL1 && kL >= nk) {
@@ -393,7 +483,7 @@ __global__ __launch_bounds__(64 * NW) void dwpw2_f32(DwPw2Args a)
         __builtin_amdgcn_sched_barrier(0);                                                                              \
         if (pendE) {                                                                                                    \
             if (!(dbg & 4)) epilogue(m0E, n0E);                                                                       \
-            zero_acc();                                                                                                 \
+            if (!(dbg & 8192)) zero_acc();                                                                              \
             pendE = false;                                                                                              \
         }                                                                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                              \
@@ -401,7 +491,7 @@ __global__ __launch_bounds__(64 * NW) void dwpw2_f32(DwPw2Args a)
         STAMP(2);                                                                                                       \
         if (!(dbg & 16)) {                                                                                            \
         _Pragma("unroll") for (int g = 0; g < 3; g++) {                                                                 \
-            ldfrag(P, g + 1, (g + 1) & 1);                                                                              \
+            if (!(dbg & 2048)) ldfrag(P, g + 1, (g + 1) & 1);                                                           \
             if (spreadL) ldx_part(kL, g);                                                                               \
             __builtin_amdgcn_sched_barrier(0);                                                                          \
             mfma_group(g & 1);                                                                                          \
@@ -412,8 +502,9 @@ __global__ __launch_bounds__(64 * NW) void dwpw2_f32(DwPw2Args a)
         mfma_group(1);                                                                                                  \
         }                                                                                                               \
         STAMP(3);                                                                                                       \
-        if (PRE && validL) ldw(kL);                                                                                     \
-        if (validL) { if (didE) lds_barrier<NX + NST>(); else lds_barrier<NX>(); }                                      \
+        if (PRE && validL && !(dbg & 1024)) ldw(kL);                                                                    \
+        if (dbg & 4096) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }                                 \
+        else if (validL) { if (didE) lds_barrier<NX + NST>(); else lds_barrier<NX>(); }                                 \
         else { if (didE) lds_barrier<NST>(); else lds_barrier<0>(); }                                                   \
         STAMP(4);                                                                                                       \
         if (kM == nk - 1) { pendE = true; m0E = m0M; n0E = n0M; }      /* stored in the next step (or behind the loop) */ \
@@ -474,7 +565,68 @@ __global__ __launch_bounds__(64 * NW) void dwpw2_f32(DwPw2Args a)
         vbL = vbL2; kL = kL2; m0L = m0L2; n0L = n0L2; validL1 = validL2;                                                \
     }
 
-    if constexpr (XA2) {
+    // IL step with the MFMA chunk in buffer P (see the template comment). Vector-memory order inside a step: filter DMA (B_LD pieces), [NST stores of the
+    // previous tile], NX x loads — so the barrier's wait for the DMA leaves exactly the NX (+ NST) youngest operations in flight, in every step.
+    // Measured and NOT taken (round 5, profiles/r05/g_*, h_*): the step in which a tile's epilogue runs is +2000 cycles on block 6-7 and +5000 on block 4-5
+    // (stamps) — the 8 waves' 128 store instructions go through the CU's one texture unit right behind the barrier with no MFMA in flight. Computing the
+    // tile's 32 outputs into temporaries and issuing the stores four at a time under the MFMA groups needs 32 more live VGPRs; with the second loop body it
+    // takes the compiler stops updating the accumulators in place (two sets of 32, alternating by step) and spills 10-125 VGPRs, and every scratch reload is
+    // a `s_waitcnt vmcnt(0)` that drains the x loads: block 6-7 0.31 -> 0.34 ms, block 4-5 0.245 -> 0.50 ms. Left as the next thing to try with the MFMAs
+    // pinned in place.
+#define MBN_DWPW2_IL_GROUP(P, G)                                                                                        \
+        ldfrag(P, (G) + 1, ((G) + 1) & 1);                                                                              \
+        dw_row(kD, G);                                                                                                  \
+        ldx_row(kL, G);                                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+        mfma_group((G) & 1);                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);
+
+#define MBN_DWPW2_STEP_IL(P)                                                                                            \
+    {                                                                                                                   \
+        STAMP(0);                                                                                                       \
+        ldfrag(P, 0, 0);                                                                                                \
+        int vbL = vbD, kL = kD + 1, n0L = n0D;                                                                          \
+        unsigned m0L = m0D;                                                                                             \
+        bool validL = validD;                                                                                           \
+        if (kL >= nk) {                                                                                                 \
+            kL = 0; vbL += gridDim.x; validL = validD && vbL < nwg;                                                     \
+            if (validL) { origin(vbL, m0L, n0L); set_offsets(m0L); }                                                    \
+        }                                                                                                               \
+        dma_filter<B_LD, NT, BN>(wrsrc, b_s0 + (P ^ 1) * BBUF, b_vo, (n0D * a.cin + kD * 32) * 4, wave_u);              \
+        STAMP(1);                                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+        const bool didE = pendE;                                                                                        \
+        if (pendE) {                                                                                                    \
+            epilogue(m0E, n0E);                                                                                         \
+            zero_acc();                                                                                                 \
+            pendE = false;                                                                                              \
+        }                                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+        STAMP(2);                                                                                                       \
+        MBN_DWPW2_IL_GROUP(P, 0)                                                                                        \
+        MBN_DWPW2_IL_GROUP(P, 1)                                                                                        \
+        MBN_DWPW2_IL_GROUP(P, 2)                                                                                        \
+        dw_fin(P ^ 1);                                                                                                  \
+        ldw_row(kL, 0);                                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+        mfma_group(1);                                                                                                  \
+        STAMP(3);                                                                                                       \
+        if (didE) lds_barrier<NX + NST>(); else lds_barrier<NX>();                                                      \
+        STAMP(4);                                                                                                       \
+        if (kM == nk - 1) { pendE = true; m0E = m0M; n0E = n0M; }      /* stored in the next step (or behind the loop) */ \
+        STAMP(5);                                                                                                       \
+        stepno++;                                                                                                       \
+        if (!validD) break;                                                                                             \
+        vbM = vbD; kM = kD; m0M = m0D; n0M = n0D;                                                                       \
+        vbD = vbL; kD = kL; m0D = m0L; n0D = n0L; validD = validL;                                                      \
+    }
+
+    if constexpr (IL) {
+        for (;;) {
+            MBN_DWPW2_STEP_IL(0)
+            MBN_DWPW2_STEP_IL(1)
+        }
+    } else if constexpr (XA2) {
         for (;;) {
             MBN_DWPW2_STEP2(0)
             MBN_DWPW2_STEP2(1)
@@ -488,6 +640,8 @@ __global__ __launch_bounds__(64 * NW) void dwpw2_f32(DwPw2Args a)
     if (pendE && !(dbg & 4)) epilogue(m0E, n0E);               // the workgroup's last tile
 #undef MBN_DWPW2_STEP
 #undef MBN_DWPW2_STEP2
+#undef MBN_DWPW2_STEP_IL
+#undef MBN_DWPW2_IL_GROUP
 #undef STAMP
 }
 
@@ -519,15 +673,21 @@ void launch2(DwPw2Args &a, hipStream_t s, int num_cus, bool pre)
             if (g_mbn_tune.dwpw_variant == 8) { hipLaunchKernelGGL((dwpw2_f32<S, BN, false, false, 8, true>), dim3((unsigned)grid), dim3(NT), 0, s, a); return; }
         }
     }
+    if (a.dbg & 16384) {                                                     // r5: the stamps (bit 64) in the interleaved form
+        if constexpr (BN == 128) { hipLaunchKernelGGL((dwpw2_f32<S, BN, true, true, 8, false, true, true>), dim3((unsigned)grid), dim3(NT), 0, s, a); return; }
+    }
     if (a.dbg) {
         if (pre) hipLaunchKernelGGL((dwpw2_f32<S, BN, true, true>), dim3((unsigned)grid), dim3(NT), 0, s, a);
         else hipLaunchKernelGGL((dwpw2_f32<S, BN, false, true>), dim3((unsigned)grid), dim3(NT), 0, s, a);
         return;
     }
     if (!pre) { hipLaunchKernelGGL((dwpw2_f32<S, BN, false, false>), dim3((unsigned)grid), dim3(NT), 0, s, a); return; }
+    if (g_mbn_tune.dwpw_variant == 9) { hipLaunchKernelGGL((dwpw2_f32<S, BN, true, false>), dim3((unsigned)grid), dim3(NT), 0, s, a); return; }   // r5 A/B: the burst form (rounds 2-4)
 #endif
     (void)pre;
-    hipLaunchKernelGGL((dwpw2_f32<S, BN, true, false>), dim3((unsigned)grid), dim3(NT), 0, s, a);
+    constexpr bool FOK = BN == 128;                    // the 256-column shapes are at the 256-VGPR limit without it (spills with): general offsets there
+    if (FOK && a.fast_off) hipLaunchKernelGGL((dwpw2_f32<S, BN, true, false, 8, false, true, FOK>), dim3((unsigned)grid), dim3(NT), 0, s, a);
+    else hipLaunchKernelGGL((dwpw2_f32<S, BN, true, false, 8, false, true, false>), dim3((unsigned)grid), dim3(NT), 0, s, a);
 }
 
 }   // namespace
@@ -549,6 +709,11 @@ int mbn_launch_f32_dwpw2(mbn_context *ctx, hipStream_t stream, float *out, const
     a.in_bytes = (unsigned)(4.0 * batch * in_rows * in_cols * cin);
     a.wp_bytes = (unsigned)(4.0 * cin * cout);
     a.dbg = variant >= 100 ? variant - 100 : 0;
+    a.inv_wo = 1.0f / (float)out_cols;
+    a.inv_ho = 1.0f / (float)out_rows;
+    // the full-rate offsets need every input byte offset below the invalid-column constant, and (n h + iy0) in mul24 range
+    a.fast_off = (4.0 * batch * in_rows * in_cols * cin < (double)0x70000000u && (double)batch * in_rows < 8388000.0 && in_cols < 32768 &&
+                  out_cols < 32768 && g_mbn_tune.exp0 != 51) ? 1 : 0;
     a.stagger = g_mbn_tune.exp2;                                             // lab: start stagger of the workgroups in kcycles per phase
     const bool pre = variant != 3;                                       // 3: taps read from LDS inside the step (A/B hook)
     // 256-column tiles only when they alone fill the chip (see mbn_dwpw_fused); pw_tile=1: force the 128-column tile (A/B hook)
