@@ -130,6 +130,58 @@ def stage_table(plan, pkg, launches, layer_ms, batch, act_bytes, mfma_peak):
     return stages, per_layer, stage_of
 
 
+def sample_power(step, sync, seconds=1.5):
+    """Package power and core clock while `step` runs back to back for `seconds` (AFTER the timed region, never inside it): `rocm-smi --showpower
+    --showclocks --json` sampled every ~40 ms from a thread. Round 5 found the step at the package power limit (1350-1390 W of 1400 W:
+    profiles/r05/l_power_probe_net.txt), which is what holds the clock under the fp32 MFMA stream. Returns None when rocm-smi is not usable."""
+    import re
+    import shutil
+    import subprocess
+    import threading
+    if not shutil.which("rocm-smi"):
+        return None
+    samples, stop = [], threading.Event()
+
+    def sampler():
+        while not stop.is_set():
+            try:
+                r = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=5)
+                c = json.loads(r.stdout)
+                c = c[sorted(c)[0]]
+                m = re.search(r"(\d+)", c.get("sclk clock speed:", ""))
+                samples.append((time.time(), float(c.get("Current Socket Graphics Package Power (W)", "nan")), float(m.group(1)) if m else float("nan")))
+            except Exception:
+                pass
+            time.sleep(0.04)
+
+    cap = None
+    try:
+        r = subprocess.run(["rocm-smi", "--showmaxpower", "--json"], capture_output=True, text=True, timeout=10)
+        c = json.loads(r.stdout)
+        c = c[sorted(c)[0]]
+        cap = float(next(v for k, v in c.items() if "Max" in k and "Power" in k))
+    except Exception:
+        pass
+    th = threading.Thread(target=sampler, daemon=True)
+    th.start()
+    t0 = time.time()
+    n = 0
+    while time.time() - t0 < seconds:
+        for _ in range(20):
+            step()
+        sync()
+        n += 20
+    t1 = time.time()
+    stop.set()
+    th.join(timeout=6)
+    mine = sorted((p, c) for (t, p, c) in samples if t0 + 0.4 <= t <= t1 and p == p)
+    if len(mine) < 3:
+        return None
+    return {"package_w": mine[len(mine) // 2][0], "cap_w": cap, "sclk_mhz": sorted(c for _, c in mine)[len(mine) // 2], "samples": len(mine),
+            "ms_per_step_while_sampling": round(1000.0 * (t1 - t0) / n, 4),
+            "how": "median of rocm-smi samples while the step ran back to back for %.1f s after the timed region" % seconds}
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -172,6 +224,7 @@ def parse_args(argv=None):
     ap.add_argument("--profile-steps", type=int, default=5,
                     help="forwards AFTER the timed region whose kernels are timed one by one (HIP event pair per launch, one stream): "
                          "the evidence behind `roofline` and `stages_frac`. Never inside the region `value` comes from")
+    ap.add_argument("--no-power", action="store_true", help="skip the untimed ~1.5 s loop that samples package power / core clock with rocm-smi")
     ap.add_argument("--record", default="", help="path of the full record (default: gpurun_out/bench_full_<workload>.json under the repo)")
     args = ap.parse_args(argv)
     if args.streams <= 0:
@@ -256,9 +309,9 @@ def compact_line(out, record_path=None):
         line["step_ms"] = [out["step_ms"]["median"], out["step_ms"]["p10"], out["step_ms"]["p90"]]
     ca = out.get("configs_alt")
     if ca:
-        line["configs_alt"] = {name: [_r(c.get("value"), 1), _r((c.get("roofline") or {}).get("frac")), (c.get("parity_check") or {}).get("ok")]
-                               for name, c in ca.items()}
-        line["configs_alt_cols"] = "images_per_sec,roofline_frac(bf16: pointwise of 8 TB/s; f32: of mfma peak),parity_ok"
+        line["configs_alt"] = {name: [_r(c.get("value"), 1), _r((c.get("roofline") or {}).get("frac")), (c.get("parity_check") or {}).get("ok"),
+                                      (c.get("power") or {}).get("package_w")] for name, c in ca.items()}
+        line["configs_alt_cols"] = "images_per_sec,roofline_frac(bf16: pointwise of 8 TB/s; f32: of mfma peak),parity_ok,package_w"
     alt = out.get("pw_emul_alt")
     if alt:
         line["pw_emul_alt"] = [_r(alt["value"], 1), (alt.get("parity_check") or {}).get("ok")]
@@ -366,7 +419,7 @@ def configs_alt(args, env):
         a.cpu_images = 1 if a.batch == 1 else 8
         o = run_one(a, env)
         keep = ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "roofline", "stages", "sum_kernel_ms",
-                "profiled_steps", "event_overhead_us", "step_ms", "parity_check")
+                "profiled_steps", "event_overhead_us", "step_ms", "parity_check", "power")
         res[name] = {k: o[k] for k in keep if k in o}
     return res
 
@@ -492,6 +545,10 @@ def run_one(args, env):
         if multi:
             net.set_streams(args.streams, free_running=True)
 
+    power = None
+    if world == 1 and not args.no_power and not args.graph:
+        power = sample_power(lambda: net.forward(d_in.ptr, d_out.ptr, args.batch), ctx.sync, 1.0 if args.batch == 1 else 1.5)
+
     # ---- the opt-in split form of the pointwise GEMM beside the default line (N = 1, fp32): same net, same buffers, same
     # stream configuration, 3 warm-up + 10 timed steps without per-kernel events. Never part of `value`.
     alt = None
@@ -611,6 +668,11 @@ def run_one(args, env):
                 out["ranks_error"] = "two ranks held the same GPU (PCI bus ids %s) without --device-override" % buses
             if len(ranks_info) != world:
                 out["ranks_error"] = "the process group has %d ranks, the line claims %d" % (len(ranks_info), world)
+        if power is not None:
+            out["power"] = power
+            if "roofline" in out:       # scalars the driver's record keeps: the step runs at the package power limit, which sets the held clock
+                out["roofline"]["package_power_w"] = power["package_w"]
+                out["roofline"]["power_cap_w"] = power["cap_w"]
         out["h2d_ms_per_batch"] = round(h2d_ms, 3)   # PCIe-inclusive rate = batch / (ms_per_step + this)
         if step_ms.size:
             out["step_ms"] = {"median": round(float(np.median(step_ms)), 4), "p10": round(float(np.percentile(step_ms, 10)), 4),

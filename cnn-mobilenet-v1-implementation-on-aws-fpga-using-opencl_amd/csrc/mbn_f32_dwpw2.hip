@@ -45,6 +45,7 @@ constexpr int BKF = 32;
 constexpr int BM8 = 128;                       // rows of the shipped 8-wave tile (2 waves per SIMD, 256 VGPRs each); the 16-wave lab form: 256
 constexpr int NOUT = 1024;                     // widest pointwise output whose scale/shift the LDS copy holds
 constexpr int CMAX = 1024;                     // largest Cin (depthwise constants resident in LDS: 44 KB)
+constexpr int CMAX4 = 256, NOUT4 = 256;        // ... of the 4-wave form (two workgroups per CU: 66 KB of LDS each)
 constexpr unsigned OOB = 0xF0000000u;          // byte offset beyond any supported tensor: the load returns zeros
 
 // In-kernel stamps (diagnostic: dwpw_variant = 100 + 64): workgroup 0 records s_memtime at five points of its first 96 steps,
@@ -126,7 +127,7 @@ template <int S, int BN, bool PRE, bool DBG, int NW = 8, bool XA2 = false, bool 
 __global__ __launch_bounds__(64 * NW) void dwpw2_f32(DwPw2Args a)
 {
     static_assert(!XA2 || (!DBG && NW == 8), "XA2: shipped 8-wave form only");
-    static_assert(!IL || (NW == 8 && !XA2), "IL: 8-wave form only (DBG: stamps, dwpw_variant = 164 + 1024 ... in the lab build)");
+    static_assert(!IL || ((NW == 8 || NW == 4) && !XA2), "IL: 8-wave form, or 4 waves on a 64-row tile with two workgroups per CU");
     const int dbg = DBG ? a.dbg : 0;
     constexpr int NT = 64 * NW, BM = 16 * NW;
     constexpr int WN = 64, WM = BN == 256 ? 64 : 32;   // wave tile: 8 waves as 2 x 4 (BN 256) or 4 x 2 (BN 128)
@@ -137,12 +138,14 @@ __global__ __launch_bounds__(64 * NW) void dwpw2_f32(DwPw2Args a)
     constexpr int XC = S + 3;                          // input columns feeding 2 adjacent output pixels
     constexpr int NX = 3 * XC;                         // buffer loads per lane per chunk
     constexpr int ABUF = BM * BKF, BBUF = BN * BKF;
-    __shared__ __attribute__((aligned(16))) float lds[2 * ABUF + 2 * BBUF + 11 * CMAX + 2 * NOUT];
-    float *const a_s0 = lds, *const b_s0 = lds + 2 * ABUF, *const wd_s = b_s0 + 2 * BBUF, *const sb_s = wd_s + 9 * CMAX;
+    // NW = 4 (two workgroups per CU): depthwise constants of <= 256 input channels (11 KB), scale/shift of <= 256 outputs: 66 KB per workgroup
+    constexpr int CMAXK = NW == 4 ? CMAX4 : CMAX, NOUTK = NW == 4 ? NOUT4 : NOUT;
+    __shared__ __attribute__((aligned(16))) float lds[2 * ABUF + 2 * BBUF + 11 * CMAXK + 2 * NOUTK];
+    float *const a_s0 = lds, *const b_s0 = lds + 2 * ABUF, *const wd_s = b_s0 + 2 * BBUF, *const sb_s = wd_s + 9 * CMAXK;
     // pointwise scale | shift of all Cout channels: the epilogue reads them with ds_read. As global loads they were the wave's
     // youngest vector-memory operations, and waiting for them (in-order vmcnt) drained the x-window loads and the filter DMA
     // already in flight for the next steps: 1700-3100 cycles per tile in the stamps (profiles/r02/g_dwpw2_stamps.txt)
-    float *const sc3_s = sb_s + 2 * CMAX, *const sh3_s = sc3_s + NOUT;
+    float *const sc3_s = sb_s + 2 * CMAXK, *const sh3_s = sc3_s + NOUTK;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -658,6 +661,19 @@ void launch2(DwPw2Args &a, hipStream_t s, int num_cus, bool pre)
         if (g16 > (long)a.mt * a.nt) g16 = (long)a.mt * a.nt;
         if (nw == 16) hipLaunchKernelGGL((dwpw2_f32<S, 128, false, false, 16>), dim3((unsigned)g16), dim3(1024), 0, s, a);
         else hipLaunchKernelGGL((dwpw2_f32<S, 128, false, false, 12>), dim3((unsigned)g16), dim3(768), 0, s, a);
+        return;
+    }
+#endif
+#ifdef MBN_LAB
+    if (BN == 128 && g_mbn_tune.dwpw_variant == 10 && a.cin <= CMAX4 && a.cout <= NOUT4) {      // r5 A/B: two 4-wave workgroups per CU on 64-row tiles (they de-phase by themselves)
+        a.mt = (int)((a.m + 63) / 64);
+        a.nt = a.cout / BN;
+        long g4 = 2L * num_cus;
+        if (g4 > (long)a.mt * a.nt) g4 = (long)a.mt * a.nt;
+        if constexpr (BN == 128) {
+            if (a.fast_off) hipLaunchKernelGGL((dwpw2_f32<S, 128, true, false, 4, false, true, true>), dim3((unsigned)g4), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((dwpw2_f32<S, 128, true, false, 4, false, true, false>), dim3((unsigned)g4), dim3(256), 0, s, a);
+        }
         return;
     }
 #endif

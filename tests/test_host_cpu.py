@@ -569,7 +569,7 @@ def _fake_bench_record():
             "unit": "TFLOP/s", "frac": 0.81571234, "traffic": 205277161.0, "traffic_source": {"git_sha": "x" * 12, "command": "y" * 300, "date": "2026-10-04"},
             "avg_launch_ms": 0.1794212, "algorithmic_flops_per_launch": 23018340352.0, "algorithmic_bytes_per_launch": 171704320.0, "launches_per_step": 8,
             "held_clock_ghz": 2.213, "frac_at_held_clock": 0.8846, "held_clock_launches": 40, "dw_x13_frac_hbm": 0.69, "pw_x13_frac_mfma": 0.72,
-            "blocks_ms": 0.93, "stem_ms": 0.28}
+            "blocks_ms": 0.93, "stem_ms": 0.28, "package_power_w": 1349.0, "power_cap_w": 1400.0}
     base = {"metric": "images/sec MobileNet-V1 1.0x224 fp32, batch 256; per-stage HBM GB/s vs roofline", "value": 89059.123456789, "unit": "images/sec",
             "n_gpus": 1, "steps": 20, "warmup": 5, "ms_per_step": 2.87451234, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
@@ -585,7 +585,8 @@ def _fake_bench_record():
             "cpu_baseline": {"value": 46.655550652782544, "unit": "images/sec", "cores": 16, "kind": "port", "sample": "s" * 250,
                              "variants": {"threads%d_batch%d" % (t, b): {"ms_per_image": 1.0, "images_per_sec": 2.0} for t in (1, 16) for b in (1, 8)}, "variants_how": "v" * 80},
             "parity_check": {"images": 64, "max_rel_err": 4.781746733827894e-07, "tolerance": 0.001, "ok": True, "argmax_agree": 64, "against": "a" * 120}}
-    alt = {k: base[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "roofline", "stages", "sum_kernel_ms", "profiled_steps",
+    base["power"] = {"package_w": 1389.0, "cap_w": 1400.0, "sclk_mhz": 2296.0, "samples": 22, "how": "h" * 100}
+    alt = {k: base[k] for k in ("power", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "roofline", "stages", "sum_kernel_ms", "profiled_steps",
                                 "event_overhead_us", "step_ms", "parity_check")}
     base["configs_alt"] = {"bf16_1.0x224_b512": alt, "bf16_0.5x160_b512": alt, "f32_1.0x224_b1": alt}
     return base
@@ -616,7 +617,7 @@ def test_bench_line_is_compact_parseable_and_keeps_the_contract(tmp_path):
     assert abs(out["roofline"]["frac"] - out["roofline"]["achieved"] / out["roofline"]["peak"]) < 1e-3
     assert set(out["cpu_baseline"]) == {"value", "unit", "cores", "kind", "sample"} and out["cpu_baseline"]["kind"] == "port"
     assert out["stages_frac"]["pointwise"] == [0.4, 0.4376, 0.8157] and out["stages_frac"]["unfused_depthwise_x13"][0] == 0.96
-    assert out["configs_alt"]["bf16_1.0x224_b512"] == [89059.1, 0.8157, True]
+    assert out["configs_alt"]["bf16_1.0x224_b512"] == [89059.1, 0.8157, True, 1389.0] and out["roofline"]["package_power_w"] == 1349.0
     assert "layers" not in out and "unfused_stages" not in out and "config" in out and "streams_note" not in out["config"]
     # N = 8: the per-rank evidence rides along and the line still fits
     rec8 = dict(rec, n_gpus=8, ranks=[[r, r, "0000:%02x:00.0" % (5 + r), 256, 0.0574123] for r in range(8)], ranks_cols="c" * 70,
