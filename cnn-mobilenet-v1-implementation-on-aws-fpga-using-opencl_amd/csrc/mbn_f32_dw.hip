@@ -828,7 +828,9 @@ int launch_dw(const mbn_call &c, DwArgs &a, int rows, int cols, int fs, int stri
     // with TWO output rows per segment although a full-height march already fills the chip — 0.1988 -> 0.1861 ms at batch 256, 0.4194 -> 0.3772 at 512,
     // 0.2148 -> 0.1923 at 320 x 320 / 128 images — and 1-20 % slower below that size (411 MB at batch 128: +1 %; cache-sized inputs: +10-20 %): a lane's
     // 56-row march is one dependent HBM round trip per row, and the row a segment re-reads was fetched by its neighbour microseconds earlier.
-    if (g_mbn_tune.dw_nseg <= 0 && sizeof(T) == 4 && stride == 2 && rows >= 8 &&
+    // The rule covers the shape it was measured on: output maps of >= 40 rows (the 112 -> 56 layer 4, the 320 -> 160 case). On the 56 -> 28 layer 8
+    // the same segmentation measured flat to +6 % (0.0916 -> 0.0971 ms at 411 MB; 822 MB at batch 512 was never measured): not taken there.
+    if (g_mbn_tune.dw_nseg <= 0 && sizeof(T) == 4 && stride == 2 && rows >= 40 &&
         (double)c.batch * a.in_rows * a.in_cols * channels * sizeof(T) >= 512.0 * 1048576)
         nseg = rows / 2;
     if (nseg > rows) nseg = rows;

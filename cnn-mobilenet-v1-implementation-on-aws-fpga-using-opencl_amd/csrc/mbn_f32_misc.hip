@@ -317,6 +317,9 @@ constexpr int TAIL_CLASSES_MAX = 1024;      // one image's logits in LDS (4 KB)
 __device__ __forceinline__ void softmax_topk_wave(float *__restrict__ probs, int *__restrict__ topk_idx, float *__restrict__ topk_prob,
                                                   const float *l, long n, int classes, int k);
 
+// TAIL (a.k > 0): the one-launch classifier tail; the plain pool + FC launch (k = 0: mbn_pool_fc) is the TAIL = false instantiation, which has neither the
+// 16 KB of logits in LDS nor the second hand-over.
+template <bool TAIL>
 __global__ __launch_bounds__(256) void poolfc_f32(PoolFcArgs a)
 {
     __shared__ float pooled[4][64];
@@ -385,11 +388,11 @@ __global__ __launch_bounds__(256) void poolfc_f32(PoolFcArgs a)
         for (int k = 0; k < 16; k++) v += k < a.nks ? pt[k] : 0.f;
         const float lg = v + (a.bias ? a.bias[n] : 0.f);
         // with the tail in this launch the logits are read back by another workgroup (possibly on another XCD): agent-scope stores, like the partials
-        if (a.k > 0) __hip_atomic_store(a.out + (long)b * a.classes + n, lg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if constexpr (TAIL) __hip_atomic_store(a.out + (long)b * a.classes + n, lg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else a.out[(long)b * a.classes + n] = lg;
     }
     if (tid == 0) __hip_atomic_store(a.cnt + ns, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch on this workspace (stream order)
-    if (a.k <= 0) return;
+    if constexpr (TAIL) {
     // ---- second hand-over: this range's logits are acknowledged (explicit vmcnt(0) in every wave, then the barrier) before it is counted as done;
     // the range that counts nns - 1 is the last one and owns the softmax + top-k of every image
     __shared__ float s_logits[4][TAIL_CLASSES_MAX];
@@ -405,6 +408,7 @@ __global__ __launch_bounds__(256) void poolfc_f32(PoolFcArgs a)
     // one WAVE per image (the images side by side instead of one after the other: 18 / 27 / 45 us for 1 / 2 / 4 images with the block form, measured)
     const int wv = tid >> 6;
     if (wv < a.batch) softmax_topk_wave(a.probs, a.topk_idx, a.topk_prob, s_logits[wv], wv, a.classes, a.k);
+    }
 }
 
 // softmax + argmax: one 256-lane workgroup per image; wave shuffles then a 4-entry LDS combine.
@@ -689,7 +693,8 @@ int mbn_launch_f32_pool_fc(mbn_context *ctx, hipStream_t s, float *out, const fl
     if (nns > (classes + 15) / 16) nns = (classes + 15) / 16;
     a.npc = ((classes + nns - 1) / nns + 15) / 16 * 16;
     a.nns = (classes + a.npc - 1) / a.npc;
-    hipLaunchKernelGGL(poolfc_f32, dim3((unsigned)(a.nks * a.nns)), dim3(256), 0, s, a);
+    if (a.k > 0) hipLaunchKernelGGL(poolfc_f32<true>, dim3((unsigned)(a.nks * a.nns)), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(poolfc_f32<false>, dim3((unsigned)(a.nks * a.nns)), dim3(256), 0, s, a);
     return MBN_OK;
 }
 

@@ -1,5 +1,8 @@
 #!/bin/bash
 # round 4, call B: bf16 fused block on 16x16x32 MFMAs (tests + A/B), the streaming GEMM's 16x16x32 form on the K <= 256 layers
+# NOTE: the file names and the header text below are those of the commit this call ran at (e3-era: the block kernel's DEFAULT was the 16x16x32 form and
+# `misc=32` selected the 32x32x16 form). At HEAD it is the other way round — the shipped fused bf16 block is 32x32x16 and `misc=32` selects the 16x16x32 lab form
+# (mbn_bf16_dwpw2.hip launch2) — so a re-run from HEAD produces the two series under swapped names. Kept as the record of the call, not as a tool.
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 O=gpurun_out
