@@ -235,6 +235,114 @@ __global__ __launch_bounds__(64 * LD_WAVES) void lit_pointwise_dot_k(uint8_t *__
     }
 }
 
+// ------------------------------------------------------------------------------------ pointwise on the int8 matrix cores (round 5)
+// SURVEY.md 8f-4's other form: the same integer MACs of kernel.cl:106-108 on v_mfma_i32_32x32x32_i8 (gfx950: 32 x 32 outputs x 32 input channels per
+// instruction = what 128 v_dot4 instructions do). Same preconditions as the v_dot4 kernel (carry quirk off, every filter value in int8 — else the scalar
+// loop on the device), same algebra (x - 128 = x ^ 0x80 as int8, + 128 * sum(w) afterwards, all mod 2^32), bit-exact.
+//   pre-pass  lit_pack_filter_rows_k: int32 [oc][cin] -> int8 rows [ocp32][cin32] (zero padded: a lane's A operand is 16 consecutive input channels of one
+//             output channel = one 16-byte load), per-oc sum of weights, the "fits" flag.
+//   main      one workgroup = 64 pixels x all output channels, the pixels' uint8 planes gathered once into LDS as [cin32/4][64] dwords of 4 consecutive input
+//             channels (the v_dot4 kernel's image: the planar NCHW layout puts k at plane stride, this is the transposition). A wave owns 32 x 32 (oc x pixel)
+//             tiles: per 32 input channels its B operand is four ds_read_b32 (k = 16 * (lane / 32) + 0..15 of pixel lane % 32), its A operand one 16-byte
+//             global load (the filter is L2-resident), then one MFMA. The k-to-byte assignment inside a lane is the same function for A and B, and integer
+//             sums do not depend on the order, so any such assignment gives the exact dot product.
+//   C/D       lane l holds pixel l % 32 and output channels (r & 3) + 8 * (r >> 2) + 4 * (l / 32), r = 0..15: 32 lanes store 32 consecutive bytes of a plane.
+constexpr int LM_PIX = 64, LM_WAVES = 8;
+typedef int lit_v4i __attribute__((ext_vector_type(4)));
+typedef int lit_v16i __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void lit_pack_filter_rows_k(unsigned *__restrict__ w8r, int *__restrict__ wsum, int *__restrict__ bad,
+                                                              const int *__restrict__ filt, int cin, int op_size, int cin32, int ocp32)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;           // one dword = 4 consecutive input channels of one output channel
+    const int q = cin32 / 4;
+    if (t >= (long)q * ocp32) return;
+    const int oc = (int)(t / q), g = (int)(t % q);
+    unsigned pk = 0;
+    int sum = 0;
+    bool ok = true;
+    if (oc < op_size)
+        for (int j = 0; j < 4; j++) {
+            const int ic = 4 * g + j;
+            const int w = ic < cin ? filt[(long)oc * cin + ic] : 0;
+            ok = ok && w >= -128 && w <= 127;
+            pk |= ((unsigned)w & 0xffu) << (8 * j);
+            sum += w;
+        }
+    w8r[t] = pk;
+    if (sum) atomicAdd(&wsum[oc], sum);
+    if (!ok) atomicOr(bad, 1);
+}
+
+__global__ __launch_bounds__(64 * LM_WAVES) void lit_pointwise_mfma_k(uint8_t *__restrict__ out, const uint8_t *__restrict__ in,
+                                                                      const int *__restrict__ filt, const unsigned *__restrict__ w8r,
+                                                                      const int *__restrict__ wsum, const int *__restrict__ bad,
+                                                                      long plane, int cin, int op_size, int cin32, int ocp32, long in_image)
+{
+    extern __shared__ unsigned xs[];                       // [cin32 / 4][64] dwords: 4 consecutive input channels of one pixel, x ^ 0x80
+    const int n = blockIdx.z, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long p0 = (long)blockIdx.x * LM_PIX;
+    const long p = p0 + lane;
+    const bool pok = p < plane;
+    const uint8_t *ip = in + n * in_image + p;
+    if (*bad) {
+        // a filter value outside int8: the scalar loop (lit_pointwise_k without the carry), output channels split over the waves
+        if (!pok) return;
+        uint8_t *o = out + n * plane * op_size + p;
+        for (int oc = wave; oc < op_size; oc += LM_WAVES) {
+            int sum = 0;
+            const int *f = filt + (long)oc * cin;
+            for (int i = 0; i < cin; i++) sum = mac_i32(sum, ip[plane * i], f[i]);
+            if (sum <= 0) sum = 0;
+            o[plane * oc] = (uint8_t)sum;
+        }
+        return;
+    }
+    const int q = cin32 / 4;
+    for (int g = wave; g < q; g += LM_WAVES) {             // channels past cin: byte 0 ^ 0x80 meets a zero weight
+        unsigned pk = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int ic = 4 * g + j;
+            const unsigned b = (pok && ic < cin) ? ip[plane * ic] : 0u;
+            pk |= b << (8 * j);
+        }
+        xs[g * LM_PIX + lane] = pk ^ 0x80808080u;
+    }
+    __syncthreads();
+    const int li = lane & 31, lh = lane >> 5;
+    const int ntile = (ocp32 / 32) * (LM_PIX / 32);
+    for (int t = wave; t < ntile; t += LM_WAVES) {
+        const int oc0 = (t >> 1) * 32, px0 = (t & 1) * 32;
+        lit_v16i acc;
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] = 0;
+        const lit_v4i *arow = reinterpret_cast<const lit_v4i *>(w8r + ((long)(oc0 + li) * cin32 + 16 * lh) / 4);
+        const unsigned *brow = xs + (4 * lh) * LM_PIX + px0 + li;
+        for (int ks = 0; ks < cin32 / 32; ks++) {
+            const lit_v4i a = arow[2 * ks];                                    // 32 input channels = two 16-byte pieces per row: this lane's half
+            lit_v4i b;
+#pragma unroll
+            for (int j = 0; j < 4; j++) b[j] = (int)brow[(8 * ks + j) * LM_PIX];
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc, 0, 0, 0);
+        }
+        const long px = p0 + px0 + li;
+        if (px < plane) {
+            uint8_t *o = out + n * plane * op_size + px;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int oc = oc0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (oc < op_size) {
+                    int sum = (int)((unsigned)acc[r] + 128u * (unsigned)wsum[oc]);   // + 128 * sum of weights (mod 2^32)
+                    if (sum <= 0) sum = 0;
+                    o[plane * oc] = (uint8_t)sum;
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ 3x3 taps on v_dot4 (round 3)
 // SURVEY.md 8f-4 for the two 3x3 kernels (kernel.cl:16-50 convolute, :75-86 depthwise): the three taps of one filter ROW are
 // three adjacent bytes of a uint8 plane (x-1, x, x+1 — also at stride 2: 2x-1, 2x, 2x+1), so one unaligned dword load brings
@@ -388,11 +496,34 @@ int mbn_launch_lit_pointwise(const mbn_call &c, uint8_t *out, const uint8_t *in,
                              int cols, int cin, int op_size)
 {
     const long plane = (long)rows * cols;
-    // v_dot4 path: channels independent (no carry quirk), on the context's own stream (the packed filter lives
-    // in a per-context workspace), LDS tile within 64 KB; tune lit_dot = 1 keeps the scalar kernel (A/B hook)
+    // matrix-core / v_dot4 paths: channels independent (no carry quirk), on the context's own stream (the packed filter lives in a
+    // per-context workspace), LDS tile within 64 KB. tune lit_dot: 0 = int8 MFMA where it measured faster (K >= 512, or >= 16384 pixels in the call:
+    // profiles/r05/q_literal_int8_mfma.txt: 1.1-1.4x there, 0.7-0.8x on one image of the K <= 256 layers, where the call is its three launches), else v_dot4
+    // where eligible; 1 = the scalar kernel; 2 = v_dot4 (never the MFMA form); 3 = the MFMA form wherever eligible: A/B hooks and what the tests force
+    const int lit_dot = g_mbn_tune.lit_dot;
+    const bool indep = !(c.quirks & MBN_Q_CARRY_SUM) && c.stream == c.ctx->stream && lit_dot != 1;
+    const int cin32 = (cin + 31) / 32 * 32, ocp32 = (op_size + 31) / 32 * 32;
+    if (indep && lit_dot != 2 && cin >= 16 && op_size >= 16 && (long)cin32 * LM_PIX <= 65536 &&
+        (lit_dot == 3 || cin >= 512 || (double)c.batch * plane >= 16384.0)) {
+        const size_t need = (size_t)cin32 * ocp32 + (size_t)ocp32 * 4 + 256;
+        if (c.ctx->lit_ws_bytes < need) {
+            if (c.ctx->lit_ws) { (void)hipStreamSynchronize(c.stream); (void)hipFree(c.ctx->lit_ws); c.ctx->lit_ws = nullptr; c.ctx->lit_ws_bytes = 0; }
+            if (hipMalloc(&c.ctx->lit_ws, need) != hipSuccess) return MBN_ENOMEM;
+            c.ctx->lit_ws_bytes = need;
+        }
+        unsigned *w8r = (unsigned *)c.ctx->lit_ws;
+        int *wsum = (int *)(w8r + (size_t)cin32 * ocp32 / 4), *bad = wsum + ocp32;
+        (void)hipMemsetAsync(wsum, 0, (size_t)ocp32 * 4 + 4, c.stream);
+        const long nt = (long)(cin32 / 4) * ocp32;
+        hipLaunchKernelGGL(lit_pack_filter_rows_k, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, c.stream, w8r, wsum, bad, filt, cin, op_size,
+                           cin32, ocp32);
+        dim3 grid((unsigned)((plane + LM_PIX - 1) / LM_PIX), 1, c.batch);
+        hipLaunchKernelGGL(lit_pointwise_mfma_k, grid, dim3(64 * LM_WAVES), (size_t)cin32 * LM_PIX, c.stream, out, in, filt, w8r, wsum, bad, plane,
+                           cin, op_size, cin32, ocp32, plane * cin);
+        return MBN_OK;
+    }
     const int cin4 = (cin + 3) / 4, ocp = (op_size + LD_OCR - 1) / LD_OCR * LD_OCR;
-    if (!(c.quirks & MBN_Q_CARRY_SUM) && c.stream == c.ctx->stream && g_mbn_tune.lit_dot != 1 && cin4 * LD_PIX * 4 <= 65536 &&
-        cin >= 8 && op_size >= 8) {
+    if (indep && cin4 * LD_PIX * 4 <= 65536 && cin >= 8 && op_size >= 8) {
         const size_t need = (size_t)cin4 * ocp * 4 + (size_t)ocp * 4 + 256;
         if (c.ctx->lit_ws_bytes < need) {
             if (c.ctx->lit_ws) { (void)hipStreamSynchronize(c.stream); (void)hipFree(c.ctx->lit_ws); c.ctx->lit_ws = nullptr; c.ctx->lit_ws_bytes = 0; }

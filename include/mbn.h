@@ -569,7 +569,9 @@ const char *mbn_version(void);
  *                4-channel lanes, bit 7 = no raised wave priority
  *   dw_nseg      depthwise: row segments per image
  *   net_stagger  layers between the starts of consecutive sub-batch streams (mbn_net_set_streams)
- *   lit_dot      LITERAL pointwise: 0 = v_dot4_i32_i8 path where eligible (no carry quirk, filter fits int8), 1 = scalar kernel
+ *   lit_dot      LITERAL pointwise: 0 = v_mfma_i32_32x32x32_i8 where eligible (no carry quirk, filter fits int8, Cin and Cout >= 16) and measured
+ *                faster (K >= 512 or >= 16384 pixels in the call), else the v_dot4_i32_i8 path where eligible; 1 = scalar kernel; 2 = v_dot4 (never
+ *                the matrix cores); 3 = the matrix cores wherever eligible. All bit-exact (kernel.cl:94-114)
  *   pw_ring      bf16 pointwise: 0 = streaming ring kernel for K = 64 (shipped), 1 = always the tiled GEMM, 2 = ring wherever eligible
  *   pw_splitk    fp32 pointwise of 1..4 images in the few-tile regime: 0 = split-K kernel (mbn_f32_pw_splitk.hip), 1 = always the
  *                tiled GEMM, 2 = split-K wherever the shape allows (K >= 128, K % 64 == 0), whatever the batch; 16 / 32 = as 2 with

@@ -2346,31 +2346,37 @@ def test_net_free_running_streams_interleaved_with_single_stream(pkg, ctx, tmp_p
 
 @pytest.mark.parametrize("shape", [(14, 14, 32, 64, 1), (7, 7, 1024, 1024, 2), (9, 5, 30, 13, 1), (1, 1, 1024, 1000, 3), (28, 28, 130, 20, 1), (56, 56, 64, 128, 1)])
 def test_literal_pointwise_on_dot4_is_bit_exact(pkg, orc, ctx, shape):
-    """the reference's integer pointwise (kernel.cl:94-114, quirks off) on v_dot4_i32_i8 — bit-exact against the
-    oracle and against the scalar LITERAL kernel (tune lit_dot=1): random int8-range filters incl. the extremes -128 / 127,
-    activations over the whole uint8 range (the x - 128 re-centring and its 128 * sum(w) correction), Cin not a multiple of
-    4, Cout not a multiple of 8, planes not a multiple of 64, batch > 1; and a filter with ONE value outside int8, for which
-    the kernel must fall back to the scalar loop on the device."""
+    """the reference's integer pointwise (kernel.cl:94-114, quirks off) on the packed-int8 units — v_mfma_i32_32x32x32_i8 (round 5, the default
+    where Cin and Cout >= 16) and v_dot4_i32_i8 (tune lit_dot=2; the default for the narrower shapes) — bit-exact against the oracle and against the scalar
+    LITERAL kernel (lit_dot=1): random int8-range filters incl. the extremes -128 / 127, activations over the whole uint8 range (the x - 128 re-centring and its
+    128 * sum(w) correction), Cin not a multiple of 4 / 32, Cout not a multiple of 8 / 32, planes not a multiple of 64, batch > 1; and a filter with ONE value
+    outside int8, for which every form must fall back to the scalar loop on the device."""
     rows, cols, cin, oc, n = shape
     rng = np.random.default_rng(rows * 100 + cin + oc)
     x = rng.integers(0, 256, (n, cin, rows, cols), dtype=np.uint8)
     f = rng.integers(-128, 128, (oc, cin), dtype=np.int32)
     f[0, 0], f[-1, -1] = -128, 127
     d_x, d_f = ctx.to_device(x), ctx.to_device(f)
-    d_o, d_s = ctx.alloc(n * oc * rows * cols), ctx.alloc(n * oc * rows * cols)
+    d_o, d_s, d_d, d_m = (ctx.alloc(n * oc * rows * cols) for _ in range(4))
     ext = pkg.make_ext(batch=n, dtype=pkg.DT_U8, quirks=0)
     for trial in range(2):
         want = np.stack([orc.lit_pointwise(x[i], f, rows, cols, cin, oc, quirks=0) for i in range(n)])
-        ctx.pointwise(d_o.ptr, d_x.ptr, d_f.ptr, rows, cols, cin, oc, ext)
+        ctx.pointwise(d_o.ptr, d_x.ptr, d_f.ptr, rows, cols, cin, oc, ext)           # default: the matrix cores where they measured faster, else v_dot4
         try:
             assert ctx.lib.mbn_tune_set(b"lit_dot", 1) == 0
             ctx.pointwise(d_s.ptr, d_x.ptr, d_f.ptr, rows, cols, cin, oc, ext)
+            assert ctx.lib.mbn_tune_set(b"lit_dot", 2) == 0
+            ctx.pointwise(d_d.ptr, d_x.ptr, d_f.ptr, rows, cols, cin, oc, ext)
+            assert ctx.lib.mbn_tune_set(b"lit_dot", 3) == 0                       # the matrix cores wherever eligible (Cin, Cout >= 16), whatever the size
+            ctx.pointwise(d_m.ptr, d_x.ptr, d_f.ptr, rows, cols, cin, oc, ext)
         finally:
             ctx.lib.mbn_tune_set(b"lit_dot", 0)
         ctx.sync()
-        got, scalar = d_o.download(want.shape, np.uint8), d_s.download(want.shape, np.uint8)
+        got, scalar, dot4 = d_o.download(want.shape, np.uint8), d_s.download(want.shape, np.uint8), d_d.download(want.shape, np.uint8)
+        assert np.array_equal(d_m.download(want.shape, np.uint8), want), "int8 MFMA form, trial %d" % trial
         assert np.array_equal(scalar, want)
-        assert np.array_equal(got, want), "trial %d: %d of %d bytes differ" % (trial, int((got != want).sum()), want.size)
+        assert np.array_equal(dot4, want), "v_dot4, trial %d: %d of %d bytes differ" % (trial, int((dot4 != want).sum()), want.size)
+        assert np.array_equal(got, want), "default (int8 MFMA where eligible), trial %d: %d of %d bytes differ" % (trial, int((got != want).sum()), want.size)
         f[oc // 2, cin // 2] = 300 if trial == 0 else f[oc // 2, cin // 2]       # second trial: one value outside int8 -> device fallback
         d_f.upload(f)
     # with the carry quirk the channels are a serial chain: the call must still be right (scalar kernel)
@@ -2378,6 +2384,41 @@ def test_literal_pointwise_on_dot4_is_bit_exact(pkg, orc, ctx, shape):
     ctx.pointwise(d_o.ptr, d_x.ptr, d_f.ptr, rows, cols, cin, oc, pkg.make_ext(dtype=pkg.DT_U8, quirks=1))
     ctx.sync()
     assert np.array_equal(d_o.download(wantc.shape, np.uint8), wantc)
+
+
+def test_literal_pointwise_mfma_operand_map_with_one_hot_filters(pkg, orc, ctx):
+    """The int8 MFMA form's operand maps, pinned without the oracle: a filter whose row oc is one-hot at input channel perm[oc] with weight s[oc] in {1, -1, 2}
+    must move plane perm[oc] of the input into plane oc of the output (x, 0 after the ReLU for -1, (2 x) mod 256 after the truncating store of kernel.cl:112) —
+    every (output channel, input channel, pixel) pairing of the 32 x 32 x 32 instruction is hit by a known answer. Cin = 96, Cout = 80 (padded to 96 rows),
+    a 9 x 9 plane (pixels past the 64-pixel tile and a ragged last tile)."""
+    rows, cols, cin, oc, n = 9, 9, 96, 80, 2
+    assert ctx.lib.mbn_tune_set(b"lit_dot", 3) == 0                           # 3 = the matrix-core form wherever it is eligible, whatever the size
+    rng = np.random.default_rng(2)
+    x = rng.integers(0, 256, (n, cin, rows, cols), dtype=np.uint8)
+    perm = rng.permutation(cin)[:oc]
+    sgn = rng.choice(np.array([1, -1, 2], np.int32), oc)
+    f = np.zeros((oc, cin), np.int32)
+    f[np.arange(oc), perm] = sgn
+    want = np.empty((n, oc, rows, cols), np.uint8)
+    for o in range(oc):
+        src = x[:, perm[o]].astype(np.int64) * int(sgn[o])
+        want[:, o] = (np.maximum(src, 0) % 256).astype(np.uint8)
+    d_x, d_f, d_o = ctx.to_device(x), ctx.to_device(f), ctx.alloc(want.size)
+    try:
+        ctx.pointwise(d_o.ptr, d_x.ptr, d_f.ptr, rows, cols, cin, oc, pkg.make_ext(batch=n, dtype=pkg.DT_U8, quirks=0))
+    finally:
+        ctx.lib.mbn_tune_set(b"lit_dot", 0)
+    ctx.sync()
+    got = d_o.download(want.shape, np.uint8)
+    assert np.array_equal(got, want), "%d of %d bytes differ" % (int((got != want).sum()), want.size)
+    assert np.array_equal(np.stack([orc.lit_pointwise(x[i], f, rows, cols, cin, oc, quirks=0) for i in range(n)]).reshape(want.shape), want)     # the oracle says the same
+    try:                                                                     # and so does the v_dot4 form
+        assert ctx.lib.mbn_tune_set(b"lit_dot", 2) == 0
+        ctx.pointwise(d_o.ptr, d_x.ptr, d_f.ptr, rows, cols, cin, oc, pkg.make_ext(batch=n, dtype=pkg.DT_U8, quirks=0))
+    finally:
+        ctx.lib.mbn_tune_set(b"lit_dot", 0)
+    ctx.sync()
+    assert np.array_equal(d_o.download(want.shape, np.uint8), want)
 
 
 def test_net_graph_under_pw_emul(pkg, ctx, tmp_path):
