@@ -419,7 +419,7 @@ def configs_alt(args, env):
         a.cpu_images = 1 if a.batch == 1 else 8
         o = run_one(a, env)
         keep = ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "roofline", "stages", "sum_kernel_ms",
-                "profiled_steps", "event_overhead_us", "step_ms", "parity_check", "power")
+                "profiled_steps", "event_overhead_us", "step_ms", "parity_check", "power", "layers")
         res[name] = {k: o[k] for k in keep if k in o}
     return res
 

@@ -887,7 +887,7 @@ int mbn_dwpw_fused_bf16(mbn_context *ctx, void *out, const void *in, const void 
               { wp_bf16, 2.0 * cin * cout, "dwpw pointwise filter" });
     Scope sc(ctx, s);
 #ifdef MBN_LAB
-    if (g_mbn_tune.dwpw_variant == 1)      // the round-1 producer/consumer kernel (A/B hook; mbn_bf16_dwpw.hip's kernels are lab-only)
+    if (g_mbn_tune.dwpw_variant == 1 && (cout % 128) == 0 && (cin % 64) == 0)      // the round-1 producer/consumer kernel (A/B hook; mbn_bf16_dwpw.hip's kernels are lab-only; whole 128-column tiles only)
         return sc.finish(mbn_launch_bf16_dwpw(ctx, s, out, in, (const float *)wd, (const float *)s2, (const float *)b2, wp_bf16,
                                               (const float *)s3, (const float *)b3, batch, in_rows, in_cols, out_rows, out_cols,
                                               cin, cout, stride, pad_top, pad_left));

@@ -263,8 +263,8 @@ int mbn_bf16_dwpw_check(const void *out, const void *in, const float *wd, const 
     const void *ptrs[] = { in, wd, s2, b2, wp, s3, b3, out };
     for (const void *p : ptrs)
         if (!p) return MBN_EINVAL;
-    if (batch <= 0 || (stride != 1 && stride != 2) || cin < 64 || (cin % 64) != 0 || cin > CMAX || cout < 128 || cout > 1024 ||
-        (cout % 128) != 0 || (out_cols & 1) || out_rows <= 0 || out_cols <= 0 || in_rows <= 0 || in_cols <= 0 ||
+    if (batch <= 0 || (stride != 1 && stride != 2) || (cin != 32 && (cin < 64 || (cin % 64) != 0)) || cin > CMAX || cout < 64 || cout > 1024 ||
+        (cout % 64) != 0 || (out_cols & 1) || out_rows <= 0 || out_cols <= 0 || in_rows <= 0 || in_cols <= 0 ||
         pad_top < 0 || pad_left < 0)
         return MBN_EUNSUPPORTED;
     if (2.0 * batch * in_rows * in_cols * cin >= (double)OOB) return MBN_EUNSUPPORTED;

@@ -118,7 +118,9 @@ __global__ __launch_bounds__(NT) void dwpw2_bf16(DwPw2Args a)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nk = a.cin / 64, nwg = a.mt * a.nt;
+    // Cin = 32 (round 5: block 4-5 of the 0.5x network) is half a 64-channel chunk: one chunk whose upper 32 channels are padding — lanes c4 >= 4 load
+    // nothing (out-of-range offsets), write zeros into the A tile, and the filter pieces of k >= 32 come from beyond the descriptor (zeros)
+    const int nk = (a.cin + 63) / 64, nwg = a.mt * a.nt;
     const unsigned mtot = (unsigned)a.m;
 
     for (int i = tid * 4; i < 9 * a.cin; i += NT * 4) *reinterpret_cast<f4 *>(wd_s + i) = *reinterpret_cast<const f4 *>(a.wd + i);
@@ -149,15 +151,17 @@ __global__ __launch_bounds__(NT) void dwpw2_bf16(DwPw2Args a)
     for (int p = 0; p < B_LD; p++) {
         const int row = (p * NT + tid) >> 3;
         // channel-paired column blocks (mbn_epilogue.h): LDS filter row `row` holds output channel mbn_pair_channel(row)
-        b_vo[p] = ((unsigned)mbn_pair_channel(row) * (unsigned)a.cin + (unsigned)(((c4 ^ (row >> 1)) & 7) * 8)) * 2u;
+        const unsigned kch = (unsigned)(((c4 ^ (row >> 1)) & 7) * 8);                   // first k of this 16-byte piece
+        b_vo[p] = kch < (unsigned)a.cin ? ((unsigned)mbn_pair_channel(row) * (unsigned)a.cin + kch) * 2u : OOB;
     }
+    const bool cok = c4 * 8 < a.cin;                                            // this lane's 8 channels exist (false only for Cin = 32, c4 >= 4)
     const float *wk = wd_s + c4 * 8;                                           // depthwise taps of this lane's 8 channels (+ kc*64 + tap*cin)
     const float *sk = sb_s + c4 * 8;
 
     unsigned off[3][XC];
     auto set_offsets = [&](unsigned m0) __attribute__((always_inline)) {
         const unsigned m = m0 + 2 * pair;
-        const bool mok = m < mtot;
+        const bool mok = m < mtot && cok;
         const unsigned q = a.wo_m ? __umulhi(m, a.wo_m) >> a.wo_s : m;
         const unsigned x = m - q * (unsigned)a.wo;
         const unsigned n = a.ho_m ? __umulhi(q, a.ho_m) >> a.ho_s : q;
@@ -207,6 +211,11 @@ __global__ __launch_bounds__(NT) void dwpw2_bf16(DwPw2Args a)
         for (int i = 0; i < 8; i++) {
             o0[i] = (__bf16)fminf(fmaxf(fmaf(acc0[i], sc[i], sh[i]), 0.f), 6.f);
             o1[i] = (__bf16)fminf(fmaxf(fmaf(acc1[i], sc[i], sh[i]), 0.f), 6.f);
+        }
+        if (!cok) {                               // padded channels (Cin = 32): exact zeros, whatever the LDS words behind the taps held
+            const u4v z = { 0u, 0u, 0u, 0u };
+            o0 = __builtin_bit_cast(bf8, z);
+            o1 = o0;
         }
         *reinterpret_cast<bf8 *>(a_s0 + buf * ABUF + aw0) = o0;
         *reinterpret_cast<bf8 *>(a_s0 + buf * ABUF + aw1) = o1;
@@ -368,7 +377,9 @@ __global__ __launch_bounds__(NT) void dwpw2_bf16(DwPw2Args a)
         }                                                                                                               \
         if (validL) lds_barrier<NX>();                                                                                  \
         else lds_barrier<0>();                                                                                          \
-        if (kM == nk - 1 && !(dbg & 4)) {                                                                             \
+        /* Cout = 64 (mod 128), round 5: a wave whose 64-column group lies past Cout multiplied zeros (its filter rows are beyond the descriptor: the  */ \
+        /* LDS-DMA wrote zeros) and stores nothing. Block 6-7 of the 0.5x network (64 -> 64 channels) is inside the envelope with it.               */ \
+        if (kM == nk - 1 && !(dbg & 4) && n0M + wn < a.cout) {                                                        \
             if constexpr (M16) {                                                                                        \
             if (m0M + BM <= mtot) mbn_store_relu6_bf16_pair16<MI16, NI16, 0>(orsrc, (unsigned)a.cout, m0M + wm, n0M + wn, lane, acc16, sc3_s, sh3_s); \
             else mbn_store_relu6_bf16_pair16<MI16, NI16, 1>(orsrc, (unsigned)a.cout, m0M + wm, n0M + wn, lane, acc16, sc3_s, sh3_s);               \
@@ -393,7 +404,7 @@ template <int S, int BN>
 void launch2(DwPw2Args &a, hipStream_t s, int num_cus)
 {
     a.mt = (int)((a.m + BM - 1) / BM);
-    a.nt = a.cout / BN;
+    a.nt = (a.cout + BN - 1) / BN;          // Cout = 64 (mod 128): the last tile's upper 64 columns are padding (round 5, see the epilogue)
     const long nwg = (long)a.mt * a.nt;
     long grid = num_cus;
     if (grid > nwg) grid = nwg;

@@ -236,7 +236,7 @@ static int block_fusable(const mbn_net *net, int i, int count, int last_layer)
 {
     const int bf = net->dtype == MBN_DT_BF16;
     if ((net->dtype != MBN_DT_F32 && !bf) || net->keep || i + 2 > last_layer || i + 1 >= net->plan.n_layers || i + 1 >= 32) return 0;
-    if (bf && (!net->bf16_filt[i + 1] || (net->plan.layer[i].in_ch % 64) != 0)) return 0;
+    if (bf && (!net->bf16_filt[i + 1] || ((net->plan.layer[i].in_ch % 64) != 0 && net->plan.layer[i].in_ch != 32))) return 0;   /* 32: half a chunk, padded (round 5) */
     if (!((fuse_mask(net) >> (i + 1)) & 1u)) return 0;
     /* bf16 default: the block kernel recomputes the depthwise chunk once per 256-column tile and is bound by that VALU work,
      * so a block wider than one tile measures slower fused than as two launches; an explicit mask overrides */
@@ -255,7 +255,8 @@ static int block_fusable(const mbn_net *net, int i, int count, int last_layer)
     if (((uintptr_t)net->dev_blob % 16) != 0) return 0;            /* see stem_fusable */
     const mbn_layer_desc *d = &net->plan.layer[i], *p = &net->plan.layer[i + 1];
     if (d->kind != MBN_L_DW || p->kind != MBN_L_PW || (d->stride != 1 && d->stride != 2)) return 0;
-    if (d->in_ch < 32 || (d->in_ch % 32) != 0 || d->in_ch > 1024 || p->out_ch < 128 || (p->out_ch % 128) != 0 || p->out_ch > 1024) return 0;
+    if (d->in_ch < 32 || (d->in_ch % 32) != 0 || d->in_ch > 1024 || p->out_ch > 1024) return 0;
+    if (bf ? (p->out_ch < 64 || (p->out_ch % 64) != 0) : (p->out_ch < 128 || (p->out_ch % 128) != 0)) return 0;   /* bf16 (round 5): 64-column remainders on a padded tile */
     if ((d->out_cols & 1) || p->in_ch != d->out_ch) return 0;
     const double es = bf ? 2.0 : 4.0;
     if (es * count * d->in_rows * d->in_cols * d->in_ch >= 4026531840.0) return 0;

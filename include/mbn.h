@@ -284,7 +284,9 @@ int mbn_softmax_f32(mbn_context *ctx, void *probs, void *argmax_i32, const void 
 
 /* The same block in the network's bf16 mode (BASELINE config 5): in/out are bf16 NHWC, wp_bf16 is the bf16 copy of the
  * pointwise filter [cout][cin]; the depthwise filter and all scale/shift vectors stay fp32, arithmetic is fp32, the
- * depthwise output is rounded to bf16 where the separate launch would store it. cin must be a multiple of 64. */
+ * depthwise output is rounded to bf16 where the separate launch would store it. cin must be a multiple of 64 or 32 itself (half a chunk, padded), cout a multiple
+ * of 64 (round 5; a 64-column remainder — block 6-7 of the 0.5x network: 64 -> 64 channels — runs on a 128-column tile whose
+ * upper half multiplies zeros and stores nothing). */
 int mbn_dwpw_fused_bf16(mbn_context *ctx, void *out, const void *in, const void *wd, const void *s2, const void *b2,
                         const void *wp_bf16, const void *s3, const void *b3, int batch, int in_rows, int in_cols, int out_rows,
                         int out_cols, int cin, int cout, int stride, int pad_top, int pad_left, void *stream);

@@ -1481,7 +1481,9 @@ def test_net_full_size_fused_equals_unfused(pkg, ctx, tmp_path, n):
 
 
 @pytest.mark.parametrize("shape", [(2, 112, 64, 128, 2), (2, 56, 128, 128, 1), (2, 56, 128, 256, 2), (2, 28, 256, 256, 1),
-                                   (1, 28, 256, 512, 2), (3, 14, 64, 128, 1), (1, 6, 192, 384, 1), (2, 14, 512, 512, 1)])
+                                   (1, 28, 256, 512, 2), (3, 14, 64, 128, 1), (1, 6, 192, 384, 1), (2, 14, 512, 512, 1),
+                                   (2, 40, 64, 64, 1), (3, 20, 64, 192, 2), (1, 14, 128, 320, 1), (5, 40, 64, 64, 1),    # round 5: Cout = 64 (mod 128) on a padded tile
+                                   (2, 80, 32, 64, 2), (3, 24, 32, 128, 1), (1, 10, 32, 64, 1)])                         # ... and Cin = 32: half a K chunk
 def test_bf16_dwpw_fused(pkg, orc, ctx, shape):
     """mbn_dwpw_fused_bf16 vs the oracle's bf16 emulation of the pair (depthwise output rounded to bf16, bf16 pointwise
     filter, output rounded) and vs the two separate bf16 launches; bf16 tolerance (the pointwise summation order differs)."""
