@@ -44,6 +44,8 @@ struct DwPw2Args {
     unsigned in_bytes, wp_bytes;
     int dbg;                // experiments (tune misc): 1 = no x loads after the first, 2 = no depthwise math, 4 = no output stores, 8 = no filter DMA, 16 = no MFMA
     unsigned wo_m, wo_s, ho_m, ho_s;   // floor(v / wo) = umulhi(v, wo_m) >> wo_s for v < 2^31 (m == 0: the divisor is 1)
+    int fast_off;           // launcher: 1 = the FO instantiation (tile offsets in their full-rate form, as in mbn_f32_dwpw2.hip: input < 0x70000000 bytes)
+    float inv_wo, inv_ho;   // 1 / wo, 1 / ho
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return (row << 5) + (((chunk ^ (row >> 1)) & 7) << 2); }
@@ -97,7 +99,9 @@ __device__ __forceinline__ void dma_filter(__amdgpu_buffer_rsrc_t rsrc, float *l
 // bf16 1.0x224 batch 512, alternating runs): blocks 4-11 0.746-0.754 ms against 0.739-0.749 with 32x32x16 — equal within the run-to-run spread, 0.8 % worse
 // on the means: a block's matrix work is a sixteenth of the fp32 kernel's, too thin to pull the clock down, and the 16 x 16 form holds 24-32 more
 // fragment registers. Parity-tested (oracle + exact integers, tests/test_parity_gpu.py::test_bf16_dwpw_fused under MBN_LAB=1), not shipped.
-template <int S, int BN, bool DBG, bool M16>
+// FO (round 5): set_offsets from full-rate instructions — see mbn_f32_dwpw2.hip (set_offsets_fast). In bf16 a block with Cin <= 64 is ONE chunk per tile, so the
+// offsets are computed in every step: the general form's two v_mul_hi_u32, six v_mul_lo_u32 and 12-15 compare/select pairs under exec-mask branches were ~20 % of it.
+template <int S, int BN, bool DBG, bool M16, bool FO = false>
 __global__ __launch_bounds__(NT) void dwpw2_bf16(DwPw2Args a)
 {
     const int dbg = DBG ? a.dbg : 0;
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(NT) void dwpw2_bf16(DwPw2Args a)
     const float *sk = sb_s + c4 * 8;
 
     unsigned off[3][XC];
-    auto set_offsets = [&](unsigned m0) __attribute__((always_inline)) {
+    auto set_offsets_general = [&](unsigned m0) __attribute__((always_inline)) {
         const unsigned m = m0 + 2 * pair;
         const bool mok = m < mtot && cok;
         const unsigned q = a.wo_m ? __umulhi(m, a.wo_m) >> a.wo_s : m;
@@ -178,6 +182,37 @@ __global__ __launch_bounds__(NT) void dwpw2_bf16(DwPw2Args a)
                 off[dy][j] = ok ? base + dy * rs + j * cs : OOB;
             }
         }
+    };
+    auto set_offsets_fast = [&](unsigned m0) __attribute__((always_inline)) {
+        const unsigned q0 = a.wo_m ? __umulhi(m0, a.wo_m) >> a.wo_s : m0;                    // wave-uniform: scalar unit
+        const unsigned x0 = m0 - q0 * (unsigned)a.wo;
+        const unsigned n0 = a.ho_m ? __umulhi(q0, a.ho_m) >> a.ho_s : q0;
+        const unsigned y0 = q0 - n0 * (unsigned)a.ho;
+        const unsigned r = x0 + 2u * (unsigned)pair;
+        const unsigned q1 = (unsigned)__builtin_fmaf((float)r, a.inv_wo, 0.5f * a.inv_wo);     // exact: r < wo + 128, see the fp32 kernel
+        const unsigned x = r - q1 * (unsigned)a.wo;
+        const unsigned yy = y0 + q1;
+        const unsigned q2 = (unsigned)__builtin_fmaf((float)yy, a.inv_ho, 0.5f * a.inv_ho);
+        const unsigned y = yy - q2 * (unsigned)a.ho;
+        const unsigned n = n0 + q2;
+        const bool mok = m0 + 2u * (unsigned)pair < mtot && cok;
+        const int iy0 = (int)y * S - a.pad_top, ix0 = (int)x * S - a.pad_left;
+        const unsigned cs = (unsigned)a.cin * 2u, rs = (unsigned)a.w * cs;
+        const int pix = __mul24((int)(n * (unsigned)a.h) + iy0, a.w) + ix0;
+        const unsigned base = (unsigned)pix * cs + (unsigned)(c4 * 8) * 2u;
+        unsigned rowv[3], colv[XC];
+#pragma unroll
+        for (int dy = 0; dy < 3; dy++) rowv[dy] = (mok && (unsigned)(iy0 + dy) < (unsigned)a.h) ? base + dy * rs : 0x80000000u;
+#pragma unroll
+        for (int j = 0; j < XC; j++) colv[j] = ((unsigned)(ix0 + j) < (unsigned)a.w) ? j * cs : 0x70000000u;
+#pragma unroll
+        for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+            for (int j = 0; j < XC; j++) off[dy][j] = rowv[dy] + colv[j];
+    };
+    auto set_offsets = [&](unsigned m0) __attribute__((always_inline)) {
+        if constexpr (FO) set_offsets_fast(m0);
+        else set_offsets_general(m0);
     };
     u4v xr[3][XC];                                                            // the window stays packed (4 VGPRs per vector)
     auto ldx = [&](int kc) __attribute__((always_inline)) {
@@ -412,7 +447,8 @@ void launch2(DwPw2Args &a, hipStream_t s, int num_cus)
     if (a.dbg) { hipLaunchKernelGGL((dwpw2_bf16<S, BN, true, false>), dim3((unsigned)grid), dim3(NT), 0, s, a); return; }
     if (g_mbn_tune.misc == 32) { hipLaunchKernelGGL((dwpw2_bf16<S, BN, false, true>), dim3((unsigned)grid), dim3(NT), 0, s, a); return; }   // A/B: the 16x16x32 form
 #endif
-    hipLaunchKernelGGL((dwpw2_bf16<S, BN, false, false>), dim3((unsigned)grid), dim3(NT), 0, s, a);
+    if (a.fast_off) hipLaunchKernelGGL((dwpw2_bf16<S, BN, false, false, true>), dim3((unsigned)grid), dim3(NT), 0, s, a);
+    else hipLaunchKernelGGL((dwpw2_bf16<S, BN, false, false, false>), dim3((unsigned)grid), dim3(NT), 0, s, a);
 }
 
 }   // namespace
@@ -434,6 +470,10 @@ int mbn_launch_bf16_dwpw2(mbn_context *ctx, hipStream_t stream, void *out, const
     a.in_bytes = (unsigned)(2.0 * batch * in_rows * in_cols * cin);
     a.wp_bytes = (unsigned)(2.0 * cin * cout);
     a.dbg = variant >= 100 ? variant - 100 : 0;
+    a.inv_wo = 1.0f / (float)out_cols;
+    a.inv_ho = 1.0f / (float)out_rows;
+    a.fast_off = (2.0 * batch * in_rows * in_cols * cin < (double)0x70000000u && (double)batch * in_rows < 8388000.0 && in_cols < 32768 &&
+                  out_cols < 32768 && g_mbn_tune.exp0 != 51) ? 1 : 0;
     // 256-column tiles only when they alone fill the chip; pw_tile=1: force the 128-column tile (A/B hook)
     const bool wide = (cout % 256) == 0 && g_mbn_tune.pw_tile != 1 && ((a.m + BM - 1) / BM) * (cout / 256) >= ctx->num_cus;
     if (stride == 1) {
