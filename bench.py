@@ -614,18 +614,27 @@ def run_one(args, env):
             stages, per_layer, stage_of = stage_table(plan, pkg, launches, layer_ms, args.batch, act_bytes, mfma_peak)
             # dominant kernel: the stand-alone pointwise GEMMs; at 1..4 images every block is one fused launch, so the fused
             # block launches are the dominant kernel and their pointwise layers carry the flops
+            # ... and in bf16 at 0.5x160 since round 5 (every block but the two 5 x 5 ones is a fused launch): the dominant kernel is whichever of the
+            # two groups takes more of the step
             dom = "pointwise" if "pointwise" in stages else "block_fused"
+            if bf16 and "pointwise" in stages and "block_fused" in stages and stages["pointwise"]["launches"] < 4 and \
+                    stages["block_fused"]["ms"] > stages["pointwise"]["ms"]:
+                dom = "block_fused"       # 0.5x160: two stand-alone pointwise launches (the 5 x 5 layers) are not what the step spends its time in
             pw = stages[dom]
             pw_idx = [launches[j][-1] for j in range(n_launch) if stage_of[j] == dom]
             flops_per_launch = sum(layer_work(plan.layer[i], args.batch, pkg, act_bytes)[0] for i in pw_idx) / len(pw_idx)
             bytes_per_launch = sum(layer_work(plan.layer[i], args.batch, pkg, act_bytes)[1] for i in pw_idx) / len(pw_idx)
+            if dom == "block_fused":          # a fused launch moves its depthwise layer's input and its pointwise layer's output (+ both filters)
+                bytes_per_launch = pw["GBps"] * pw["ms"] * 1e6 / len(pw_idx)
             avg_ms = pw["ms"] / len(pw_idx)           # per LAYER (= per launch when --streams 1)
             traffic, traffic_src = load_traffic([i + 1 for i in pw_idx], "bf16_%gx%d" % (args.alpha, args.res) if bf16 else
                                                 ("f32_pw_emul%d" % args.pw_emul if args.pw_emul else "f32"))
+            if dom == "block_fused":
+                traffic, traffic_src = None, None     # the committed PMC passes are per stand-alone layer
             if bf16:       # ridge ~312 flop/B: every pointwise layer is HBM-bound in bf16
                 out["roofline"] = {
                     "kernel": ("bf16 pointwise GEMMs: pw_stream_bf16 (K >= 512 on 16x16x32 MFMAs; K <= 256 narrow layers) and pw_gemm<bf16> (%d pointwise 1x1 conv launches per step)" if dom == "pointwise" else
-                               "fused depthwise->pointwise blocks (%d launches per step; bytes of their pointwise layers)") % len(pw_idx),
+                               "dwpw2_bf16: fused depthwise->pointwise blocks (%d launches per step; input of the depthwise layer + output of the pointwise layer + filters)") % len(pw_idx),
                     "bound": "hbm", "achieved": round(bytes_per_launch / avg_ms / 1e6, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(bytes_per_launch / avg_ms / 1e6 / HBM_PEAK_GBS, 4),
                     "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(avg_ms, 5),
