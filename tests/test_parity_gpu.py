@@ -2569,6 +2569,38 @@ def test_bench_self_launches_its_ranks(pkg):
         assert r.returncode == 19 and "MBN_ENODEVICE" in r.stderr and not r.stdout.strip()
 
 
+def test_held_clock_counters_and_pci_bus_id(pkg, ctx):
+    """Round 5: mbn_device_pci_bus_id names the card a context holds; the product switch pw_clock makes every pw_gemm launch add the core
+    cycles (s_memtime) and 100 MHz reference ticks (s_memrealtime) its first eight workgroups lived to device counters, mbn_pw_clock_read turns them into the clock
+    the chip held. Off: nothing is recorded. The GEMM's result does not depend on the switch."""
+    bus = ctx.pci_bus_id()
+    assert bus.count(":") == 2 and "." in bus and len(bus) >= 10, bus
+    m, k, n = 50176, 512, 512
+    rng = np.random.default_rng(3)
+    x = rng.uniform(-1, 1, (m, k)).astype(np.float32)
+    f = rng.normal(0, (2.0 / k) ** 0.5, (n, k)).astype(np.float32)
+    d_x, d_f, d_o = ctx.to_device(x), ctx.to_device(f), ctx.alloc(m * n * 4)
+    d_sc, d_sh = ctx.to_device(np.ones(n, np.float32)), ctx.to_device(np.zeros(n, np.float32))
+    ext = pkg.make_ext(act=2, scale=d_sc.ptr, shift=d_sh.ptr)
+    ctx.pw_clock(reset=True)
+    ctx.pointwise(d_o.ptr, d_x.ptr, d_f.ptr, m, 1, k, n, ext)
+    ctx.sync()
+    base = d_o.download((m, n), np.float32)
+    assert ctx.pw_clock(reset=True) == (0.0, 0)                      # switch off: nothing recorded
+    try:
+        assert ctx.lib.mbn_tune_set(b"pw_clock", 1) == 0
+        for _ in range(6):
+            ctx.pointwise(d_o.ptr, d_x.ptr, d_f.ptr, m, 1, k, n, ext)
+        ghz, launches = ctx.pw_clock(reset=False)
+        assert launches == 6 and 0.8 < ghz < 2.6, (ghz, launches)    # MI355X: 2.4 GHz peak engine clock; held 2.1-2.4 under the fp32 MFMA stream
+        assert ctx.pw_clock(reset=True)[1] == 6 and ctx.pw_clock(reset=True) == (0.0, 0)
+    finally:
+        ctx.lib.mbn_tune_set(b"pw_clock", 0)
+    assert np.array_equal(d_o.download((m, n), np.float32), base)
+    for b in (d_x, d_f, d_o, d_sc, d_sh):
+        b.free()
+
+
 def test_graft_entry_smoke_runs():
     """__graft_entry__.smoke() is what the driver runs on the GPU box before the bench: it must keep passing when dispatch
     rules change (it asserts which fused kernels are on its path)."""

@@ -45,6 +45,23 @@ def net(dtype, alpha, res, batch, streams):
     imgs = np.random.default_rng(0).random((batch, res, res, 3), dtype=np.float32) * 2 - 1
     d_in, d_out = ctx.to_device(imgs), ctx.alloc(batch * 4000)
     return n, (lambda: n.forward(d_in.ptr, d_out.ptr, batch))
+if "--stem" in sys.argv:
+    plan = pkg.plan_build(1.0, 224, 1000, lib=lib)
+    fd, path = tempfile.mkstemp(suffix=".h5"); os.close(fd)
+    pkg.synthetic_h5(path, alpha=1.0, classes=1000, seed=1, lib=lib)
+    hw = pkg.HostWeights(path, alpha=1.0, res=224, lib=lib); os.remove(path)
+    for dtype in ("f32", "bf16"):
+        nb = 256 if dtype == "f32" else 512
+        ns = pkg.Net(ctx, hw.plan, hw.blob.copy(), nb)
+        if dtype == "bf16": ns.set_dtype(pkg.DT_BF16)
+        imgs = np.random.default_rng(0).random((nb, 224, 224, 3), dtype=np.float32) * 2 - 1
+        d_in, d_o = ctx.to_device(imgs), ctx.alloc(nb * 112 * 112 * 64 * 4)
+        run("fused stem (layers 1-3) %s b%d" % (dtype, nb), lambda: ns.forward(d_in.ptr, d_o.ptr, nb, 3))
+        ns.set_fuse_blocks(1 << 4)
+        d_o2 = ctx.alloc(nb * 56 * 56 * 128 * 4)
+        run("layers 1-5 (stem + fused block 4-5) %s b%d" % (dtype, nb), lambda: ns.forward(d_in.ptr, d_o2.ptr, nb, 5))
+        ns.destroy(); d_in.free(); d_o.free(); d_o2.free()
+    stop.set(); sys.exit(0)
 n1, f = net("f32", 1.0, 224, 256, 2); run("net fp32 1.0x224 b256, 2 streams (headline)", f, 256)
 n1.set_streams(1); run("net fp32 1.0x224 b256, 1 stream", f, 256)
 assert lib.mbn_tune_set(b"pw_emul", 6) == 0 and lib.mbn_tune_set(b"pw_emul_static", 1) == 0
