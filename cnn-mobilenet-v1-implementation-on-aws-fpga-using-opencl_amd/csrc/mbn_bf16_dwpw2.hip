@@ -26,10 +26,11 @@ typedef unsigned u4v __attribute__((ext_vector_type(4)));
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 typedef mbn_f16v f16v;
 
-constexpr int BM = 128, BKF = 32;              // LDS rows are 128 bytes = 32 words = 64 bf16
-constexpr int NW = 8, NT = 64 * NW;            // 8 waves: 2 per SIMD, 256 VGPRs each
-constexpr int NOUT = 1024;                     // widest pointwise output whose scale/shift the LDS copy holds
-constexpr int CMAX = 1024;                     // largest Cin (depthwise constants resident in LDS: 44 KB)
+constexpr int BKF = 32;                        // LDS rows are 128 bytes = 32 words = 64 bf16
+constexpr int BM8 = 128;                       // rows of the 8-wave tile (2 waves per SIMD, 256 VGPRs each); the 4-wave form (two workgroups per CU): 64
+constexpr int CMAX4 = 256, NOUT4 = 256;        // LDS-resident constants of the 4-wave form (61 KB per workgroup)
+constexpr int NOUT_G = 1024;                   // widest pointwise output whose scale/shift the LDS copy holds
+constexpr int CMAX_G = 1024;                   // largest Cin (depthwise constants resident in LDS: 44 KB)
 constexpr unsigned OOB = 0xF0000000u;          // byte offset beyond any supported tensor: the load returns zeros
 
 struct DwPw2Args {
@@ -44,6 +45,7 @@ struct DwPw2Args {
     unsigned in_bytes, wp_bytes;
     int dbg;                // experiments (tune misc): 1 = no x loads after the first, 2 = no depthwise math, 4 = no output stores, 8 = no filter DMA, 16 = no MFMA
     unsigned wo_m, wo_s, ho_m, ho_s;   // floor(v / wo) = umulhi(v, wo_m) >> wo_s for v < 2^31 (m == 0: the divisor is 1)
+    int use4;               // launcher: the 4-wave / two-workgroups-per-CU form is allowed (tune exp2 == 44 in the lab build until measured)
     int fast_off;           // launcher: 1 = the FO instantiation (tile offsets in their full-rate form, as in mbn_f32_dwpw2.hip: input < 0x70000000 bytes)
     float inv_wo, inv_ho;   // 1 / wo, 1 / ho
 };
@@ -83,7 +85,7 @@ __device__ __forceinline__ void lds_barrier()
 }
 
 // pointwise filter chunk -> LDS, buffer form (a __device__ function: see mbn_f32_pw.hip lds_dma_rows)
-template <int B_LD>
+template <int B_LD, int NT>
 __device__ __forceinline__ void dma_filter(__amdgpu_buffer_rsrc_t rsrc, float *lds_b, const unsigned *voff, int soff, int wave_u)
 {
 #pragma unroll
@@ -101,13 +103,18 @@ __device__ __forceinline__ void dma_filter(__amdgpu_buffer_rsrc_t rsrc, float *l
 // fragment registers. Parity-tested (oracle + exact integers, tests/test_parity_gpu.py::test_bf16_dwpw_fused under MBN_LAB=1), not shipped.
 // FO (round 5): set_offsets from full-rate instructions — see mbn_f32_dwpw2.hip (set_offsets_fast). In bf16 a block with Cin <= 64 is ONE chunk per tile, so the
 // offsets are computed in every step: the general form's two v_mul_hi_u32, six v_mul_lo_u32 and 12-15 compare/select pairs under exec-mask branches were ~20 % of it.
-template <int S, int BN, bool DBG, bool M16, bool FO = false>
-__global__ __launch_bounds__(NT) void dwpw2_bf16(DwPw2Args a)
+// NW (round 5): 8 = one workgroup of 8 waves per CU on 128-row tiles (rounds 2-4); 4 = 4 waves on 64-row tiles, two independent workgroups per CU (61 KB of LDS each:
+// Cin, Cout <= 256): they fall out of phase by themselves, so one's waits, barrier and epilogue run under the other's depthwise arithmetic. Pays only below the power limit
+// (the fp32 counterpart measured equal at the limit: profiles/r05/j_*) — and, measured, not there either: lab only (launch2).
+template <int S, int BN, bool DBG, bool M16, bool FO = false, int NW = 8>
+__global__ __launch_bounds__(64 * NW) void dwpw2_bf16(DwPw2Args a)
 {
+    constexpr int NT = 64 * NW, BM = 16 * NW;
+    constexpr int CMAX = NW == 4 ? CMAX4 : CMAX_G, NOUT = NW == 4 ? NOUT4 : NOUT_G;
     const int dbg = DBG ? a.dbg : 0;
     constexpr int WN = 64, WM = BN == 256 ? 64 : 32;   // wave tile: 8 waves as 2 x 4 (BN 256) or 4 x 2 (BN 128)
     constexpr int WAVES_N = BN / WN;
-    static_assert((BM / WM) * WAVES_N == NW, "8 waves");
+    static_assert((BM / WM) * WAVES_N == NW, "wave grid");
     constexpr int MI = WM / 32, NI = WN / 32;
     constexpr int B_LD = BN * 8 / NT;                  // 16-B filter pieces per lane per chunk (2 / 4)
     constexpr int XC = S + 3;                          // input columns feeding 2 adjacent output pixels
@@ -359,7 +366,7 @@ __global__ __launch_bounds__(NT) void dwpw2_bf16(DwPw2Args a)
     origin(vbM, m0M, n0M);
     set_offsets(m0M);
     ldx(0);
-    dma_filter<B_LD>(wrsrc, b_s0, b_vo, (n0M * a.cin + 0) * 2, wave_u);
+    dma_filter<B_LD, NT>(wrsrc, b_s0, b_vo, (n0M * a.cin + 0) * 2, wave_u);
     dw(0, 0);
     // D cursor = successor of M
     vbD = vbM; kD = 1; m0D = m0M; n0D = n0M; validD = true;
@@ -383,7 +390,7 @@ __global__ __launch_bounds__(NT) void dwpw2_bf16(DwPw2Args a)
         int vbL = vbD, kL = kD + 1, n0L = n0D;                                                                          \
         unsigned m0L = m0D;                                                                                             \
         if (validD) {                                                                                                   \
-            if (!(dbg & 8)) dma_filter<B_LD>(wrsrc, b_s0 + (P ^ 1) * BBUF, b_vo, (n0D * a.cin + kD * 64) * 2, wave_u); \
+            if (!(dbg & 8)) dma_filter<B_LD, NT>(wrsrc, b_s0 + (P ^ 1) * BBUF, b_vo, (n0D * a.cin + kD * 64) * 2, wave_u); \
             if (!(dbg & 2)) dw(kD, P ^ 1);                                                                            \
             validL = true;                                                                                              \
             if (kL >= nk) {                                                                                             \
@@ -438,6 +445,7 @@ __global__ __launch_bounds__(NT) void dwpw2_bf16(DwPw2Args a)
 template <int S, int BN>
 void launch2(DwPw2Args &a, hipStream_t s, int num_cus)
 {
+    constexpr int BM = BM8, NT = 512;
     a.mt = (int)((a.m + BM - 1) / BM);
     a.nt = (a.cout + BN - 1) / BN;          // Cout = 64 (mod 128): the last tile's upper 64 columns are padding (round 5, see the epilogue)
     const long nwg = (long)a.mt * a.nt;
@@ -446,6 +454,19 @@ void launch2(DwPw2Args &a, hipStream_t s, int num_cus)
 #ifdef MBN_LAB
     if (a.dbg) { hipLaunchKernelGGL((dwpw2_bf16<S, BN, true, false>), dim3((unsigned)grid), dim3(NT), 0, s, a); return; }
     if (g_mbn_tune.misc == 32) { hipLaunchKernelGGL((dwpw2_bf16<S, BN, false, true>), dim3((unsigned)grid), dim3(NT), 0, s, a); return; }   // A/B: the 16x16x32 form
+#endif
+#ifdef MBN_LAB
+    if constexpr (BN == 128) {
+        // LAB (exp2 = 44; profiles/r05/u_*): two 4-wave workgroups per CU on 64-row tiles (see the kernel's NW). Measured equal to slower at bf16 0.5x160 (block group
+        // 0.3161-0.3191 -> 0.3205-0.3223 ms) and at 1.0x224 (0.706 -> 0.748): the bf16 blocks keep the VALU busy in either form. Not shipped.
+        const long mt4 = (a.m + 63) / 64, nwg4 = mt4 * a.nt;
+        if (a.fast_off && a.use4 && a.cin <= CMAX4 && a.cout <= NOUT4 && nwg4 >= 4L * num_cus) {
+            a.mt = (int)mt4;
+            long g4 = 2L * num_cus;
+            hipLaunchKernelGGL((dwpw2_bf16<S, 128, false, false, true, 4>), dim3((unsigned)g4), dim3(256), 0, s, a);
+            return;
+        }
+    }
 #endif
     if (a.fast_off) hipLaunchKernelGGL((dwpw2_bf16<S, BN, false, false, true>), dim3((unsigned)grid), dim3(NT), 0, s, a);
     else hipLaunchKernelGGL((dwpw2_bf16<S, BN, false, false, false>), dim3((unsigned)grid), dim3(NT), 0, s, a);
@@ -472,10 +493,11 @@ int mbn_launch_bf16_dwpw2(mbn_context *ctx, hipStream_t stream, void *out, const
     a.dbg = variant >= 100 ? variant - 100 : 0;
     a.inv_wo = 1.0f / (float)out_cols;
     a.inv_ho = 1.0f / (float)out_rows;
+    a.use4 = g_mbn_tune.exp2 == 44 ? 1 : 0;
     a.fast_off = (2.0 * batch * in_rows * in_cols * cin < (double)0x70000000u && (double)batch * in_rows < 8388000.0 && in_cols < 32768 &&
                   out_cols < 32768 && g_mbn_tune.exp0 != 51) ? 1 : 0;
     // 256-column tiles only when they alone fill the chip; pw_tile=1: force the 128-column tile (A/B hook)
-    const bool wide = (cout % 256) == 0 && g_mbn_tune.pw_tile != 1 && ((a.m + BM - 1) / BM) * (cout / 256) >= ctx->num_cus;
+    const bool wide = (cout % 256) == 0 && g_mbn_tune.pw_tile != 1 && ((a.m + BM8 - 1) / BM8) * (cout / 256) >= ctx->num_cus;
     if (stride == 1) {
         if (wide) launch2<1, 256>(a, stream, ctx->num_cus);
         else launch2<1, 128>(a, stream, ctx->num_cus);
