@@ -2423,6 +2423,33 @@ def test_literal_pointwise_mfma_operand_map_with_one_hot_filters(pkg, orc, ctx):
     assert np.array_equal(d_o.download(want.shape, np.uint8), want)
 
 
+def test_literal_pointwise_mfma_random_ragged_shapes(pkg, orc, ctx):
+    """The int8 MFMA form forced (lit_dot = 3) on 24 seeded random shapes — Cin 16..200 (padded to 32s), Cout 16..150 (padded to 32s), planes of 1..211 pixels (ragged 64-pixel
+    tiles, single-pixel FC-like calls), batch 1..3, weights over the whole int8 range — bit-exact against the oracle; every third shape also with one weight outside int8
+    (device fallback to the scalar loop)."""
+    rng = np.random.default_rng(20261004)
+    try:
+        assert ctx.lib.mbn_tune_set(b"lit_dot", 3) == 0
+        for case in range(24):
+            cin, oc = int(rng.integers(16, 201)), int(rng.integers(16, 151))
+            rows, cols, n = int(rng.integers(1, 15)), int(rng.integers(1, 16)), int(rng.integers(1, 4))
+            x = rng.integers(0, 256, (n, cin, rows, cols), dtype=np.uint8)
+            f = rng.integers(-128, 128, (oc, cin), dtype=np.int32)
+            if case % 3 == 2:
+                f[int(rng.integers(0, oc)), int(rng.integers(0, cin))] = int(rng.choice([128, -129, 4000, -70000]))
+            want = np.stack([orc.lit_pointwise(x[i], f, rows, cols, cin, oc, quirks=0) for i in range(n)]).reshape(n, oc, rows, cols)
+            d_x, d_f, d_o = ctx.to_device(x), ctx.to_device(f), ctx.alloc(want.size)
+            ctx.pointwise(d_o.ptr, d_x.ptr, d_f.ptr, rows, cols, cin, oc, pkg.make_ext(batch=n, dtype=pkg.DT_U8, quirks=0))
+            ctx.sync()
+            got = d_o.download(want.shape, np.uint8)
+            assert np.array_equal(got, want), "case %d (cin %d, cout %d, %d x %d, batch %d): %d of %d bytes differ" % (
+                case, cin, oc, rows, cols, n, int((got != want).sum()), want.size)
+            for b in (d_x, d_f, d_o):
+                b.free()
+    finally:
+        ctx.lib.mbn_tune_set(b"lit_dot", 0)
+
+
 def test_net_graph_under_pw_emul(pkg, ctx, tmp_path):
     """mbn_net_set_graph with the opt-in pw_emul: the pre-split filter images are allocated on first use, which may not happen
     inside a capture — the runner makes one eager pass before it captures, and the graph key holds the pw_emul value. Replayed
