@@ -106,13 +106,17 @@ __device__ __forceinline__ void dma_filter(__amdgpu_buffer_rsrc_t rsrc, float *l
 // NW (round 5): 8 = one workgroup of 8 waves per CU on 128-row tiles (rounds 2-4); 4 = 4 waves on 64-row tiles, two independent workgroups per CU (61 KB of LDS each:
 // Cin, Cout <= 256): they fall out of phase by themselves, so one's waits, barrier and epilogue run under the other's depthwise arithmetic. Pays only below the power limit
 // (the fp32 counterpart measured equal at the limit: profiles/r05/j_*) — and, measured, not there either: lab only (launch2).
-template <int S, int BN, bool DBG, bool M16, bool FO = false, int NW = 8>
+// H32 (round 5): Cin = 32 with every depthwise lane busy. The padded form above leaves lanes c4 >= 4 idle (half the VALU lanes of a VALU-bound kernel). Here FOUR lanes
+// cover a pixel pair's 32 channels, so the 512 lanes cover 128 pairs = a 256-row tile; the A tile keeps its 128-byte rows with 16-byte slots 0..3 written (k = 0..31)
+// and the MFMAs run over k-groups 0 and 1 only; 8 waves as 4 x 2 of 64 x 64 (the 256-column variant's wave tile). Block 4-5 of the 0.5x network (32 -> 64, stride 2).
+template <int S, int BN, bool DBG, bool M16, bool FO = false, int NW = 8, bool H32 = false>
 __global__ __launch_bounds__(64 * NW) void dwpw2_bf16(DwPw2Args a)
 {
-    constexpr int NT = 64 * NW, BM = 16 * NW;
+    static_assert(!H32 || (BN == 128 && NW == 8 && !M16 && !DBG), "H32: the shipped 8-wave 128-column form");
+    constexpr int NT = 64 * NW, BM = (H32 ? 32 : 16) * NW;
     constexpr int CMAX = NW == 4 ? CMAX4 : CMAX_G, NOUT = NW == 4 ? NOUT4 : NOUT_G;
     const int dbg = DBG ? a.dbg : 0;
-    constexpr int WN = 64, WM = BN == 256 ? 64 : 32;   // wave tile: 8 waves as 2 x 4 (BN 256) or 4 x 2 (BN 128)
+    constexpr int WN = 64, WM = (BN == 256 || H32) ? 64 : 32;   // wave tile: 8 waves as 2 x 4 (BN 256), 4 x 2 (BN 128), 4 x 2 of 64 x 64 (H32: 256 rows)
     constexpr int WAVES_N = BN / WN;
     static_assert((BM / WM) * WAVES_N == NW, "wave grid");
     constexpr int MI = WM / 32, NI = WN / 32;
@@ -144,7 +148,8 @@ __global__ __launch_bounds__(64 * NW) void dwpw2_bf16(DwPw2Args a)
     if ((int)blockIdx.x >= nwg) return;
 
     // ---- roles of this lane
-    const int c4 = tid & 7, pair = tid >> 3;                        // depthwise: tile rows 2*pair, 2*pair+1, channels 8*c4..+7 of the chunk
+    const int c4 = H32 ? (tid & 3) : (tid & 7), pair = H32 ? (tid >> 2) : (tid >> 3);   // depthwise: tile rows 2*pair, 2*pair+1, channels 8*c4..+7 of the chunk
+    const int c8 = tid & 7;                                         // 16-byte slot of the filter row this lane stages
     const int wm = (wave_u / WAVES_N) * WM, wn = (wave_u % WAVES_N) * WN;      // MFMA tile origin inside the workgroup tile
     const int li = lane & 31, lh = lane >> 5;
     const __amdgpu_buffer_rsrc_t irsrc = mbn_make_rsrc(a.in, a.in_bytes);
@@ -162,10 +167,10 @@ __global__ __launch_bounds__(64 * NW) void dwpw2_bf16(DwPw2Args a)
     for (int p = 0; p < B_LD; p++) {
         const int row = (p * NT + tid) >> 3;
         // channel-paired column blocks (mbn_epilogue.h): LDS filter row `row` holds output channel mbn_pair_channel(row)
-        const unsigned kch = (unsigned)(((c4 ^ (row >> 1)) & 7) * 8);                   // first k of this 16-byte piece
+        const unsigned kch = (unsigned)(((c8 ^ (row >> 1)) & 7) * 8);                   // first k of this 16-byte piece
         b_vo[p] = kch < (unsigned)a.cin ? ((unsigned)mbn_pair_channel(row) * (unsigned)a.cin + kch) * 2u : OOB;
     }
-    const bool cok = c4 * 8 < a.cin;                                            // this lane's 8 channels exist (false only for Cin = 32, c4 >= 4)
+    const bool cok = H32 || c4 * 8 < a.cin;                                            // this lane's 8 channels exist (false only for Cin = 32, c4 >= 4)
     const float *wk = wd_s + c4 * 8;                                           // depthwise taps of this lane's 8 channels (+ kc*64 + tap*cin)
     const float *sk = sb_s + c4 * 8;
 
@@ -408,7 +413,7 @@ __global__ __launch_bounds__(64 * NW) void dwpw2_bf16(DwPw2Args a)
             __builtin_amdgcn_sched_barrier(0);                                                                          \
             mfma_group(1);                                                                                              \
         } else {                                                                                                        \
-        _Pragma("unroll") for (int g = 0; g < 3; g++) {                                                                 \
+        _Pragma("unroll") for (int g = 0; g < (H32 ? 1 : 3); g++) {      /* H32: K = 32 = k-groups 0 and 1 */           \
             ldfrag(P, g + 1, (g + 1) & 1);                                                                              \
             __builtin_amdgcn_sched_barrier(0);                                                                          \
             if (g == 0) mfma_group_first(0, kM == 0); else mfma_group(g & 1);                                           \
@@ -446,6 +451,16 @@ template <int S, int BN>
 void launch2(DwPw2Args &a, hipStream_t s, int num_cus)
 {
     constexpr int BM = BM8, NT = 512;
+    if constexpr (BN == 128) {
+        if (a.cin == 32 && a.fast_off && g_mbn_tune.exp0 != 53) {                  // H32 (lab exp0 = 53: the padded 128-row form instead)
+            a.mt = (int)((a.m + 255) / 256);
+            a.nt = (a.cout + BN - 1) / BN;
+            long g32 = num_cus;
+            if (g32 > (long)a.mt * a.nt) g32 = (long)a.mt * a.nt;
+            hipLaunchKernelGGL((dwpw2_bf16<S, 128, false, false, true, 8, true>), dim3((unsigned)g32), dim3(NT), 0, s, a);
+            return;
+        }
+    }
     a.mt = (int)((a.m + BM - 1) / BM);
     a.nt = (a.cout + BN - 1) / BN;          // Cout = 64 (mod 128): the last tile's upper 64 columns are padding (round 5, see the epilogue)
     const long nwg = (long)a.mt * a.nt;
