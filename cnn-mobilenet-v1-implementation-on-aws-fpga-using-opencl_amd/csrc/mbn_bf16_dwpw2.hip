@@ -404,7 +404,8 @@ __global__ __launch_bounds__(64 * NW) void dwpw2_bf16(DwPw2Args a)
             }                                                                                                           \
             if (validL && !(dbg & 1)) ldx(kL);                                                                        \
         }                                                                                                               \
-        if (!(dbg & 16)) {                                                                                            \
+        /* a wave whose 64-column group lies past Cout (Cout = 64 mod 128) has nothing to multiply: no fragment reads, no MFMAs (wave-uniform) */ \
+        if (!(dbg & 16) && n0M + wn < a.cout) {                                                                       \
         if constexpr (M16) {                                                                                            \
             if (LATEFRAG) ldfrag(P, 0, 0);                                                                              \
             ldfrag(P, 1, 1);                                                                                            \
