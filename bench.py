@@ -682,6 +682,8 @@ def run_one(args, env):
             if "roofline" in out:       # scalars the driver's record keeps: the step runs at the package power limit, which sets the held clock
                 out["roofline"]["package_power_w"] = power["package_w"]
                 out["roofline"]["power_cap_w"] = power["cap_w"]
+                if power["package_w"] and power.get("ms_per_step_while_sampling"):      # at the limit, speed is energy per image
+                    out["roofline"]["images_per_joule"] = round(args.batch / (power["ms_per_step_while_sampling"] * 1e-3) / power["package_w"], 2)
         out["h2d_ms_per_batch"] = round(h2d_ms, 3)   # PCIe-inclusive rate = batch / (ms_per_step + this)
         if step_ms.size:
             out["step_ms"] = {"median": round(float(np.median(step_ms)), 4), "p10": round(float(np.percentile(step_ms, 10)), 4),
