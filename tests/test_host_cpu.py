@@ -633,3 +633,33 @@ def test_bench_line_is_compact_parseable_and_keeps_the_contract(tmp_path):
     args = bench.parse_args(["--record", str(tmp_path / "full.json")])
     path = bench.write_record(args, _fake_bench_record())
     assert json.load(open(path))["layers"][0]["stage"] == "pointwise"
+
+
+def test_bench_power_sampler_parses_rocm_smi_json(monkeypatch):
+    """bench.py's sample_power (round 5: package power and core clock while the step runs back to back, AFTER the timed region) against a canned rocm-smi: the JSON
+    shapes of `--showpower --showclocks --json` and `--showmaxpower --json` as the MI355X boxes print them; a missing rocm-smi gives None, never an exception."""
+    import importlib
+    import shutil
+    import subprocess
+    import sys
+    import types
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    bench = importlib.import_module("bench")
+    calls = {"n": 0}
+
+    def fake_run(cmd, **kw):
+        calls["n"] += 1
+        if "--showmaxpower" in cmd:
+            out = {"card0": {"Max Graphics Package Power (W)": "1400.0"}}
+        else:
+            out = {"card0": {"fclk clock speed:": "(1250Mhz)", "mclk clock speed:": "(2000Mhz)", "sclk clock speed:": "(%dMhz)" % (2280 + calls["n"] % 3), "sclk clock level:": "1",
+                             "Current Socket Graphics Package Power (W)": "%d.0" % (1340 + calls["n"] % 5)}}
+        return types.SimpleNamespace(stdout=json.dumps(out), returncode=0)
+    monkeypatch.setattr(shutil, "which", lambda name: "/opt/rocm/bin/rocm-smi")
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    steps = {"n": 0}
+    p = bench.sample_power(lambda: steps.__setitem__("n", steps["n"] + 1), lambda: None, seconds=0.9)
+    assert p is not None and p["cap_w"] == 1400.0 and 1340 <= p["package_w"] <= 1344 and 2280 <= p["sclk_mhz"] <= 2282 and p["samples"] >= 3
+    assert steps["n"] > 0 and p["ms_per_step_while_sampling"] > 0
+    monkeypatch.setattr(shutil, "which", lambda name: None)
+    assert bench.sample_power(lambda: None, lambda: None, seconds=0.1) is None
