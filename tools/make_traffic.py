@@ -39,7 +39,7 @@ def assemble():
     The fp32 section stays at the top level (bench.py's default line), the bf16 sections under their own keys."""
     import datetime
     d, sha = sys.argv[2], sys.argv[3]
-    cmd = "bash tools/r03_final.sh B %s (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE --kernel-trace over tools/layer_bench.py --iters 3 --warmup 1)" % sha
+    cmd = "bash tools/r05_traffic.sh %s (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE --kernel-trace over tools/layer_bench.py --iters 3 --warmup 1)" % sha
 
     def section(key, workload):
         pw, dw = json.load(open("%s/%s_pw.json" % (d, key))), json.load(open("%s/%s_dw.json" % (d, key)))
