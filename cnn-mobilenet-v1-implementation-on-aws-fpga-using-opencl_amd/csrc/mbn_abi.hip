@@ -858,6 +858,13 @@ int mbn_dwpw_fused(mbn_context *ctx, void *out, const void *in, const void *wd, 
                                 cin, cout, stride, pad_top, pad_left) == MBN_OK)
         return sc.finish(MBN_OK);
     const int dv = g_mbn_tune.dwpw_variant;
+    // round 6: the wave-private form (mbn_f32_dwpw3.hip: no barrier in the loop, filter slice resident in LDS) where it applies
+    // (Cin 64 / 128 / 256). Lab A/B: dwpw_variant 11 = always where eligible, 12 = never, 300 + bits = its ablation build.
+    if ((dv == 11 || dv >= 300 || (dv == 0 && MBN_DWPW3_DEFAULT)) &&
+        mbn_f32_dwpw3_eligible(ctx, batch, in_rows, in_cols, out_rows, out_cols, cin, cout, stride, pad_top, pad_left))
+        return sc.finish(mbn_launch_f32_dwpw3(ctx, s, (float *)out, (const float *)in, (const float *)wd, (const float *)s2,
+                                              (const float *)b2, (const float *)wp, (const float *)s3, (const float *)b3, batch,
+                                              in_rows, in_cols, out_rows, out_cols, cin, cout, stride, pad_top, pad_left));
     const long tiles256 = (((long)batch * out_rows * out_cols + 127) / 128) * (cout / 256);
     const bool small = tiles256 < ctx->num_cus;
     // stride-2 blocks (15 x-window loads per lane and step): with the loads spread under the MFMA groups the unified kernel also wins at

@@ -170,6 +170,14 @@ int mbn_launch_f32_dwpw2(mbn_context *ctx, hipStream_t stream, float *out, const
                          const float *s2, const float *b2, const float *wp, const float *s3, const float *b3, int batch,
                          int in_rows, int in_cols, int out_rows, int out_cols, int cin, int cout, int stride, int pad_top,
                          int pad_left);
+// wave-private form of the fp32 block (mbn_f32_dwpw3.hip, round 6)
+#define MBN_DWPW3_DEFAULT 0
+int mbn_f32_dwpw3_eligible(const mbn_context *ctx, int batch, int in_rows, int in_cols, int out_rows, int out_cols, int cin, int cout, int stride,
+                           int pad_top, int pad_left);
+int mbn_launch_f32_dwpw3(mbn_context *ctx, hipStream_t stream, float *out, const float *in, const float *wd,
+                         const float *s2, const float *b2, const float *wp, const float *s3, const float *b3, int batch,
+                         int in_rows, int in_cols, int out_rows, int out_cols, int cin, int cout, int stride, int pad_top,
+                         int pad_left);
 int mbn_bf16_dwpw_check(const void *out, const void *in, const float *wd, const float *s2, const float *b2, const void *wp,
                         const float *s3, const float *b3, int batch, int in_rows, int in_cols, int out_rows, int out_cols,
                         int cin, int cout, int stride, int pad_top, int pad_left);

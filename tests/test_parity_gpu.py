@@ -1021,16 +1021,18 @@ DWPW_SHAPES = [  # (batch, in side, Cin, Cout, stride)
     (1, 28, 256, 512, 2),                                  # L12-13: two 256-column tiles, depthwise recomputed
     (3, 14, 32, 128, 1), (1, 6, 64, 384, 1), (5, 12, 96, 128, 2), (1, 2, 32, 256, 1),          # ragged M, 3 n-tiles, tiny maps
     (2, 14, 512, 512, 1), (3, 28, 512, 1024, 2), (40, 14, 64, 256, 1),                         # L14-15, Cin 512 stride 2; many tiles per workgroup
+    (70, 28, 128, 128, 1), (9, 28, 64, 384, 2), (33, 10, 256, 128, 1),      # r6 (wave-private form): several tiles per wave + a remainder round; 3 slices; ragged last tile
 ]
 
 
-@pytest.mark.parametrize("variant", [0, 6, 5, 7, 8])
+@pytest.mark.parametrize("variant", [0, 6, 5, 7, 8, 11, 12])
 @pytest.mark.parametrize("shape", DWPW_SHAPES)
 def test_f32_dwpw_fused(pkg, orc, ctx, shape, variant):
     """mbn_dwpw_fused vs mbn_depthwise + mbn_pointwise (same arithmetic order -> bit-identical) and vs the oracle.
     variant 6 / 5 (lab build): the unified kernel with 12 / 16 waves on 192- / 256-row tiles (128-column tiles only);
     7 / 8 (lab build, round 4): the x window requested two steps ahead into a second register set (7: stride 1 with 128-column tiles;
-    8: also stride 2 with 128-column tiles and the taps read inside the step)."""
+    8: also stride 2 with 128-column tiles and the taps read inside the step); 11 / 12 (lab build, round 6): the wave-private form
+    (mbn_f32_dwpw3.hip) wherever eligible / nowhere."""
     n, h, cin, cout, stride = shape
     if variant:
         _tune_lab(ctx, b"dwpw_variant", variant)
