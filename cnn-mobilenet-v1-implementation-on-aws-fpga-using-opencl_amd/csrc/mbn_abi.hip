@@ -860,7 +860,7 @@ int mbn_dwpw_fused(mbn_context *ctx, void *out, const void *in, const void *wd, 
     const int dv = g_mbn_tune.dwpw_variant;
     // round 6: the wave-private form (mbn_f32_dwpw3.hip: no barrier in the loop, filter slice resident in LDS) where it applies
     // (Cin 64 / 128 / 256). Lab A/B: dwpw_variant 11 = always where eligible, 12 = never, 300 + bits = its ablation build.
-    if ((dv == 11 || dv >= 300 || (dv == 0 && MBN_DWPW3_DEFAULT)) &&
+    if ((dv == 11 || dv >= 300 || (dv == 0 && MBN_DWPW3_DEFAULT(stride, cin))) &&
         mbn_f32_dwpw3_eligible(ctx, batch, in_rows, in_cols, out_rows, out_cols, cin, cout, stride, pad_top, pad_left))
         return sc.finish(mbn_launch_f32_dwpw3(ctx, s, (float *)out, (const float *)in, (const float *)wd, (const float *)s2,
                                               (const float *)b2, (const float *)wp, (const float *)s3, (const float *)b3, batch,

@@ -5,32 +5,38 @@
 //   out[m][n] = relu6( s3[n] * sum_c relu6( s2[c] * sum_{dy,dx} in[pix(m)+(dy,dx)][c] * wd[dy][dx][c] + b2[c] ) * wp[n][c] + b3[n] )
 //
 // Why a third form. The unified-wave kernel (dwpw2) hands the depthwise output of a 32-channel chunk from the 8 waves that
-// produced it to the 8 waves that multiply it through a workgroup barrier — one barrier per 32 MFMAs per wave, with ONE
-// workgroup per CU, so at every barrier the CU's matrix pipes drain and each SIMD's two waves wait for each other
-// (round 5 stamps, profiles/r05/g_*: 1100-3500 cycles of wait + barrier in a 6700-cycle step whose MFMAs take 4096; the
-// MFMA-only skeleton of that kernel runs at 1.33-1.48x its MFMA time, the stand-alone GEMM with four independent
-// 4-wave workgroups per CU at 1.10x). Here no wave ever waits for another one:
-//   * a wave owns 32 output pixels x 128 output channels (64 accumulators): it computes the depthwise output of ITS 32
-//     pixels, 16 channels at a time (lane = 2 adjacent pixels x 4 channels, as in dwpw2), writes them into its private
-//     2 KB A tile in LDS and reads them back as MFMA fragments — LDS operations of one wave execute in order, so the
-//     hand-over needs no barrier and no wait beyond the read's own lgkmcnt;
-//   * the pointwise filter slice [128 output channels][Cin] stays RESIDENT in LDS for the whole launch (<= 130 KB: Cin
-//     <= 256), loaded once per workgroup: no filter DMA in the loop, no counted vmcnt, no barrier for it either. A
-//     block with more than 128 output channels runs as Cout/128 slices in different workgroups (the depthwise part is
-//     recomputed per slice: +9/128 of the slice's FMAs);
-//   * the 8 waves of a workgroup (2 per SIMD, <= 256 VGPRs) are independent persistent pipelines over their own tile
-//     sequences; the SIMD's issue logic interleaves one wave's MFMAs with the other's loads, LDS traffic and waits.
-// Per 16-channel step and wave: 3 x (S+3) buffer_load_dwordx4 (one step ahead of their use), 36 v_pk_fma_f32 + 4 + 8
-// (BN, clamp), 2 ds_write_b128, 2 + 8 fragment reads, 11 tap reads, 32 MFMAs — the k loop of a tile is fully unrolled
-// (Cin is a template parameter), so every LDS address is a lane constant + an immediate and every x load a lane offset +
-// an immediate: no address arithmetic inside a tile.
-// Arithmetic order = mbn_f32_dw.hip (dy-major fma chain, BN, clamp) and mbn_f32_pw.hip (k pairs (8g+s, 8g+4+s) in
-// increasing g, s on v_mfma_f32_32x32x2_f32): bit-identical to the two launches and to dwpw2.
-// LDS images: filter rows padded to Cin + 4 floats (fragment reads of 16 lanes fall on 16 different 16-byte bank
-// groups); A tile rows of 16 floats with the 16-byte unit XORed by (row >> 2) & 3; tile row = 16 * (pixel & 1) +
-// (pixel >> 1), so both ds_write_b128 of a lane and the fragment ds_read_b128 are conflict-free (MI355X_MICROARCH.md
-// §LDS lane groups). Epilogue: LDS filter row 32 t + l holds output channel 4 l + t, so lane l's four accumulator
-// blocks are 4 adjacent channels: one buffer_store_dwordx4 per lane and row pair = 512 contiguous bytes per pixel.
+// produced it to the 8 waves that multiply it through a workgroup barrier, one barrier per 32 MFMAs per wave with ONE workgroup
+// per CU, and streams the pointwise filter through LDS once per tile (as many bytes as the activations it multiplies). Here:
+//   * a wave owns 32 output pixels x 128 output channels (64 accumulators): it computes the depthwise output of ITS pixels
+//     (lane = 2 adjacent pixels x 4 channels, as in dwpw2), writes them into its private A tile in LDS and reads them back as
+//     MFMA fragments — LDS operations of one wave execute in order, so the hand-over needs no barrier;
+//   * the pointwise filter slice [128 output channels][Cin] stays RESIDENT in LDS for the whole launch (<= 130 KB: Cin <= 256),
+//     loaded once per workgroup. A block with more than 128 output channels runs as Cout/128 slices in different workgroups
+//     (the depthwise part is recomputed per slice: +9/128 of the slice's FMAs);
+//   * the 8 waves of a workgroup (2 per SIMD, <= 256 VGPRs) are independent persistent pipelines over their own tile sequences.
+// What the first build of this form measured (profiles/r06/b_*, d_*): the barrier was NOT what the block kernels lose their time to —
+// their x-window loads are: every input byte is requested six times (3 rows x 2 column overlaps), and what the L1 does not absorb goes
+// to the L2 (TCP_TCC_READ_REQ: dwpw2 2.0x the unique bytes + the filter, the strip-tiled first build of this kernel 5.2x with no L1 reuse
+// between its free-running waves). So the tile and lane maps are built for the L1:
+//   * a tile is a 2-D PATCH, not a strip: the 16 pixel pairs of a tile are consecutive in a band-major zigzag order (bands of R = 4 | 2 | 1
+//     output rows; inside a band column pair by column pair, the band's R rows innermost), i.e. R rows x 16/R column pairs. The three
+//     window rows of vertically adjacent pixels are then requested by the same wave within one step (L1 hits), and a patch touches
+//     (R + 2) x (32/R + 2) input pixels instead of 3 x 34;
+//   * KS = 32 (Cin <= 128): a pixel's 32 channels of a chunk = one 128-byte line per load instruction (8 lanes x 16 B), the tile's 16 pairs
+//     in two half-rounds of 8; KS = 16 (Cin = 256, where LDS has no room for the 32-channel A tiles): 4 lanes x 16 B = half a line.
+// A substep = 32 MFMAs (k groups 2 s, 2 s + 1 of the tile) + one depthwise half-round (KS / 16 substeps ahead of the MFMAs that consume it)
+// + the window loads of the half-round after that, cut by filter row in front of the four MFMA groups. The substeps of a tile are fully
+// unrolled (Cin is a template parameter): every LDS address is a lane constant + an immediate, every x load a lane offset + an immediate.
+// The zigzag map lives in set_offsets alone: it leaves the pair's output pixel offset in LDS, from where the epilogue reads the 8 it needs.
+// Arithmetic order = mbn_f32_dw.hip (dy-major fma chain, BN, clamp) and mbn_f32_pw.hip (k pairs (8g+s, 8g+4+s) in increasing g, s on
+// v_mfma_f32_32x32x2_f32): bit-identical to the two launches and to dwpw2.
+// LDS images: filter rows padded to Cin + 4 floats; A tile row = 16 * (pixel & 1) + pair, 16-byte units XORed by (row >> 2) & 3 (KS 16) or
+// (row >> 1) & 7 (KS 32): the ds_write_b128 of the depthwise lanes and the fragment ds_read_b128 are conflict-free (MI355X_MICROARCH.md
+// §LDS lane groups). Epilogue: LDS filter row 32 t + l holds output channel 4 l + t, so lane l's four accumulator blocks are 4 adjacent
+// channels: one buffer_store_dwordx4 per lane and row pair = 512 contiguous bytes per pixel.
+// gfx950 hazard found here (profiles/r06/a_*): a buffer_store_dwordx4 followed directly by a VALU write of its first data register stores
+// the NEW value in lanes 12-15 of every 16 (the ">64-bit store data" hazard; the compiler pads only the immediate-soffset form): the
+// epilogue issues its stores in pairs and waits two states behind each pair, pinned by sched_barriers.
 #include "mbn_internal.h"
 #include "mbn_epilogue.h"
 
@@ -42,8 +48,8 @@ typedef unsigned u4 __attribute__((ext_vector_type(4)));
 typedef mbn_f16v f16v;
 
 constexpr int BN3 = 128;                       // output channels per workgroup slice
-constexpr int WT = 32;                         // output pixels per wave tile
-constexpr int KS = 16;                         // channels per step
+constexpr int WT = 32;                         // output pixels per wave tile (16 pixel pairs)
+constexpr unsigned PO_INVALID = 0x80000000u;   // output offset of a pixel pair past the end: beyond any descriptor, the store is dropped
 
 struct DwPw3Args {
     float *out;
@@ -55,10 +61,13 @@ struct DwPw3Args {
     int nh;                 // 128-channel slices = cout / 128
     int tiles;              // wave tiles = ceil(m / 32)
     unsigned in_bytes;
-    unsigned wo_m, wo_s, ho_m, ho_s;   // floor(v / wo) = umulhi(v, wo_m) >> wo_s for v < 2^31 (m == 0: the divisor is 1)
-    float inv_wo, inv_ho;   // 1 / wo, 1 / ho
+    // zigzag order of the pixel pairs: bands of R = 1 << rsh output rows; pb = R * wo / 2 pairs per band, bi = ho / R bands per image
+    int rsh;
+    unsigned pb, bi;
+    unsigned pb_m, pb_s, bi_m, bi_s;   // floor(v / d) = umulhi(v, d_m) >> d_s for v < 2^31 (m == 0: the divisor is 1)
+    float inv_pb, inv_bi;
     int dbg;                // lab ablations (dwpw_variant = 300 + bits): 1 no x loads after the prologue, 2 no depthwise math, 4 no stores, 16 no MFMA,
-                            // 32 no tap reads, 64 no BN / clamp / A-tile writes, 128 no fragment reads, 256 no per-tile zeroing / window offsets (timing only)
+                            // 32 no tap reads, 64 no BN / clamp / A-tile writes, 128 no fragment reads, 256 no per-tile window offsets (timing only)
 };
 
 __device__ __forceinline__ float relu6(float v) { return fminf(fmaxf(v, 0.f), 6.f); }
@@ -68,22 +77,27 @@ __device__ __forceinline__ f4 bn_relu6(f4 a, f4 s, f4 b)
     return f4{ relu6(v.x), relu6(v.y), relu6(v.z), relu6(v.w) };
 }
 
-// S = depthwise stride (1, 2), CIN = input channels (64, 128, 256). DBG: the lab instantiation with the ablation switches.
-template <int S, int CIN, bool DBG>
+// S = depthwise stride (1, 2), CIN = input channels (64, 128, 256), KS = channels per depthwise half-round and lane group (16: 4 lanes per
+// pixel pair, all 16 pairs at once; 32: 8 lanes per pair, 8 pairs per half-round). DBG: the lab instantiation with the ablation switches.
+template <int S, int CIN, int KS, bool DBG>
 __global__ __launch_bounds__(512) void dwpw3_f32(DwPw3Args a)
 {
     constexpr int XC = S + 3;                          // input columns feeding 2 adjacent output pixels
-    constexpr int NK = CIN / KS;                       // steps per tile
+    constexpr int NS = CIN / 16;                       // substeps per tile (32 MFMAs each)
+    constexpr int AH = KS / 16;                        // half-rounds per chunk = substeps between a half-round and the MFMAs of its chunk
+    constexpr int LPP = KS / 4;                        // lanes per pixel pair
     constexpr int LDB = CIN + 4;                       // padded filter row (floats)
-    static_assert(NK >= 4 && (CIN % 64) == 0, "Cin in multiples of 64");
-    __shared__ __attribute__((aligned(16))) float lds[BN3 * LDB + 8 * WT * KS + 11 * CIN + 2 * BN3];
-    float *const wp_s = lds, *const a_s = wp_s + BN3 * LDB, *const wd_s = a_s + 8 * WT * KS, *const sb_s = wd_s + 9 * CIN;
+    constexpr int ABUF = WT * KS;                      // floats per A buffer; AH buffers per wave (KS 32: by chunk parity)
+    static_assert(NS >= 4 && (CIN % 64) == 0 && (KS == 16 || KS == 32), "Cin in multiples of 64");
+    __shared__ __attribute__((aligned(16))) float lds[BN3 * LDB + 8 * AH * ABUF + 11 * CIN + 2 * BN3 + 8 * 32];
+    float *const wp_s = lds, *const a_s = wp_s + BN3 * LDB, *const wd_s = a_s + 8 * AH * ABUF, *const sb_s = wd_s + 9 * CIN;
     float *const sc3_s = sb_s + 2 * CIN, *const sh3_s = sc3_s + BN3;
+    unsigned *const po_s = reinterpret_cast<unsigned *>(sh3_s + BN3);      // [wave][tile parity][16 pairs]: output byte offset of each pair's first pixel
     const int dbg = DBG ? a.dbg : 0;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const unsigned mtot = (unsigned)a.m;
+    const unsigned ptot = (unsigned)(a.m >> 1);        // pixel pairs
 
     // ---- which slice and which tiles. Workgroup b sits on XCD b & 7 (dispatch order; used for locality only). The XCD's
     // workgroups split into nh slice groups; the tile range of the XCD is walked by the JM workgroups of a slice group,
@@ -95,7 +109,7 @@ __global__ __launch_bounds__(512) void dwpw3_f32(DwPw3Args a)
     const int per_round = JM * 8;
     const int full = (r1 - r0) / per_round, rem = (r1 - r0) - full * per_round;
     const int slot = jm * 8 + wave_u, eslot = wave_u * JM + jm;
-    const int ntile = jm < JM ? full + (eslot < rem ? 1 : 0) : 0;          // (workgroups beyond nh * JM per XCD: none launched)
+    const int ntile = full + (eslot < rem ? 1 : 0);
     auto tile_at = [&](int i) __attribute__((always_inline)) { return i < full ? r0 + i * per_round + slot : r0 + full * per_round + eslot; };
 
     // ---- resident images: filter slice (row 32 t + l <- channel n0 + 4 l + t), depthwise taps, scale / shift
@@ -141,73 +155,107 @@ __global__ __launch_bounds__(512) void dwpw3_f32(DwPw3Args a)
     if (ntile == 0) return;
 
     // ---- roles of this lane
-    const int q = lane >> 2, c4 = lane & 3;                         // depthwise: pixels 2q, 2q+1 of the tile, channels 4*c4..+3 of the step
+    const int qh = lane / LPP, cl = lane % LPP;                     // depthwise: pair qh (+ 8 in the second half-round of KS 32), channels 4*cl..+3 of the chunk
     const int li = lane & 31, lh = lane >> 5;                       // MFMA: row / column li, k half lh
     const __amdgpu_buffer_rsrc_t irsrc = mbn_make_rsrc(a.in, a.in_bytes);
     const __amdgpu_buffer_rsrc_t orsrc = mbn_make_rsrc(a.out, (unsigned)(a.m * a.cout * 4));
-    float *const a_w = a_s + wave_u * (WT * KS);
-    const int aw0 = q * KS + ((c4 ^ ((q >> 2) & 3)) << 2);          // tile row q      <- pixel 2q
-    const int aw1 = aw0 + 16 * KS;                                  // tile row 16 + q <- pixel 2q + 1 (same XOR: (16 + q) >> 2 & 3 == q >> 2 & 3)
-    const int fra0 = li * KS + (((0 + lh) ^ ((li >> 2) & 3)) << 2);  // A fragments: row li, 16-byte unit 2 g + lh
-    const int fra1 = li * KS + (((2 + lh) ^ ((li >> 2) & 3)) << 2);
-    const float *const bl01 = wp_s + li * LDB + lh * 4;             // B fragments of blocks 0, 1: + t*32*LDB + k*16 + g*8 (immediates)
+    float *const a_w = a_s + wave_u * (AH * ABUF);
+    unsigned *const po_w = po_s + wave_u * 32;
+    // A-tile slot of (half-round hh, pixel e of the pair): tile row 16 e + pair, 16-byte unit cl XORed by the row's swizzle term
+    auto aw_at = [&](const int hh) __attribute__((always_inline)) {
+        const int row = 8 * hh * (AH - 1) + qh;                     // KS 32: pair = 8 hh + qh; KS 16: pair = qh
+        return KS == 16 ? row * KS + ((cl ^ ((row >> 2) & 3)) << 2) : row * KS + ((cl ^ ((row >> 1) & 7)) << 2);
+    };
+    const int aw[2] = { aw_at(0), aw_at(1) };                       // (+ 16 * KS floats for the pair's second pixel: the XOR term is the same)
+    // A fragment of 16-byte unit u: row li
+    auto fra_at = [&](const int u) __attribute__((always_inline)) {
+        return KS == 16 ? li * KS + (((u + lh) ^ ((li >> 2) & 3)) << 2) : li * KS + (((u + lh) ^ ((li >> 1) & 7)) << 2);
+    };
+    const int fra[4] = { fra_at(0), fra_at(2), fra_at(KS == 32 ? 4 : 0), fra_at(KS == 32 ? 6 : 2) };
+    const float *const bl01 = wp_s + li * LDB + lh * 4;             // B fragments of blocks 0, 1: + t*32*LDB + s*16 + g*8 (immediates)
     const float *const bl23 = bl01 + 64 * LDB;                      // ... of blocks 2, 3 (second base: the immediate is 16 bits)
-    const float *const wk = wd_s + c4 * 4;                          // taps of this lane's channels: + k*16 + tap*CIN
-    const float *const sk = sb_s + c4 * 4;
+    const float *const wk = wd_s + cl * 4;                          // taps of this lane's channels: + chunk*KS + tap*CIN
+    const float *const sk = sb_s + cl * 4;
 
-    unsigned off[3][XC];
-    // Window offsets of the tile at m0 (the full-rate form of dwpw2's set_offsets_fast; the launcher admits only inputs in its range):
-    // tile's first pixel on the scalar unit, the lane's pixel by two float-reciprocal divisions of small numbers (exact), one 32-bit
-    // multiply; validity separable by row and column: an invalid row is 0x80000000, an invalid column 0x70000000, so any sum with an
-    // invalid term lies beyond the descriptor's num_records without wrapping and the buffer unit returns zeros (= the zero padding).
-    auto set_offsets = [&](unsigned m0) __attribute__((always_inline)) {
-        const unsigned q0 = a.wo_m ? __umulhi(m0, a.wo_m) >> a.wo_s : m0;
-        const unsigned x0 = m0 - q0 * (unsigned)a.wo;
-        const unsigned nn0 = a.ho_m ? __umulhi(q0, a.ho_m) >> a.ho_s : q0;
-        const unsigned y0 = q0 - nn0 * (unsigned)a.ho;
-        const unsigned r = x0 + 2u * (unsigned)q;
-        const unsigned q1 = (unsigned)__builtin_fmaf((float)r, a.inv_wo, 0.5f * a.inv_wo);
-        const unsigned x = r - q1 * (unsigned)a.wo;
-        const unsigned yy = y0 + q1;
-        const unsigned q2 = (unsigned)__builtin_fmaf((float)yy, a.inv_ho, 0.5f * a.inv_ho);
-        const unsigned y = yy - q2 * (unsigned)a.ho;
-        const unsigned n = nn0 + q2;
-        const bool mok = m0 + 2u * (unsigned)q < mtot;
+    // SEP (stride 2 with two half-rounds: 2 x 15 offsets do not fit beside the 15-register-wider window): the offsets stay in their separable
+    // form rowv + colv (16 registers) and every load adds its pair (one full-rate v_add_u32 per load)
+    constexpr bool SEP = S == 2 && AH == 2;
+    unsigned off[SEP ? 1 : AH][SEP ? 1 : 3][SEP ? 1 : XC];
+    unsigned rowv_k[SEP ? AH : 1][3], colv_k[SEP ? AH : 1][XC];
+    // Window offsets of half-round hh of the tile whose first pair is p0 (wave-uniform), and the pair's output offset into po_w[slot].
+    // Tile-uniform part on the scalar unit (magic division); the lane's pair by float-reciprocal divisions of small numbers (exact: the
+    // quotients' numerators stay below 2^21, see the launcher's range checks); validity separable by row and column: an invalid row is
+    // 0x80000000, an invalid column 0x70000000, so any sum with an invalid term lies beyond the descriptor's num_records without wrapping and
+    // the buffer unit returns zeros (= the zero padding).
+    auto set_offsets = [&](unsigned p0, const int hh, int pslot) __attribute__((always_inline)) {
+        const unsigned bg0 = a.pb_m ? __umulhi(p0, a.pb_m) >> a.pb_s : p0;          // band (over the whole batch) of the tile's first pair
+        const unsigned i0 = p0 - bg0 * a.pb;
+        const unsigned im0 = a.bi_m ? __umulhi(bg0, a.bi_m) >> a.bi_s : bg0;        // its image
+        const unsigned b0 = bg0 - im0 * a.bi;
+        const unsigned qq = (unsigned)(8 * hh * (AH - 1) + qh);
+        const unsigned i1 = i0 + qq;
+        const unsigned dq = (unsigned)__builtin_fmaf((float)i1, a.inv_pb, 0.5f * a.inv_pb);
+        const unsigned i = i1 - (unsigned)__mul24((int)dq, (int)a.pb);
+        const unsigned b1 = b0 + dq;
+        const unsigned dn = (unsigned)__builtin_fmaf((float)b1, a.inv_bi, 0.5f * a.inv_bi);
+        const unsigned band = b1 - (unsigned)__mul24((int)dn, (int)a.bi);
+        const unsigned n = im0 + dn;
+        const unsigned y = (band << a.rsh) + (i & ((1u << a.rsh) - 1u)), x = (i >> a.rsh) << 1;
+        const bool mok = p0 + qq < ptot;
         const int iy0 = (int)y * S - a.pad_top, ix0 = (int)x * S - a.pad_left;
         const unsigned cs = (unsigned)CIN * 4u, rs = (unsigned)a.w * cs;
         const int pix = __mul24((int)(n * (unsigned)a.h) + iy0, a.w) + ix0;
-        const unsigned base = (unsigned)pix * cs + (unsigned)(c4 * 16);
+        const unsigned base = (unsigned)pix * cs + (unsigned)(cl * 16);
         unsigned rowv[3], colv[XC];
 #pragma unroll
         for (int dy = 0; dy < 3; dy++) rowv[dy] = (mok && (unsigned)(iy0 + dy) < (unsigned)a.h) ? base + dy * rs : 0x80000000u;
 #pragma unroll
         for (int jj = 0; jj < XC; jj++) colv[jj] = ((unsigned)(ix0 + jj) < (unsigned)a.w) ? jj * cs : 0x70000000u;
+        if constexpr (SEP) {
 #pragma unroll
-        for (int dy = 0; dy < 3; dy++)
+            for (int dy = 0; dy < 3; dy++) rowv_k[hh][dy] = rowv[dy];
 #pragma unroll
-            for (int jj = 0; jj < XC; jj++) off[dy][jj] = rowv[dy] + colv[jj];
+            for (int jj = 0; jj < XC; jj++) colv_k[hh][jj] = colv[jj];
+        } else {
+#pragma unroll
+            for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+                for (int jj = 0; jj < XC; jj++) off[hh][dy][jj] = rowv[dy] + colv[jj];
+        }
+        const unsigned opix = (unsigned)__mul24((int)(n * (unsigned)a.ho + y), a.wo) + x;
+        const unsigned po = mok ? opix * ((unsigned)a.cout * 4u) : PO_INVALID;
+        if (cl == 0) po_w[pslot * 16 + (int)qq] = po;
+    };
+    auto set_offsets_tile = [&](unsigned p0, int pslot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int hh = 0; hh < AH; hh++) set_offsets(p0, hh, pslot);
     };
 
+    // Substep index u (of a tile) -> the half-round's offset set, A buffer and channel offsets
+    //   KS 16: half-round u = all pairs, channels 16 u;  KS 32: chunk u >> 1, half u & 1 (pairs 8 (u & 1) + qh), channels 32 (u >> 1)
     f4 xr[3][XC];
-    auto ldx_row = [&](const int k, const int dy) __attribute__((always_inline)) {
+    auto ldx_row = [&](const int u, const int dy) __attribute__((always_inline)) {
+        const int hh = AH == 2 ? (u & 1) : 0, cb = AH == 2 ? (u >> 1) * 128 : u * 64;
 #pragma unroll
         for (int jj = 0; jj < XC; jj++)
-            xr[dy][jj] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(irsrc, off[dy][jj] + (unsigned)(k * KS * 4), 0, 0));
+            xr[dy][jj] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(irsrc, (SEP ? rowv_k[hh][dy] + colv_k[hh][jj] : off[SEP ? 0 : hh][SEP ? 0 : dy][SEP ? 0 : jj]) + (unsigned)cb, 0, 0));
     };
     f4 wrow[3], wss[2];
-    auto ldw_row = [&](const int k, const int dy) __attribute__((always_inline)) {
+    auto ldw_row = [&](const int u, const int dy) __attribute__((always_inline)) {
         if (dbg & 32) return;
+        const int cf = AH == 2 ? (u >> 1) * 32 : u * 16;
 #pragma unroll
-        for (int dx = 0; dx < 3; dx++) wrow[dx] = *reinterpret_cast<const f4 *>(wk + k * KS + (dy * 3 + dx) * CIN);
+        for (int dx = 0; dx < 3; dx++) wrow[dx] = *reinterpret_cast<const f4 *>(wk + cf + (dy * 3 + dx) * CIN);
     };
-    auto ldw_ss = [&](const int k) __attribute__((always_inline)) {
+    auto ldw_ss = [&](const int u) __attribute__((always_inline)) {
         if (dbg & 32) return;
-        wss[0] = *reinterpret_cast<const f4 *>(sk + k * KS);
-        wss[1] = *reinterpret_cast<const f4 *>(sk + CIN + k * KS);
+        const int cf = AH == 2 ? (u >> 1) * 32 : u * 16;
+        wss[0] = *reinterpret_cast<const f4 *>(sk + cf);
+        wss[1] = *reinterpret_cast<const f4 *>(sk + CIN + cf);
     };
     f4 dacc0 = f4{ 0.f, 0.f, 0.f, 0.f }, dacc1 = dacc0;
-    // filter row dy of step k into the two running sums (dy = 0 starts them), then the taps the next piece needs
-    auto dw_row = [&](const int k, const int dy) __attribute__((always_inline)) {
+    // filter row dy of half-round u into the two running sums (dy = 0 starts them), then the taps the next piece needs
+    auto dw_row = [&](const int u, const int dy) __attribute__((always_inline)) {
         if (dy == 0) {
             dacc0 = f4{ 0.f, 0.f, 0.f, 0.f };
             dacc1 = dacc0;
@@ -219,27 +267,29 @@ __global__ __launch_bounds__(512) void dwpw3_f32(DwPw3Args a)
                 dacc1 = __builtin_elementwise_fma(xr[dy][dx + S], wrow[dx], dacc1);
             }
         }
-        if (dy < 2) ldw_row(k, dy + 1);
-        else ldw_ss(k);
+        if (dy < 2) ldw_row(u, dy + 1);
+        else ldw_ss(u);
     };
-    auto dw_fin = [&]() __attribute__((always_inline)) {
+    auto dw_fin = [&](const int u) __attribute__((always_inline)) {
         if (dbg & 64) return;
-        *reinterpret_cast<f4 *>(a_w + aw0) = bn_relu6(dacc0, wss[0], wss[1]);
-        *reinterpret_cast<f4 *>(a_w + aw1) = bn_relu6(dacc1, wss[0], wss[1]);
+        const int hh = AH == 2 ? (u & 1) : 0, buf = AH == 2 ? ((u >> 1) & 1) * ABUF : 0;
+        *reinterpret_cast<f4 *>(a_w + buf + aw[hh]) = bn_relu6(dacc0, wss[0], wss[1]);
+        *reinterpret_cast<f4 *>(a_w + buf + aw[hh] + 16 * KS) = bn_relu6(dacc1, wss[0], wss[1]);
     };
 
     f16v acc[4];
-    f4 fa[2], fb[2][4];                                // A fragments [g] (g = 0 of the NEXT step is read behind dw_fin, g = 1 inside the step), B fragments [g][block]
-    auto ldfrag_a = [&](const int g) __attribute__((always_inline)) {
+    f4 fa[2], fb[2][4];                                // A fragments [g] (g = 0 of the NEXT substep is read behind dw_fin, g = 1 inside the substep), B fragments [g][block]
+    auto ldfrag_a = [&](const int u, const int g) __attribute__((always_inline)) {
         if (dbg & 128) return;
-        fa[g] = *reinterpret_cast<const f4 *>(a_w + (g ? fra1 : fra0));
+        const int buf = AH == 2 ? ((u >> 1) & 1) * ABUF : 0, idx = AH == 2 ? 2 * (u & 1) + g : g;
+        fa[g] = *reinterpret_cast<const f4 *>(a_w + buf + fra[idx]);
     };
-    auto ldfrag_b = [&](const int k, const int g) __attribute__((always_inline)) {
+    auto ldfrag_b = [&](const int u, const int g) __attribute__((always_inline)) {
         if (dbg & 128) return;
-        fb[g][0] = *reinterpret_cast<const f4 *>(bl01 + k * KS + g * 8);
-        fb[g][1] = *reinterpret_cast<const f4 *>(bl01 + 32 * LDB + k * KS + g * 8);
-        fb[g][2] = *reinterpret_cast<const f4 *>(bl23 + k * KS + g * 8);
-        fb[g][3] = *reinterpret_cast<const f4 *>(bl23 + 32 * LDB + k * KS + g * 8);
+        fb[g][0] = *reinterpret_cast<const f4 *>(bl01 + u * 16 + g * 8);
+        fb[g][1] = *reinterpret_cast<const f4 *>(bl01 + 32 * LDB + u * 16 + g * 8);
+        fb[g][2] = *reinterpret_cast<const f4 *>(bl23 + u * 16 + g * 8);
+        fb[g][3] = *reinterpret_cast<const f4 *>(bl23 + 32 * LDB + u * 16 + g * 8);
     };
     // first = the tile's first k pair: the accumulators start from the inline constant 0 (no zeroing between tiles)
     auto mfma8 = [&](const int g, const int s0, const bool first) __attribute__((always_inline)) {
@@ -251,11 +301,20 @@ __global__ __launch_bounds__(512) void dwpw3_f32(DwPw3Args a)
             for (int t = 0; t < 4; t++)
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g][s], fb[g][t][s], (first && s == s0) ? zero : acc[t], 0, 0, 0);
     };
-    // Accumulator register r of block t: channel n0 + 4 li + t, tile row i = 8 (r >> 2) + 4 lh + (r & 3) = pixel m0 + 2 (i & 15) + (i >> 4).
-    // BN of rows r, r + 1 of a channel: one v_pk_fma_f32 (adjacent registers); the clamps write each value where its 16-byte store wants it.
-    auto epilogue_mode = [&](unsigned m0, const bool inside) __attribute__((always_inline)) {
+    // Accumulator register r of block t: channel n0 + 4 li + t, tile row 8 (r >> 2) + 4 lh + (r & 3) = pixel (r >> 3) of pair 8 ((r >> 2) & 1) + 4 lh + (r & 3).
+    // The lane's 8 pairs' output offsets come from po_w (two ds_read_b128); BN of rows r, r + 1 of a channel is one v_pk_fma_f32 (adjacent
+    // registers); the clamps write each value where its 16-byte store wants it. A pair past the end carries PO_INVALID: dropped by the range check.
+    auto epilogue = [&](int pslot) __attribute__((always_inline)) {
+        if (dbg & 4) return;
         const f4 sc = *reinterpret_cast<const f4 *>(sc3_s + 4 * li), sh = *reinterpret_cast<const f4 *>(sh3_s + 4 * li);
-        const unsigned lane_off = ((unsigned)(8 * lh) * (unsigned)a.cout + (unsigned)(n0 + 4 * li)) * 4u;
+        const u4 pa = *reinterpret_cast<const u4 *>(po_w + pslot * 16 + 4 * lh), pb4 = *reinterpret_cast<const u4 *>(po_w + pslot * 16 + 8 + 4 * lh);
+        const unsigned lane_col = (unsigned)(n0 + 4 * li) * 4u;
+        unsigned vo[2][4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            vo[0][c] = pa[c] + lane_col;
+            vo[1][c] = pb4[c] + lane_col;
+        }
         const unsigned rowb = (unsigned)a.cout * 4u;
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
@@ -266,123 +325,113 @@ __global__ __launch_bounds__(512) void dwpw3_f32(DwPw3Args a)
 #pragma unroll
             for (int hh = 0; hh < 2; hh++)
                 o[hh] = f4{ relu6(hh ? p[0].y : p[0].x), relu6(hh ? p[1].y : p[1].x), relu6(hh ? p[2].y : p[2].x), relu6(hh ? p[3].y : p[3].x) };
-            // The two stores back to back, then two wait states before any VALU instruction may write their data registers. gfx950, measured here
-            // (tools/dwpw3_debug.py, profiles/r06/a_*): a buffer_store_dwordx4 with an SGPR soffset followed directly by a VALU write of its first data
-            // register stores the NEW value in lanes 12-15 of every 16 — the ">64-bit store data" hazard, which the compiler pads only in the
-            // immediate-soffset form. Pinned with sched_barriers so nothing is scheduled in between.
+            // the two stores back to back, then two wait states before any VALU instruction may write their data registers (see the header)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int hh = 0; hh < 2; hh++) {
                 const int rr = r + hh;
-                const unsigned pix = m0 + 16 * ((rr >> 2) & 1) + 2 * (rr & 3) + (rr >> 3);         // + 8 lh per lane
-                const unsigned soff = pix * rowb;
-                // rows past m (the last tile): the whole offset through the VGPR, so the descriptor's range check drops them
-                if (inside) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, o[hh]), orsrc, lane_off, soff, 0);
-                else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, o[hh]), orsrc, lane_off + soff, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, o[hh]), orsrc, vo[(rr >> 2) & 1][rr & 3], (rr >> 3) ? rowb : 0u, 0);
             }
             asm volatile("s_nop 1" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    auto epilogue = [&](unsigned m0) __attribute__((always_inline)) {
-        if (dbg & 4) return;
-        if (m0 + WT <= mtot) epilogue_mode(m0, true);
-        else epilogue_mode(m0, false);
-    };
 
-    // ---- prologue: step 0 of the first tile computed in full, the window of step 1 in flight
+    // ---- prologue: the first AH half-rounds of the first tile computed in full, the window of the next one in flight
     int it = 0;
-    unsigned m0M = (unsigned)tile_at(0) * WT;
-    set_offsets(m0M);
+    unsigned p0M = (unsigned)tile_at(0) * 16u;
+    set_offsets_tile(p0M, 0);
 #pragma unroll
-    for (int dy = 0; dy < 3; dy++) ldx_row(0, dy);
-    ldw_row(0, 0);
+    for (int u = 0; u < AH; u++) {
 #pragma unroll
-    for (int dy = 0; dy < 3; dy++) {
-        dw_row(0, dy);
-        ldx_row(1, dy);
+        for (int dy = 0; dy < 3; dy++) ldx_row(u, dy);
+        ldw_row(u, 0);
+#pragma unroll
+        for (int dy = 0; dy < 3; dy++) dw_row(u, dy);
+        dw_fin(u);
     }
-    dw_fin();
-    ldfrag_a(0);
+#pragma unroll
+    for (int dy = 0; dy < 3; dy++) ldx_row(AH, dy);
+    ldfrag_a(0, 0);
     ldfrag_b(0, 0);
-    ldw_row(1, 0);
+    ldw_row(AH, 0);
     bool pendE = false;
-    unsigned m0E = 0;
 
-    // ---- main loop: one iteration = one tile of this wave = NK steps, fully unrolled. In step k: the MFMAs of step k (A fragments of parity
-    // k & 1, read at the end of step k - 1), the depthwise part of step k + 1 (of the next tile's step 0 in the last step) cut by filter row
-    // in front of the MFMA groups, and the window loads of step k + 2 row by row behind the FMAs that consumed the row.
+    // ---- main loop: one iteration = one tile of this wave = NS substeps, fully unrolled. In substep u: the MFMAs of k groups 2 u, 2 u + 1; the
+    // depthwise half-round u + AH (of the next tile when past the end) cut by filter row in front of the MFMA groups; the window loads of
+    // half-round u + AH + 1 row by row behind the FMAs that consumed the row.
     for (;;) {
         const bool have_next = it + 1 < ntile;
-        const unsigned m0N = have_next ? (unsigned)tile_at(it + 1) * WT : m0M;
+        const unsigned p0N = have_next ? (unsigned)tile_at(it + 1) * 16u : p0M;
         if (pendE) {                                   // the previous tile's 16 stores, ahead of this tile's first MFMA
-            epilogue(m0E);
+            epilogue((it - 1) & 1);
             pendE = false;
         }
 #pragma unroll
-        for (int k = 0; k < NK; k++) {
-            const int kd = (k + 1) % NK, kl = (k + 2) % NK;
-            if (k == NK - 2 && have_next && !(dbg & 256)) set_offsets(m0N);                // the L cursor enters the next tile (no next tile: stale offsets, unused results)
+        for (int u = 0; u < NS; u++) {
+            const int ud = (u + AH) % NS, ul = (u + AH + 1) % NS;
+            // the load cursor enters the next tile (no next tile: stale offsets, unused results)
+            if (u == NS - AH - 1 && have_next && !(dbg & 256)) set_offsets_tile(p0N, (it + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);
             // group 0
-            ldfrag_a(1);
-            ldfrag_b(k, 1);
-            dw_row(kd, 0);
-            if (!(dbg & 1)) ldx_row(kl, 0);
+            ldfrag_a(u, 1);
+            ldfrag_b(u, 1);
+            dw_row(ud, 0);
+            if (!(dbg & 1)) ldx_row(ul, 0);
             __builtin_amdgcn_sched_barrier(0);
-            mfma8(0, 0, k == 0);
+            mfma8(0, 0, u == 0);
             __builtin_amdgcn_sched_barrier(0);
             // group 1
-            dw_row(kd, 1);
-            if (!(dbg & 1)) ldx_row(kl, 1);
+            dw_row(ud, 1);
+            if (!(dbg & 1)) ldx_row(ul, 1);
             __builtin_amdgcn_sched_barrier(0);
             mfma8(0, 2, false);
             __builtin_amdgcn_sched_barrier(0);
             // group 2
-            ldfrag_b(kd, 0);                           // B fragments g = 0 of the next step (fb[0] has been consumed)
-            dw_row(kd, 2);
-            if (!(dbg & 1)) ldx_row(kl, 2);
+            ldfrag_b((u + 1) % NS, 0);                 // B fragments g = 0 of the next substep (fb[0] has been consumed)
+            dw_row(ud, 2);
+            if (!(dbg & 1)) ldx_row(ul, 2);
             __builtin_amdgcn_sched_barrier(0);
             mfma8(1, 0, false);
             __builtin_amdgcn_sched_barrier(0);
             // group 3
-            dw_fin();
-            ldfrag_a(0);
-            ldw_row(kl, 0);
+            dw_fin(ud);
+            ldfrag_a((u + 1) % NS, 0);
+            ldw_row(ul, 0);
             __builtin_amdgcn_sched_barrier(0);
             mfma8(1, 2, false);
             __builtin_amdgcn_sched_barrier(0);
         }
         pendE = true;
-        m0E = m0M;
         if (!have_next) break;
-        m0M = m0N;
+        p0M = p0N;
         it++;
     }
-    epilogue(m0E);
+    epilogue(it & 1);
 }
 
-template <int S, int CIN>
+template <int S, int CIN, int KS>
 void launch3(const DwPw3Args &a, hipStream_t s, int grid)
 {
 #ifdef MBN_LAB
-    if (a.dbg) { hipLaunchKernelGGL((dwpw3_f32<S, CIN, true>), dim3((unsigned)grid), dim3(512), 0, s, a); return; }
+    if (a.dbg) { hipLaunchKernelGGL((dwpw3_f32<S, CIN, KS, true>), dim3((unsigned)grid), dim3(512), 0, s, a); return; }
 #endif
-    hipLaunchKernelGGL((dwpw3_f32<S, CIN, false>), dim3((unsigned)grid), dim3(512), 0, s, a);
+    hipLaunchKernelGGL((dwpw3_f32<S, CIN, KS, false>), dim3((unsigned)grid), dim3(512), 0, s, a);
 }
 
 }   // namespace
 
 // 1 when the wave-private form takes this block (the caller has passed mbn_f32_dwpw_check): Cin 64 / 128 / 256 (filter slice resident in LDS,
-// k loop unrolled), the full-rate window offsets' range (every input byte offset + a left-pad column below the invalid-column constant; n h + iy0
-// and the row / column quotients in exact float / mul24 range), at least one workgroup per XCD and slice.
+// substeps unrolled), the full-rate window offsets' range (every input byte offset + a left-pad column below the invalid-column constant; n h + iy0
+// in mul24 range; the band / image quotients' numerators below 2^21: exact float-reciprocal division), at least one workgroup per XCD and slice.
 int mbn_f32_dwpw3_eligible(const mbn_context *ctx, int batch, int in_rows, int in_cols, int out_rows, int out_cols, int cin, int cout, int stride,
                            int pad_top, int pad_left)
 {
     if (cin != 64 && cin != 128 && cin != 256) return 0;
     if ((cout % BN3) != 0 || cout > 1024 || (out_cols & 1) || (stride != 1 && stride != 2)) return 0;
     if (4.0 * batch * in_rows * in_cols * cin + 4.0 * (pad_left + 1) * cin > (double)0x70000000u) return 0;
-    if ((double)batch * in_rows >= 8388000.0 || in_cols >= 32768 || out_cols >= 32768 || out_rows >= 32768 || pad_left > 1 || pad_top > 1) return 0;
+    if ((double)batch * in_rows >= 8388000.0 || in_cols >= 32768 || out_cols >= 16384 || out_rows >= 32768 || pad_left > 1 || pad_top > 1) return 0;
+    if ((double)batch * out_rows >= 2000000.0 || (double)batch * out_rows * out_cols >= 2147483000.0) return 0;
     const int nh = cout / BN3;
     if (ctx->num_cus / (8 * nh) < 1) return 0;
     return 1;
@@ -401,27 +450,46 @@ int mbn_launch_f32_dwpw3(mbn_context *ctx, hipStream_t stream, float *out, const
     a.cout = cout; a.pad_top = pad_top; a.pad_left = pad_left;
     a.nh = cout / BN3;
     a.tiles = (int)((a.m + WT - 1) / WT);
-    mbn_udiv_magic((unsigned)out_cols, &a.wo_m, &a.wo_s);
-    mbn_udiv_magic((unsigned)out_rows, &a.ho_m, &a.ho_s);
+    // bands of 4 output rows where the map's height allows (2, then 1 otherwise); lab: exp1 = 1 | 2 | 3 forces R = 1 | 2 | 4 where it divides
+    a.rsh = (out_rows % 4) == 0 ? 2 : (out_rows % 2) == 0 ? 1 : 0;
+#ifdef MBN_LAB
+    if (g_mbn_tune.exp1 >= 1 && g_mbn_tune.exp1 <= 3 && (out_rows % (1 << (g_mbn_tune.exp1 - 1))) == 0) a.rsh = g_mbn_tune.exp1 - 1;
+#endif
+    a.pb = (unsigned)((out_cols / 2) << a.rsh);
+    a.bi = (unsigned)(out_rows >> a.rsh);
+    mbn_udiv_magic(a.pb, &a.pb_m, &a.pb_s);
+    mbn_udiv_magic(a.bi, &a.bi_m, &a.bi_s);
+    a.inv_pb = 1.0f / (float)a.pb;
+    a.inv_bi = 1.0f / (float)a.bi;
     a.in_bytes = (unsigned)(4.0 * batch * in_rows * in_cols * cin);
-    a.inv_wo = 1.0f / (float)out_cols;
-    a.inv_ho = 1.0f / (float)out_rows;
     const int variant = g_mbn_tune.dwpw_variant;
     a.dbg = variant >= 300 ? variant - 300 : 0;
-    // whole slice groups per XCD; no more workgroups than 8-tile rounds exist (small problems)
+    // whole slice groups per XCD; no more workgroups per slice than the XCD has tiles (small problems: the remainder round hands out its tiles
+    // one per CU first, so a few tiles spread over many CUs instead of filling the 8 waves of a few)
     int per_xcd = ctx->num_cus / 8;
     per_xcd -= per_xcd % a.nh;
-    const long rounds = ((a.tiles + 7) / 8 + 7) / 8;                          // 8-tile groups per XCD, rounded up
-    if ((long)per_xcd > rounds * a.nh) per_xcd = (int)(rounds * a.nh);
+    const long tiles_xcd = (a.tiles + 7) / 8;
+    if ((long)per_xcd > tiles_xcd * a.nh) per_xcd = (int)(tiles_xcd * a.nh);
     const int grid = per_xcd * 8;
+    // 32-channel half-rounds (a full 128-byte line per pixel and load) where the A tiles fit beside the filter slice (Cin <= 128).
+    // Lab: exp0 = 16 forces the 16-channel form.
+    [[maybe_unused]] bool ks32 = cin <= 128;
+#ifdef MBN_LAB
+    if (g_mbn_tune.exp0 == 16) ks32 = false;
+    if (!ks32 && cin <= 128) {
+        if (stride == 1) { if (cin == 64) launch3<1, 64, 16>(a, stream, grid); else launch3<1, 128, 16>(a, stream, grid); }
+        else { if (cin == 64) launch3<2, 64, 16>(a, stream, grid); else launch3<2, 128, 16>(a, stream, grid); }
+        return MBN_OK;
+    }
+#endif
     if (stride == 1) {
-        if (cin == 64) launch3<1, 64>(a, stream, grid);
-        else if (cin == 128) launch3<1, 128>(a, stream, grid);
-        else launch3<1, 256>(a, stream, grid);
+        if (cin == 64) launch3<1, 64, 32>(a, stream, grid);
+        else if (cin == 128) launch3<1, 128, 32>(a, stream, grid);
+        else launch3<1, 256, 16>(a, stream, grid);
     } else {
-        if (cin == 64) launch3<2, 64>(a, stream, grid);
-        else if (cin == 128) launch3<2, 128>(a, stream, grid);
-        else launch3<2, 256>(a, stream, grid);
+        if (cin == 64) launch3<2, 64, 32>(a, stream, grid);
+        else if (cin == 128) launch3<2, 128, 32>(a, stream, grid);
+        else launch3<2, 256, 16>(a, stream, grid);
     }
     return MBN_OK;
 }

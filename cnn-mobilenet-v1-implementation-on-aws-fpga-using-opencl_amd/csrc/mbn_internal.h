@@ -170,8 +170,9 @@ int mbn_launch_f32_dwpw2(mbn_context *ctx, hipStream_t stream, float *out, const
                          const float *s2, const float *b2, const float *wp, const float *s3, const float *b3, int batch,
                          int in_rows, int in_cols, int out_rows, int out_cols, int cin, int cout, int stride, int pad_top,
                          int pad_left);
-// wave-private form of the fp32 block (mbn_f32_dwpw3.hip, round 6)
-#define MBN_DWPW3_DEFAULT 0
+// wave-private form of the fp32 block (mbn_f32_dwpw3.hip, round 6): the default for stride-1 blocks with Cin >= 128 (blocks 6-7 and 10-11 of the
+// 1.0x network: -9...-12 % and -4...-6 % against dwpw2 in alternating runs, profiles/r06/f_*; equal on 8-9, 8 % slower on 4-5: those stay on dwpw2)
+#define MBN_DWPW3_DEFAULT(stride, cin) ((stride) == 1 && (cin) >= 128)
 int mbn_f32_dwpw3_eligible(const mbn_context *ctx, int batch, int in_rows, int in_cols, int out_rows, int out_cols, int cin, int cout, int stride,
                            int pad_top, int pad_left);
 int mbn_launch_f32_dwpw3(mbn_context *ctx, hipStream_t stream, float *out, const float *in, const float *wd,

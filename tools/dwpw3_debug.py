@@ -10,6 +10,7 @@ from mbn_amd import import_package  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--block", type=int, default=6)
+ap.add_argument("--tune", action="append", default=[])
 args = ap.parse_args()
 pkg = import_package(); lib = pkg.load(); ctx = pkg.Context(0)
 plan = pkg.plan_build(1.0, 224, 1000, lib=lib)
@@ -28,11 +29,15 @@ for v in (12, 11):
     o = ctx.alloc(n * oh * oh * cout * 4)
     lib.mbn_memset(ctx.h, o.ptr, 0xFF, n * oh * oh * cout * 4)
     lib.mbn_tune_set(b"dwpw_variant", v)
+    for kv in args.tune:
+        lib.mbn_tune_set(kv.split("=")[0].encode(), int(kv.split("=")[1]))
     rc = lib.mbn_dwpw_fused(ctx.h, o.ptr, d[0].ptr, d[1].ptr, d[2].ptr, d[3].ptr, d[4].ptr, d[5].ptr, d[6].ptr, n, h, h, oh, oh, cin, cout, s, ldw.pad_top, ldw.pad_left, None)
     assert rc == 0, rc
     ctx.sync()
     outs.append(o.download((n * oh * oh, cout), np.float32))
 lib.mbn_tune_set(b"dwpw_variant", 0)
+for kv in args.tune:
+    lib.mbn_tune_set(kv.split("=")[0].encode(), 0)
 a, b = outs
 bad = (a.view(np.uint32) != b.view(np.uint32))
 print("M", a.shape[0], "tiles", (a.shape[0] + 31) // 32, "mismatching elements", int(bad.sum()), "of", bad.size, "max abs diff", float(np.nanmax(np.abs(a - b))) if bad.any() else 0.0)
