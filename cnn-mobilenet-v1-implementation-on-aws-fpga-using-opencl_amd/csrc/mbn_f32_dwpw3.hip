@@ -78,8 +78,8 @@ __device__ __forceinline__ f4 bn_relu6(f4 a, f4 s, f4 b)
 }
 
 // S = depthwise stride (1, 2), CIN = input channels (64, 128, 256), KS = channels per depthwise half-round and lane group (16: 4 lanes per
-// pixel pair, all 16 pairs at once; 32: 8 lanes per pair, 8 pairs per half-round). DBG: the lab instantiation with the ablation switches.
-template <int S, int CIN, int KS, bool DBG>
+// pixel pair, all 16 pairs at once; 32: 8 lanes per pair, 8 pairs per half-round). ABL: ablation mask (lab; see DwPw3Args::dbg).
+template <int S, int CIN, int KS, int ABL, int SCHED = 0>
 __global__ __launch_bounds__(512) void dwpw3_f32(DwPw3Args a)
 {
     constexpr int XC = S + 3;                          // input columns feeding 2 adjacent output pixels
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(512) void dwpw3_f32(DwPw3Args a)
     float *const wp_s = lds, *const a_s = wp_s + BN3 * LDB, *const wd_s = a_s + 8 * AH * ABUF, *const sb_s = wd_s + 9 * CIN;
     float *const sc3_s = sb_s + 2 * CIN, *const sh3_s = sc3_s + BN3;
     unsigned *const po_s = reinterpret_cast<unsigned *>(sh3_s + BN3);      // [wave][tile parity][16 pairs]: output byte offset of each pair's first pixel
-    const int dbg = DBG ? a.dbg : 0;
+    const int dbg = ABL < 0 ? a.dbg : ABL;         // ABL >= 0: the ablation mask is a compile-time constant (0 = the shipped kernel); -1: runtime (a.dbg)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -372,35 +372,47 @@ __global__ __launch_bounds__(512) void dwpw3_f32(DwPw3Args a)
             const int ud = (u + AH) % NS, ul = (u + AH + 1) % NS;
             // the load cursor enters the next tile (no next tile: stale offsets, unused results)
             if (u == NS - AH - 1 && have_next && !(dbg & 256)) set_offsets_tile(p0N, (it + 1) & 1);
+            // SCHED (lab A/B, exp2): 0 = the four pinned groups below; 1 = one scheduling region per substep, the compiler's own order; 2 = one region with
+            // the interleave requested through sched_group_barrier: after every MFMA two VALU and one memory / LDS instruction
+#define SB() do { if constexpr (SCHED == 0) __builtin_amdgcn_sched_barrier(0); } while (0)
             __builtin_amdgcn_sched_barrier(0);
             // group 0
             ldfrag_a(u, 1);
             ldfrag_b(u, 1);
             dw_row(ud, 0);
             if (!(dbg & 1)) ldx_row(ul, 0);
-            __builtin_amdgcn_sched_barrier(0);
+            SB();
             mfma8(0, 0, u == 0);
-            __builtin_amdgcn_sched_barrier(0);
+            SB();
             // group 1
             dw_row(ud, 1);
             if (!(dbg & 1)) ldx_row(ul, 1);
-            __builtin_amdgcn_sched_barrier(0);
+            SB();
             mfma8(0, 2, false);
-            __builtin_amdgcn_sched_barrier(0);
+            SB();
             // group 2
             ldfrag_b((u + 1) % NS, 0);                 // B fragments g = 0 of the next substep (fb[0] has been consumed)
             dw_row(ud, 2);
             if (!(dbg & 1)) ldx_row(ul, 2);
-            __builtin_amdgcn_sched_barrier(0);
+            SB();
             mfma8(1, 0, false);
-            __builtin_amdgcn_sched_barrier(0);
+            SB();
             // group 3
             dw_fin(ud);
             ldfrag_a((u + 1) % NS, 0);
             ldw_row(ul, 0);
-            __builtin_amdgcn_sched_barrier(0);
+            SB();
             mfma8(1, 2, false);
+            if constexpr (SCHED == 2) {
+#pragma unroll
+                for (int i = 0; i < 32; i++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);      // two VALU
+                    __builtin_amdgcn_sched_group_barrier(0x320, 1, 0);      // one DS read / DS write / VMEM read
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
+#undef SB
         }
         pendE = true;
         if (!have_next) break;
@@ -414,9 +426,27 @@ template <int S, int CIN, int KS>
 void launch3(const DwPw3Args &a, hipStream_t s, int grid)
 {
 #ifdef MBN_LAB
-    if (a.dbg) { hipLaunchKernelGGL((dwpw3_f32<S, CIN, KS, true>), dim3((unsigned)grid), dim3(512), 0, s, a); return; }
+    // compile-time ablations of the two stride-1 default shapes (no runtime branches in the substep: the timings are those of the real instruction
+    // stream minus the part switched off); any other mask / shape: the runtime-switch build (its ~30 scalar branches per substep cost time of their own)
+    if constexpr (S == 1 && ((CIN == 128 && KS == 32) || (CIN == 256 && KS == 16))) {
+        switch (a.dbg) {
+        case 1: hipLaunchKernelGGL((dwpw3_f32<S, CIN, KS, 1>), dim3((unsigned)grid), dim3(512), 0, s, a); return;
+        case 2: hipLaunchKernelGGL((dwpw3_f32<S, CIN, KS, 2>), dim3((unsigned)grid), dim3(512), 0, s, a); return;
+        case 4: hipLaunchKernelGGL((dwpw3_f32<S, CIN, KS, 4>), dim3((unsigned)grid), dim3(512), 0, s, a); return;
+        case 7: hipLaunchKernelGGL((dwpw3_f32<S, CIN, KS, 7>), dim3((unsigned)grid), dim3(512), 0, s, a); return;
+        case 16: hipLaunchKernelGGL((dwpw3_f32<S, CIN, KS, 16>), dim3((unsigned)grid), dim3(512), 0, s, a); return;
+        case 23: hipLaunchKernelGGL((dwpw3_f32<S, CIN, KS, 23>), dim3((unsigned)grid), dim3(512), 0, s, a); return;
+        case 39: hipLaunchKernelGGL((dwpw3_f32<S, CIN, KS, 39>), dim3((unsigned)grid), dim3(512), 0, s, a); return;
+        case 103: hipLaunchKernelGGL((dwpw3_f32<S, CIN, KS, 103>), dim3((unsigned)grid), dim3(512), 0, s, a); return;
+        case 231: hipLaunchKernelGGL((dwpw3_f32<S, CIN, KS, 231>), dim3((unsigned)grid), dim3(512), 0, s, a); return;
+        case 487: hipLaunchKernelGGL((dwpw3_f32<S, CIN, KS, 487>), dim3((unsigned)grid), dim3(512), 0, s, a); return;
+        case 503: hipLaunchKernelGGL((dwpw3_f32<S, CIN, KS, 503>), dim3((unsigned)grid), dim3(512), 0, s, a); return;
+        default: break;
+        }
+    }
+    if (a.dbg) { hipLaunchKernelGGL((dwpw3_f32<S, CIN, KS, -1>), dim3((unsigned)grid), dim3(512), 0, s, a); return; }
 #endif
-    hipLaunchKernelGGL((dwpw3_f32<S, CIN, KS, false>), dim3((unsigned)grid), dim3(512), 0, s, a);
+    hipLaunchKernelGGL((dwpw3_f32<S, CIN, KS, 0>), dim3((unsigned)grid), dim3(512), 0, s, a);
 }
 
 }   // namespace
@@ -479,6 +509,18 @@ int mbn_launch_f32_dwpw3(mbn_context *ctx, hipStream_t stream, float *out, const
     if (!ks32 && cin <= 128) {
         if (stride == 1) { if (cin == 64) launch3<1, 64, 16>(a, stream, grid); else launch3<1, 128, 16>(a, stream, grid); }
         else { if (cin == 64) launch3<2, 64, 16>(a, stream, grid); else launch3<2, 128, 16>(a, stream, grid); }
+        return MBN_OK;
+    }
+#endif
+#ifdef MBN_LAB
+    if (stride == 1 && (g_mbn_tune.exp2 == 1 || g_mbn_tune.exp2 == 2) && !a.dbg && cin >= 128) {
+        if (cin == 128) {
+            if (g_mbn_tune.exp2 == 1) hipLaunchKernelGGL((dwpw3_f32<1, 128, 32, 0, 1>), dim3((unsigned)grid), dim3(512), 0, stream, a);
+            else hipLaunchKernelGGL((dwpw3_f32<1, 128, 32, 0, 2>), dim3((unsigned)grid), dim3(512), 0, stream, a);
+        } else {
+            if (g_mbn_tune.exp2 == 1) hipLaunchKernelGGL((dwpw3_f32<1, 256, 16, 0, 1>), dim3((unsigned)grid), dim3(512), 0, stream, a);
+            else hipLaunchKernelGGL((dwpw3_f32<1, 256, 16, 0, 2>), dim3((unsigned)grid), dim3(512), 0, stream, a);
+        }
         return MBN_OK;
     }
 #endif
