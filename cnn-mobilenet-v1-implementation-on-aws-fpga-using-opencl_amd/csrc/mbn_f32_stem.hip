@@ -165,7 +165,7 @@ __device__ __forceinline__ void x6_split8(f4 v0, f4 v1, unsigned (&h)[4], unsign
 // X6 = 6 | 9 (fp32 mode only, opt-in: mbn_tune_set("pw_emul", ...)): phase D forms its fp32 products from the exact three-way bf16
 // split of both operands (mbn_f32_pw_x6.hip): the depthwise output is split on its way into LDS (three bf16 planes), the filter once
 // per workgroup, and C1/16 x 6 (9) v_mfma_f32_32x32x16_bf16 per column block replace C1/2 fp32 MFMAs of twice the duration.
-template <int C1, int C3, bool BF, int WPE, bool MC = false, int X6 = 0>
+template <int C1, int C3, bool BF, int WPE, bool MC = false, int X6 = 0, bool PADC = true>
 __global__ __launch_bounds__(256, WPE) void stem_fused_f32(StemArgs a)
 {
     static_assert(!MC || BF || C1 == 32, "conv1 on the MFMA: bf16 mode (16x16x32 bf16, split operands), or fp32 alpha = 1 (16x16x4 fp32)");
@@ -186,7 +186,13 @@ __global__ __launch_bounds__(256, WPE) void stem_fused_f32(StemArgs a)
     constexpr bool BREG = !BF && X6 == 0 && WPE >= 3 && C1 == 32;
     __shared__ __attribute__((aligned(16))) float in_s[PR * PROW + PROWPAD]; //  9.4 KB
     __shared__ __attribute__((aligned(16))) float w1_s[27 * C1];          //  3.4 KB
-    __shared__ __attribute__((aligned(16))) float c1_s[CR * CC * C1];     // 22.5 KB
+    // conv1 output [pixel][C1P]: with conv1 on the fp32 matrix cores (MCF) a lane stores 16 bytes of ONE pixel and the 8 lanes of a ds_write_b128
+    // group are 8 consecutive pixels: at the natural 128-byte pixel stride all on one bank group (8-way: round 5 counted SQ_LDS_BANK_CONFLICT at
+    // 0.61 of SQ_LDS_IDX_ACTIVE for this kernel), and the depthwise phase's ds_read_b128 (lanes of a 16-lane group = 4 pixels 4 columns apart x 4
+    // channel quads) 2-way. At 40 floats per pixel (10 sixteen-byte units) the 16 lanes of every read group fall on 16 different units and the writes
+    // are 2-way (r6; profiles/r06/j_*). The other forms keep the dense rows their lane maps were built for.
+    constexpr int C1P = (MCF && C1 == 32 && PADC) ? 40 : C1;    // PADC = false: lab A/B (conv_variant = 6), the dense rows of round 4-5
+    __shared__ __attribute__((aligned(16))) float c1_s[CR * CC * C1P];    // 22.5 KB (28.1 KB padded)
     __shared__ __attribute__((aligned(16))) float a_s[X6 ? 3 * APL : TH * TW * C1 / (BF ? 2 : 1)];   // 16 KB (fp32, C1 = 32) ... 4 KB (bf16, C1 = 16); X6: three bf16 planes, 24 KB
     __shared__ __attribute__((aligned(16))) float b_s[BREG ? 4 : X6 ? 3 * BPL : C3 * C1 / (BF ? 2 : 1)];        //  8 KB ... 1 KB; X6: 12 KB; BREG: none
     __shared__ __attribute__((aligned(16))) float sb_s[4 * C1];           // s1 | b1 | s2 | b2
@@ -359,7 +365,7 @@ __global__ __launch_bounds__(256, WPE) void stem_fused_f32(StemArgs a)
 #pragma unroll
                     for (int t = 0; t < 7; t++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(mcf_w[h][t], xv[t], acc, 0, 0, 0);
                     const f4 v = inside ? bn_relu6(acc, mcf_s1[h], mcf_b1[h]) : f4{ 0.f, 0.f, 0.f, 0.f };   // outside: the depthwise zero padding
-                    if (q < CR * CC) *reinterpret_cast<f4 *>(c1_s + q * C1 + 16 * h + 4 * kg) = v;
+                    if (q < CR * CC) *reinterpret_cast<f4 *>(c1_s + q * C1P + 16 * h + 4 * kg) = v;
                 }
             }
         } else
@@ -455,7 +461,7 @@ __global__ __launch_bounds__(256, WPE) void stem_fused_f32(StemArgs a)
             for (int dy = 0; dy < 3; dy++) {
                 f4 v[PC + 2];
 #pragma unroll
-                for (int j = 0; j < PC + 2; j++) v[j] = *reinterpret_cast<const f4 *>(c1_s + ((cy + dy) * CC + cx + j) * C1 + c4 * 4);
+                for (int j = 0; j < PC + 2; j++) v[j] = *reinterpret_cast<const f4 *>(c1_s + ((cy + dy) * CC + cx + j) * C1P + c4 * 4);
 #pragma unroll
                 for (int dx = 0; dx < 3; dx++) {
                     f4 wt;
@@ -637,6 +643,7 @@ int mbn_launch_f32_stem(mbn_context *ctx, hipStream_t stream, float *out, const 
         }
 #endif
 #ifdef MBN_LAB
+        else if (g_mbn_tune.conv_variant == 6) hipLaunchKernelGGL((stem_fused_f32<32, 64, false, 2, true, 0, false>), g, b, 0, stream, a);   // r6 A/B: conv1 output rows unpadded (rounds 4-5)
         else if (g_mbn_tune.conv_variant == 5) hipLaunchKernelGGL((stem_fused_f32<32, 64, false, 2>), g, b, 0, stream, a);   // r4 A/B: conv1 on the VALU (round 3's form; timing only: its bits are the fmaf chain's, not conv1_mfma_f32's)
 #endif
         // round 4: conv1 on v_mfma_f32_16x16x4_f32 (profiles/r04/f_stem_conv1_mfma.txt: 0.291-0.297 -> 0.277-0.279 ms at batch 256)
