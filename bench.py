@@ -130,16 +130,40 @@ def stage_table(plan, pkg, launches, layer_ms, batch, act_bytes, mfma_peak):
     return stages, per_layer, stage_of
 
 
-def sample_power(step, sync, seconds=1.5):
+def smi_card_of(bus_id):
+    """rocm-smi's card name ("card3") of the GPU with this PCI bus id ("0000:05:00.0", as mbn_device_pci_bus_id prints it), from `rocm-smi --showbus --json`.
+    None when no card matches (on a multi-GPU box card0 need not be the GPU the context holds)."""
+    import subprocess
+    try:
+        r = subprocess.run(["rocm-smi", "--showbus", "--json"], capture_output=True, text=True, timeout=10)
+        cards = json.loads(r.stdout)
+    except Exception:
+        return None
+    want = bus_id.strip().lower()
+    for name in sorted(cards):
+        v = cards[name]
+        if isinstance(v, dict) and any(isinstance(x, str) and x.strip().lower() == want for x in v.values()):
+            return name
+    return None
+
+
+def sample_power(step, sync, seconds=1.5, bus_id=None):
     """Package power and core clock while `step` runs back to back for `seconds` (AFTER the timed region, never inside it): `rocm-smi --showpower
     --showclocks --json` sampled every ~40 ms from a thread. Round 5 found the step at the package power limit (1350-1390 W of 1400 W:
-    profiles/r05/l_power_probe_net.txt), which is what holds the clock under the fp32 MFMA stream. Returns None when rocm-smi is not usable."""
+    profiles/r05/l_power_probe_net.txt), which is what holds the clock under the fp32 MFMA stream. bus_id (round 6): the PCI bus id of the GPU the
+    context holds — the samples are read from THAT card (None when rocm-smi lists no such card); without it, the first card. Returns None when
+    rocm-smi is not usable."""
     import re
     import shutil
     import subprocess
     import threading
     if not shutil.which("rocm-smi"):
         return None
+    card = None
+    if bus_id:
+        card = smi_card_of(bus_id)
+        if card is None:
+            return None
     samples, stop = [], threading.Event()
 
     def sampler():
@@ -147,7 +171,7 @@ def sample_power(step, sync, seconds=1.5):
             try:
                 r = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=5)
                 c = json.loads(r.stdout)
-                c = c[sorted(c)[0]]
+                c = c[card if card else sorted(c)[0]]
                 m = re.search(r"(\d+)", c.get("sclk clock speed:", ""))
                 samples.append((time.time(), float(c.get("Current Socket Graphics Package Power (W)", "nan")), float(m.group(1)) if m else float("nan")))
             except Exception:
@@ -158,7 +182,8 @@ def sample_power(step, sync, seconds=1.5):
     try:
         r = subprocess.run(["rocm-smi", "--showmaxpower", "--json"], capture_output=True, text=True, timeout=10)
         c = json.loads(r.stdout)
-        c = c[sorted(c)[0]]
+        cap_card = card if card else sorted(c)[0]
+        c = c[cap_card]
         cap = float(next(v for k, v in c.items() if "Max" in k and "Power" in k))
     except Exception:
         pass
@@ -178,6 +203,7 @@ def sample_power(step, sync, seconds=1.5):
     if len(mine) < 3:
         return None
     return {"package_w": mine[len(mine) // 2][0], "cap_w": cap, "sclk_mhz": sorted(c for _, c in mine)[len(mine) // 2], "samples": len(mine),
+            "card": card if card else "first card listed", "pci_bus_id": bus_id,
             "ms_per_step_while_sampling": round(1000.0 * (t1 - t0) / n, 4),
             "how": "median of rocm-smi samples while the step ran back to back for %.1f s after the timed region" % seconds}
 
@@ -547,7 +573,11 @@ def run_one(args, env):
 
     power = None
     if world == 1 and not args.no_power and not args.graph:
-        power = sample_power(lambda: net.forward(d_in.ptr, d_out.ptr, args.batch), ctx.sync, 1.0 if args.batch == 1 else 1.5)
+        try:
+            my_bus = ctx.pci_bus_id()
+        except Exception:
+            my_bus = None
+        power = sample_power(lambda: net.forward(d_in.ptr, d_out.ptr, args.batch), ctx.sync, 1.0 if args.batch == 1 else 1.5, my_bus)
 
     # ---- the opt-in split form of the pointwise GEMM beside the default line (N = 1, fp32): same net, same buffers, same
     # stream configuration, 3 warm-up + 10 timed steps without per-kernel events. Never part of `value`.

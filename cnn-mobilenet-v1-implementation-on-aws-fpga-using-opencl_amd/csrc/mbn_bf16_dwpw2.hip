@@ -28,6 +28,7 @@ typedef mbn_f16v f16v;
 
 constexpr int BKF = 32;                        // LDS rows are 128 bytes = 32 words = 64 bf16
 constexpr int BM8 = 128;                       // rows of the 8-wave tile (2 waves per SIMD, 256 VGPRs each); the 4-wave form (two workgroups per CU): 64
+constexpr int BM_H32 = 256;                    // rows of the Cin = 32 tile (H32: four lanes per pixel pair): shared by the kernel and its launcher
 constexpr int CMAX4 = 256, NOUT4 = 256;        // LDS-resident constants of the 4-wave form (61 KB per workgroup)
 constexpr int NOUT_G = 1024;                   // widest pointwise output whose scale/shift the LDS copy holds
 constexpr int CMAX_G = 1024;                   // largest Cin (depthwise constants resident in LDS: 44 KB)
@@ -114,6 +115,7 @@ __global__ __launch_bounds__(64 * NW) void dwpw2_bf16(DwPw2Args a)
 {
     static_assert(!H32 || (BN == 128 && NW == 8 && !M16 && !DBG), "H32: the shipped 8-wave 128-column form");
     constexpr int NT = 64 * NW, BM = (H32 ? 32 : 16) * NW;
+    static_assert(!H32 || BM == BM_H32, "the launcher sizes the H32 grid by BM_H32");
     constexpr int CMAX = NW == 4 ? CMAX4 : CMAX_G, NOUT = NW == 4 ? NOUT4 : NOUT_G;
     const int dbg = DBG ? a.dbg : 0;
     constexpr int WN = 64, WM = (BN == 256 || H32) ? 64 : 32;   // wave tile: 8 waves as 2 x 4 (BN 256), 4 x 2 (BN 128), 4 x 2 of 64 x 64 (H32: 256 rows)
@@ -453,8 +455,12 @@ void launch2(DwPw2Args &a, hipStream_t s, int num_cus)
 {
     constexpr int BM = BM8, NT = 512;
     if constexpr (BN == 128) {
-        if (a.cin == 32 && a.fast_off && g_mbn_tune.exp0 != 53) {                  // H32 (lab exp0 = 53: the padded 128-row form instead)
-            a.mt = (int)((a.m + 255) / 256);
+        bool h32 = a.cin == 32 && a.fast_off;                                      // H32: Cin = 32 on the 256-row tile (BM_H32 rows: the kernel's BM)
+#ifdef MBN_LAB
+        if (g_mbn_tune.exp0 == 53) h32 = false;                                    // lab A/B: the padded 128-row form instead
+#endif
+        if (h32) {
+            a.mt = (int)((a.m + BM_H32 - 1) / BM_H32);
             a.nt = (a.cout + BN - 1) / BN;
             long g32 = num_cus;
             if (g32 > (long)a.mt * a.nt) g32 = (long)a.mt * a.nt;
@@ -509,9 +515,17 @@ int mbn_launch_bf16_dwpw2(mbn_context *ctx, hipStream_t stream, void *out, const
     a.dbg = variant >= 100 ? variant - 100 : 0;
     a.inv_wo = 1.0f / (float)out_cols;
     a.inv_ho = 1.0f / (float)out_rows;
+    a.use4 = 0;
+    // the full-rate offsets' range: every input byte offset PLUS a left-pad column stays below the invalid-column constant 0x70000000
+    // (a left-pad tap of image 0 / row 0 has base = -pad_left * cs: its sum with the constant must not wrap into the descriptor's range), the
+    // row / image quotients stay in exact float range, (n h + iy0) in mul24 range
+    const double cs_b = 2.0 * cin;
+    a.fast_off = (2.0 * batch * in_rows * in_cols * cin + (pad_left + 1) * cs_b <= (double)0x70000000u && (double)batch * in_rows < 8388000.0 &&
+                  in_cols < 32768 && out_cols < 32768 && out_rows < 32768 && pad_left <= 1) ? 1 : 0;
+#ifdef MBN_LAB
     a.use4 = g_mbn_tune.exp2 == 44 ? 1 : 0;
-    a.fast_off = (2.0 * batch * in_rows * in_cols * cin < (double)0x70000000u && (double)batch * in_rows < 8388000.0 && in_cols < 32768 &&
-                  out_cols < 32768 && g_mbn_tune.exp0 != 51) ? 1 : 0;
+    if (g_mbn_tune.exp0 == 51) a.fast_off = 0;                                     // lab A/B: the general offsets
+#endif
     // 256-column tiles only when they alone fill the chip; pw_tile=1: force the 128-column tile (A/B hook)
     const bool wide = (cout % 256) == 0 && g_mbn_tune.pw_tile != 1 && ((a.m + BM8 - 1) / BM8) * (cout / 256) >= ctx->num_cus;
     if (stride == 1) {

@@ -728,8 +728,14 @@ int mbn_launch_f32_dwpw2(mbn_context *ctx, hipStream_t stream, float *out, const
     a.inv_wo = 1.0f / (float)out_cols;
     a.inv_ho = 1.0f / (float)out_rows;
     // the full-rate offsets need every input byte offset below the invalid-column constant, and (n h + iy0) in mul24 range
-    a.fast_off = (4.0 * batch * in_rows * in_cols * cin < (double)0x70000000u && (double)batch * in_rows < 8388000.0 && in_cols < 32768 &&
-                  out_cols < 32768 && g_mbn_tune.exp0 != 51) ? 1 : 0;
+    //  ... PLUS a left-pad column: a left-pad tap of image 0 / row 0 has base = -pad_left * cs, and its sum with the invalid-column
+    // constant must stay beyond num_records without wrapping; out_rows bounded so the row quotient stays in exact float range
+    const double cs_b = 4.0 * cin;
+    a.fast_off = (4.0 * batch * in_rows * in_cols * cin + (pad_left + 1) * cs_b <= (double)0x70000000u && (double)batch * in_rows < 8388000.0 &&
+                  in_cols < 32768 && out_cols < 32768 && out_rows < 32768 && pad_left <= 1) ? 1 : 0;
+#ifdef MBN_LAB
+    if (g_mbn_tune.exp0 == 51) a.fast_off = 0;                                     // lab A/B: the general offsets
+#endif
     a.stagger = g_mbn_tune.exp2;                                             // lab: start stagger of the workgroups in kcycles per phase
     const bool pre = variant != 3;                                       // 3: taps read from LDS inside the step (A/B hook)
     // 256-column tiles only when they alone fill the chip (see mbn_dwpw_fused); pw_tile=1: force the 128-column tile (A/B hook)

@@ -175,7 +175,6 @@ __global__ __launch_bounds__(512) void dwpw3_f32(DwPw3Args a)
     const float *const bl01 = wp_s + li * LDB + lh * 4;             // B fragments of blocks 0, 1: + t*32*LDB + s*16 + g*8 (immediates)
     const float *const bl23 = bl01 + 64 * LDB;                      // ... of blocks 2, 3 (second base: the immediate is 16 bits)
     const float *const wk = wd_s + cl * 4;                          // taps of this lane's channels: + chunk*KS + tap*CIN
-    const float *const sk = sb_s + cl * 4;
 
     // SEP (stride 2 with two half-rounds: 2 x 15 offsets do not fit beside the 15-register-wider window): the offsets stay in their separable
     // form rowv + colv (16 registers) and every load adds its pair (one full-rate v_add_u32 per load)
@@ -224,7 +223,11 @@ __global__ __launch_bounds__(512) void dwpw3_f32(DwPw3Args a)
         }
         const unsigned opix = (unsigned)__mul24((int)(n * (unsigned)a.ho + y), a.wo) + x;
         const unsigned po = mok ? opix * ((unsigned)a.cout * 4u) : PO_INVALID;
-        if (cl == 0) po_w[pslot * 16 + (int)qq] = po;
+        // the slot address from a freshly read lane id (two full-rate instructions per tile) instead of a register that lives through the whole
+        // loop: at 256 VGPRs (Cin 256) that register was spilled and its reload's vmcnt(0) drained the window loads once per tile
+        unsigned lid;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lid));
+        if ((lid % LPP) == 0) po_w[pslot * 16 + 8 * hh * (AH - 1) + (int)(lid / LPP)] = po;
     };
     auto set_offsets_tile = [&](unsigned p0, int pslot) __attribute__((always_inline)) {
 #pragma unroll
@@ -250,8 +253,8 @@ __global__ __launch_bounds__(512) void dwpw3_f32(DwPw3Args a)
     auto ldw_ss = [&](const int u) __attribute__((always_inline)) {
         if (dbg & 32) return;
         const int cf = AH == 2 ? (u >> 1) * 32 : u * 16;
-        wss[0] = *reinterpret_cast<const f4 *>(sk + cf);
-        wss[1] = *reinterpret_cast<const f4 *>(sk + CIN + cf);
+        wss[0] = *reinterpret_cast<const f4 *>(wk + 9 * CIN + cf);          // scale | shift follow the nine tap planes (sb_s = wd_s + 9 CIN): one base register
+        wss[1] = *reinterpret_cast<const f4 *>(wk + 10 * CIN + cf);
     };
     f4 dacc0 = f4{ 0.f, 0.f, 0.f, 0.f }, dacc1 = dacc0;
     // filter row dy of half-round u into the two running sums (dy = 0 starts them), then the taps the next piece needs
@@ -367,6 +370,7 @@ __global__ __launch_bounds__(512) void dwpw3_f32(DwPw3Args a)
             epilogue((it - 1) & 1);
             pendE = false;
         }
+
 #pragma unroll
         for (int u = 0; u < NS; u++) {
             const int ud = (u + AH) % NS, ul = (u + AH + 1) % NS;
@@ -458,6 +462,9 @@ int mbn_f32_dwpw3_eligible(const mbn_context *ctx, int batch, int in_rows, int i
                            int pad_top, int pad_left)
 {
     if (cin != 64 && cin != 128 && cin != 256) return 0;
+#ifndef MBN_LAB
+    if (!MBN_DWPW3_DEFAULT(stride, cin)) return 0;      // the shipped library holds only the instantiations its dispatch rule reaches (stride 1, Cin 128 / 256)
+#endif
     if ((cout % BN3) != 0 || cout > 1024 || (out_cols & 1) || (stride != 1 && stride != 2)) return 0;
     if (4.0 * batch * in_rows * in_cols * cin + 4.0 * (pad_left + 1) * cin > (double)0x70000000u) return 0;
     if ((double)batch * in_rows >= 8388000.0 || in_cols >= 32768 || out_cols >= 16384 || out_rows >= 32768 || pad_left > 1 || pad_top > 1) return 0;
@@ -524,6 +531,7 @@ int mbn_launch_f32_dwpw3(mbn_context *ctx, hipStream_t stream, float *out, const
         return MBN_OK;
     }
 #endif
+#ifdef MBN_LAB
     if (stride == 1) {
         if (cin == 64) launch3<1, 64, 32>(a, stream, grid);
         else if (cin == 128) launch3<1, 128, 32>(a, stream, grid);
@@ -533,5 +541,9 @@ int mbn_launch_f32_dwpw3(mbn_context *ctx, hipStream_t stream, float *out, const
         else if (cin == 128) launch3<2, 128, 32>(a, stream, grid);
         else launch3<2, 256, 16>(a, stream, grid);
     }
+#else
+    if (cin == 128) launch3<1, 128, 32>(a, stream, grid);
+    else launch3<1, 256, 16>(a, stream, grid);
+#endif
     return MBN_OK;
 }

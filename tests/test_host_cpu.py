@@ -649,11 +649,14 @@ def test_bench_power_sampler_parses_rocm_smi_json(monkeypatch):
 
     def fake_run(cmd, **kw):
         calls["n"] += 1
-        if "--showmaxpower" in cmd:
-            out = {"card0": {"Max Graphics Package Power (W)": "1400.0"}}
+        if "--showbus" in cmd:
+            out = {"card0": {"PCI Bus": "0000:05:00.0"}, "card1": {"PCI Bus": "0000:26:00.0"}}
+        elif "--showmaxpower" in cmd:
+            out = {"card0": {"Max Graphics Package Power (W)": "1400.0"}, "card1": {"Max Graphics Package Power (W)": "1000.0"}}
         else:
             out = {"card0": {"fclk clock speed:": "(1250Mhz)", "mclk clock speed:": "(2000Mhz)", "sclk clock speed:": "(%dMhz)" % (2280 + calls["n"] % 3), "sclk clock level:": "1",
-                             "Current Socket Graphics Package Power (W)": "%d.0" % (1340 + calls["n"] % 5)}}
+                             "Current Socket Graphics Package Power (W)": "%d.0" % (1340 + calls["n"] % 5)},
+                   "card1": {"sclk clock speed:": "(132Mhz)", "Current Socket Graphics Package Power (W)": "140.0"}}     # an idle neighbour
         return types.SimpleNamespace(stdout=json.dumps(out), returncode=0)
     monkeypatch.setattr(shutil, "which", lambda name: "/opt/rocm/bin/rocm-smi")
     monkeypatch.setattr(subprocess, "run", fake_run)
@@ -661,5 +664,11 @@ def test_bench_power_sampler_parses_rocm_smi_json(monkeypatch):
     p = bench.sample_power(lambda: steps.__setitem__("n", steps["n"] + 1), lambda: None, seconds=0.9)
     assert p is not None and p["cap_w"] == 1400.0 and 1340 <= p["package_w"] <= 1344 and 2280 <= p["sclk_mhz"] <= 2282 and p["samples"] >= 3
     assert steps["n"] > 0 and p["ms_per_step_while_sampling"] > 0
+    # round 6: the card is chosen by the PCI bus id of the GPU the context holds, not "the first one"; an id rocm-smi does not list gives None
+    p1 = bench.sample_power(lambda: None, lambda: None, seconds=0.6, bus_id="0000:26:00.0")
+    assert p1 is not None and p1["card"] == "card1" and p1["package_w"] == 140.0 and p1["cap_w"] == 1000.0 and p1["sclk_mhz"] == 132.0
+    p0 = bench.sample_power(lambda: None, lambda: None, seconds=0.6, bus_id="0000:05:00.0")
+    assert p0 is not None and p0["card"] == "card0" and p0["cap_w"] == 1400.0
+    assert bench.sample_power(lambda: None, lambda: None, seconds=0.1, bus_id="0000:99:00.0") is None
     monkeypatch.setattr(shutil, "which", lambda name: None)
     assert bench.sample_power(lambda: None, lambda: None, seconds=0.1) is None

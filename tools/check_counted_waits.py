@@ -99,6 +99,34 @@ def check(path, stem="pw_gemm", nst_of=None):
     return seen, sorted(set(bad))
 
 
+def check_spills(path, stem, in_loop_only=False):
+    """Shipped block kernels must not touch scratch where it costs: a scratch reload is an `s_waitcnt vmcnt(0)` that drains the window loads in flight
+    (profiles/r05/h_*: 0.245 -> 0.50 ms with spills in the step). dwpw2 forms: no scratch instruction at all. dwpw3 (in_loop_only): none
+    between a loop header and its backward branch (its 256-VGPR form reloads one register once, behind the loop, in front of the last tile's stores)."""
+    text = open(path).read()
+    bad, seen = [], 0
+    for name, lines in kernels(text, stem):
+        seen += 1
+        idx = [k for k, l in enumerate(lines) if re.match(r"\s+scratch_", l)]
+        if not idx:
+            continue
+        if not in_loop_only:
+            bad.append("%s: %d scratch instructions (spills) in a shipped block kernel" % (name, len(idx)))
+            continue
+        label = {m.group(1): k for k, l in enumerate(lines) if (m := re.match(r"^(\.LBB\w+):", l))}
+        loops = []
+        for k, l in enumerate(lines):
+            m = re.search(r"\bs_c?branch\w*\s+(\.LBB\w+)", l)
+            if m and m.group(1) in label and label[m.group(1)] < k:
+                loops.append((label[m.group(1)], k))
+        inside = [k for k in idx if any(a <= k <= b for a, b in loops)]
+        if inside:
+            bad.append("%s: %d scratch instructions inside a loop" % (name, len(inside)))
+    if seen == 0:
+        bad.append("no %s kernel found in %s" % (stem, path))
+    return seen, bad
+
+
 def dwpw2_nst(name):
     """dwpw2_f32<S, BN, ...>: NST = 16 * MI * (NI / 2) buffer_store_dwordx2 per lane: 16 (BN = 128: MI 1, NI 2) or 32 (BN = 256: MI 2, NI 2)"""
     return 32 if "ILi1ELi256E" in name or "ILi2ELi256E" in name else 16
@@ -112,6 +140,8 @@ if __name__ == "__main__":
         env = dict(os.environ, ISA_OUT=tmp)
         subprocess.check_call(["bash", os.path.join(ROOT, "tools", "isa.sh"), "mbn_f32_pw"], stdout=subprocess.DEVNULL, env=env)
         subprocess.check_call(["bash", os.path.join(ROOT, "tools", "isa.sh"), "mbn_f32_dwpw2"], stdout=subprocess.DEVNULL, env=env)
+        subprocess.check_call(["bash", os.path.join(ROOT, "tools", "isa.sh"), "mbn_bf16_dwpw2"], stdout=subprocess.DEVNULL, env=env)
+        subprocess.check_call(["bash", os.path.join(ROOT, "tools", "isa.sh"), "mbn_f32_dwpw3"], stdout=subprocess.DEVNULL, env=env)
     seen, bad = check(path)
     if len(sys.argv) <= 1:
         s2, b2 = check(os.path.join(tmp, "mbn_f32_dwpw2.s"), "dwpw2_f32", dwpw2_nst)
@@ -119,6 +149,14 @@ if __name__ == "__main__":
         if s2 == 0:
             b2.append("no dwpw2_f32 kernel with a counted wait found")
         bad += b2
+        # round 6: the bf16 block kernel's counted waits (FO / H32 instantiations included: the shipped build's set), and no spills in any shipped block kernel
+        s3, b3 = check(os.path.join(tmp, "mbn_bf16_dwpw2.s"), "dwpw2_bf16")
+        print("%d bf16 fused block kernels with counted waits checked" % s3)
+        bad += b3
+        for f, st, loop_only in (("mbn_f32_dwpw2.s", "dwpw2_f32", False), ("mbn_bf16_dwpw2.s", "dwpw2_bf16", False), ("mbn_f32_dwpw3.s", "dwpw3_f32", True)):
+            s4, b4 = check_spills(os.path.join(tmp, f), st, loop_only)
+            print("%d %s kernels checked for scratch use" % (s4, st))
+            bad += b4
     print("%d kernels with a counted wait checked" % seen)
     for b in bad:
         print("FAIL:", b)

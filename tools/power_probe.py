@@ -14,6 +14,11 @@ ap.add_argument("--block", type=int, default=6)
 ap.add_argument("--seconds", type=float, default=3.0)
 args = ap.parse_args()
 pkg = import_package(); lib = pkg.load(); ctx = pkg.Context(0)
+from bench import smi_card_of  # noqa: E402
+try:
+    SMI_CARD = smi_card_of(ctx.pci_bus_id())      # the card the context holds, by PCI bus id
+except Exception:
+    SMI_CARD = None
 plan = pkg.plan_build(1.0, 224, 1000, lib=lib)
 ldw, lpw = plan.layer[args.block - 1], plan.layer[args.block]
 n, h, oh, cin, cout, s = 256, ldw.in_rows, ldw.out_rows, ldw.in_ch, lpw.out_ch, ldw.stride
@@ -28,7 +33,7 @@ def sampler():
         try:
             r = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=5)
             j = json.loads(r.stdout)
-            c = j[sorted(j)[0]]
+            c = j[SMI_CARD or sorted(j)[0]]
             samples.append((time.time(), c))
         except Exception as e:
             samples.append((time.time(), {"error": str(e)}))

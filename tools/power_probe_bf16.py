@@ -8,12 +8,17 @@ os.environ.setdefault("MBN_LAB", "1")
 sys.path.insert(0, ROOT)
 from mbn_amd import import_package
 pkg = import_package(); lib = pkg.load(); ctx = pkg.Context(0)
+from bench import smi_card_of  # noqa: E402
+try:
+    SMI_CARD = smi_card_of(ctx.pci_bus_id())      # the card the context holds, by PCI bus id
+except Exception:
+    SMI_CARD = None
 samples, stop = [], threading.Event()
 def sampler():
     while not stop.is_set():
         try:
             r = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=5)
-            c = json.loads(r.stdout); c = c[sorted(c)[0]]
+            c = json.loads(r.stdout); c = c[SMI_CARD or sorted(c)[0]]
             m = re.search(r"(\d+)", c.get("sclk clock speed:", ""))
             samples.append((time.time(), float(c.get("Current Socket Graphics Package Power (W)", "nan")), float(m.group(1)) if m else float("nan")))
         except Exception:
