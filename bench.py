@@ -609,7 +609,27 @@ def run_one(args, env):
     ranks_info = None
     if world > 1 or mdist._force_pg():
         import torch.distributed as tdist
-        mine = [rank, local_rank, ctx.pci_bus_id(), args.batch, round(elapsed_rank, 6)]
+        # round 6: what each card held while ALL ranks ran — the >= 7x target at 8 GPUs is set by the slowest card of a chassis in
+        # which every card sits at its power cap. After the timed region and behind a barrier every rank runs its step back to back for ~1 s, sampling
+        # ITS card (chosen by PCI bus id) with rocm-smi and the core clock held inside the GEMM launches (mbn_pw_clock_read); None where unavailable.
+        my_bus = ctx.pci_bus_id()
+        rank_w = rank_sclk = rank_ghz = None
+        if not args.no_power and not args.graph:
+            try:
+                tdist.barrier()
+                clock_on = (not bf16) and lib.mbn_tune_set(b"pw_clock", 1) == 0
+                if clock_on:
+                    ctx.pw_clock(reset=True)
+                pw = sample_power(lambda: net.forward(d_in.ptr, d_out.ptr, args.batch), ctx.sync, 1.0, my_bus)
+                if clock_on:
+                    g, nl = ctx.pw_clock(reset=True)
+                    lib.mbn_tune_set(b"pw_clock", 0)
+                    rank_ghz = round(g, 3) if nl > 0 else None
+                if pw:
+                    rank_w, rank_sclk = pw["package_w"], pw["sclk_mhz"]
+            except Exception:
+                pass
+        mine = [rank, local_rank, my_bus, args.batch, round(elapsed_rank, 6), rank_w, rank_sclk, rank_ghz]
         ranks_info = [None] * tdist.get_world_size()
         tdist.all_gather_object(ranks_info, mine)
 
@@ -699,7 +719,7 @@ def run_one(args, env):
         if ranks_info is not None:
             import torch.distributed as tdist
             out["ranks"] = ranks_info
-            out["ranks_cols"] = "rank,device_ordinal,pci_bus_id,images_per_step,seconds_for_the_K_steps"
+            out["ranks_cols"] = "rank,device_ordinal,pci_bus_id,images_per_step,seconds_for_the_K_steps,package_w,sclk_mhz,held_clock_ghz (all ranks loaded, after the timed region)"
             out["collective_world_size"] = tdist.get_world_size()
             out["backend"] = tdist.get_backend()
             buses = [r[2] for r in ranks_info]

@@ -620,7 +620,7 @@ def test_bench_line_is_compact_parseable_and_keeps_the_contract(tmp_path):
     assert out["configs_alt"]["bf16_1.0x224_b512"] == [89059.1, 0.8157, True, 1389.0] and out["roofline"]["package_power_w"] == 1349.0
     assert "layers" not in out and "unfused_stages" not in out and "config" in out and "streams_note" not in out["config"]
     # N = 8: the per-rank evidence rides along and the line still fits
-    rec8 = dict(rec, n_gpus=8, ranks=[[r, r, "0000:%02x:00.0" % (5 + r), 256, 0.0574123] for r in range(8)], ranks_cols="c" * 70,
+    rec8 = dict(rec, n_gpus=8, ranks=[[r, r, "0000:%02x:00.0" % (5 + r), 256, 0.0574123, 1387.0, 2290.0, 2.281] for r in range(8)], ranks_cols="c" * 150,
                 collective_world_size=8, backend="nccl")
     line8 = bench.compact_line(rec8, "gpurun_out/bench_full.json")
     out8 = json.loads(line8)

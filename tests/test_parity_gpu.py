@@ -1485,7 +1485,8 @@ def test_net_full_size_fused_equals_unfused(pkg, ctx, tmp_path, n):
 @pytest.mark.parametrize("shape", [(2, 112, 64, 128, 2), (2, 56, 128, 128, 1), (2, 56, 128, 256, 2), (2, 28, 256, 256, 1),
                                    (1, 28, 256, 512, 2), (3, 14, 64, 128, 1), (1, 6, 192, 384, 1), (2, 14, 512, 512, 1),
                                    (2, 40, 64, 64, 1), (3, 20, 64, 192, 2), (1, 14, 128, 320, 1), (5, 40, 64, 64, 1),    # round 5: Cout = 64 (mod 128) on a padded tile
-                                   (2, 80, 32, 64, 2), (3, 24, 32, 128, 1), (1, 10, 32, 64, 1)])                         # ... and Cin = 32: half a K chunk
+                                   (2, 80, 32, 64, 2), (3, 24, 32, 128, 1), (1, 10, 32, 64, 1),                          # ... and Cin = 32: half a K chunk
+                                   (105, 28, 32, 64, 1)])              # r6: Cin = 32 on the 256-row tile, stride 1, 322 tiles > one grid pass (the persistent-tile cursors)
 def test_bf16_dwpw_fused(pkg, orc, ctx, shape):
     """mbn_dwpw_fused_bf16 vs the oracle's bf16 emulation of the pair (depthwise output rounded to bf16, bf16 pointwise
     filter, output rounded) and vs the two separate bf16 launches; bf16 tolerance (the pointwise summation order differs)."""
@@ -2589,6 +2590,9 @@ def test_bench_self_launches_its_ranks(pkg):
     # the N > 1 line proves its ranks: one entry per rank, the group's own world size, the backend
     assert len(out["ranks"]) == 2 and [x[0] for x in out["ranks"]] == [0, 1] and out["collective_world_size"] == 2 and out["backend"] == "gloo"
     assert out["ranks"][0][2] == out["ranks"][1][2] and all(x[3] == 16 and x[4] > 0 for x in out["ranks"])      # --device-override: the same card, said so
+    # round 6: each rank also reports what ITS card held while all ranks ran (package W, sclk MHz, clock inside the GEMM launches); None only where the box has no rocm-smi
+    assert all(len(x) == 8 for x in out["ranks"]) and "package_w" in out["ranks_cols"]
+    assert all((x[5] is None or x[5] > 0) and (x[7] is None or 0.5 < x[7] < 3.0) for x in out["ranks"])
     # flat per-stage triples [ms, frac_hbm, frac_mfma]; roofline holds scalars only (the driver's parser keeps scalars)
     assert len(out["stages_frac"]["pointwise"]) == 3 and all(not isinstance(v, (dict, list)) for v in out["roofline"].values())
     import torch
