@@ -655,11 +655,17 @@ int mbn_launch_f32_pointwise(const mbn_call &c, void *out, const void *in, const
         mbn_launch_bf16_pw_ring(c, out, in, filt, m, cin, op_size) == MBN_OK)
         return MBN_OK;
 #endif
+    // round 6: short K (Cin 64 / 128 / 256) with BN + ReLU6 on the wave-private GEMM with the filter slice resident in LDS (mbn_f32_pw3.hip; same
+    // bits as pw_gemm, so the choice may depend on M). pw_tile = 9: wherever eligible; 10: never; 0: where it measured faster (MBN_PW3_DEFAULT).
+    if (!bf && (g_mbn_tune.pw_tile == 9 || (g_mbn_tune.pw_tile == 0 && MBN_PW3_DEFAULT(m, cin, op_size, c.ctx->num_cus))) &&
+        mbn_launch_f32_pw3(c, (float *)out, (const float *)in, (const float *)filt, m, cin, op_size) == MBN_OK)
+        return MBN_OK;
     // Tile choice measured per layer on MI355X in fp32 with the software-pipelined loop (tools/layer_bench.py --tune
     // pw_tile=1..8, profiles/r01/e_gemm_tile_sweep_pipelined.txt): 64x64 tiles at 4 workgroups per CU are best from
     // K = 512 up and for K = 256 with wide outputs (133 TFLOP/s = 85 % of the fp32 matrix peak on the 512 -> 512 layers),
     // 8 waves of 32x64 on a 128x128 tile win slightly for K <= 256, <128,64> in between; small grids take 64x64 too.
     int tile = g_mbn_tune.pw_tile;
+    if (tile == 9 || tile == 10) tile = 0;                                 // (pw3 switches: this kernel's own rule)
     // a forced shape this kernel does not have in this build (the value may be meant for the pw_emul kernels, which fell through to
     // here because the layer is outside their envelope): the per-layer rule decides
     if (!MBN_LAB_BUILD && tile != 2 && tile != 3 && tile != 5) tile = 0;

@@ -170,6 +170,11 @@ int mbn_launch_f32_dwpw2(mbn_context *ctx, hipStream_t stream, float *out, const
                          const float *s2, const float *b2, const float *wp, const float *s3, const float *b3, int batch,
                          int in_rows, int in_cols, int out_rows, int out_cols, int cin, int cout, int stride, int pad_top,
                          int pad_left);
+// short-K pointwise GEMM with the filter slice resident in LDS (mbn_f32_pw3.hip, round 6). Taken where it measured faster than pw_gemm (profiles/r06/l_*:
+// layers 5 / 7 / 9 / 11 at batch 256: -22 / -12 / -12 / -7 %, batch 64: -17 / -8 / -9 / -2 %, batch 16: equal; layer 13 (N = 512, four slices): +2 ... +40 %):
+// Cin <= 256, Cout <= 256, at least 128 pixels per CU. Same bits as pw_gemm, so the rule may depend on M.
+#define MBN_PW3_DEFAULT(m, cin, n, cus) ((cin) <= 256 && (n) <= 256 && (m) >= 128L * (cus))
+int mbn_launch_f32_pw3(const mbn_call &c, float *out, const float *in, const float *filt, long m, int cin, int op_size);
 // wave-private form of the fp32 block (mbn_f32_dwpw3.hip, round 6): the default for stride-1 blocks with Cin >= 128 (blocks 6-7 and 10-11 of the
 // 1.0x network: -9...-12 % and -4...-6 % against dwpw2 in alternating runs, profiles/r06/f_*; equal on 8-9, 8 % slower on 4-5: those stay on dwpw2)
 #define MBN_DWPW3_DEFAULT(stride, cin) ((stride) == 1 && (cin) >= 128)

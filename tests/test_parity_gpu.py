@@ -375,6 +375,47 @@ def test_f32_pointwise(pkg, orc, ctx, shape):
         b.free()
 
 
+PW3_SHAPES = [  # (M, Cin, Cout) inside mbn_f32_pw3.hip's envelope: the short-K layers 5 / 7 / 9 / 11 / 13 at small batch, ragged M, several tiles per wave
+    (2 * 56 * 56, 64, 128), (56 * 56 + 7, 128, 128), (2 * 28 * 28, 128, 256), (28 * 28, 256, 256), (2 * 14 * 14, 256, 512), (33, 64, 384),
+    (40 * 56 * 56, 64, 128), (70 * 28 * 28, 128, 256), (90 * 14 * 14 + 5, 256, 128),
+]
+
+
+@pytest.mark.parametrize("shape", PW3_SHAPES)
+def test_f32_pointwise_short_k_resident_filter(pkg, orc, ctx, shape):
+    """Round 6: mbn_f32_pw3.hip (pw_tile = 9 forces it: filter slice resident in LDS, wave-private A staging, no barrier in the loop) against the
+    oracle and BIT FOR BIT against pw_gemm (pw_tile = 10 keeps it off; pw_splitk = 1 keeps the few-tile calls on pw_gemm too): the same
+    v_mfma_f32_32x32x2_f32 k pairs in the same order and the same epilogue arithmetic (kernel.cl:94-114 in the F32 mode)."""
+    m, cin, cout = shape
+    rng = np.random.default_rng(m + cin * 5 + cout)
+    x = rng.uniform(-1, 1, (m, cin)).astype(np.float32)
+    f = rng.normal(0, (2.0 / cin) ** 0.5, (cout, cin)).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    sh = rng.normal(0, 0.1, cout).astype(np.float32)
+    want = orc.f32_pointwise(x, f, sc, sh, 2)
+    d_x, d_f, d_sc, d_sh = (ctx.to_device(a) for a in (x, f, sc, sh))
+    d_a, d_b = ctx.alloc(want.nbytes + 256), ctx.alloc(want.nbytes)
+    ext = pkg.make_ext(batch=1, act=2, scale=d_sc.ptr, shift=d_sh.ptr)
+    try:
+        assert ctx.lib.mbn_tune_set(b"pw_splitk", 1) == 0
+        assert ctx.lib.mbn_tune_set(b"pw_tile", 9) == 0
+        ctx.lib.mbn_memset(ctx.h, d_a.ptr, 0xFF, want.nbytes + 256)
+        ctx.pointwise(d_a.ptr, d_x.ptr, d_f.ptr, m, 1, cin, cout, ext)
+        assert ctx.lib.mbn_tune_set(b"pw_tile", 10) == 0
+        ctx.pointwise(d_b.ptr, d_x.ptr, d_f.ptr, m, 1, cin, cout, ext)
+    finally:
+        ctx.lib.mbn_tune_set(b"pw_tile", 0)
+        ctx.lib.mbn_tune_set(b"pw_splitk", 0)
+    ctx.sync()
+    got, ref = d_a.download(want.shape, np.float32), d_b.download(want.shape, np.float32)
+    assert_close(got, want, TOL_PW, "pw3 %s vs oracle" % (shape,))
+    assert np.array_equal(got, ref), "pw3 differs from pw_gemm by %g" % np.abs(got - ref).max()
+    tail = d_a.download((want.size + 64,), np.float32)[want.size:]
+    assert np.isnan(tail).all(), "pw3 stored past the output"
+    for b in (d_x, d_f, d_sc, d_sh, d_a, d_b):
+        b.free()
+
+
 def test_f32_pointwise_exact_integers(pkg, ctx):
     """Integer-valued operands: every product and partial sum is exact in fp32, so any k-order gives the same
     result — checks the MFMA operand/C-D lane maps bit-exactly with an ASYMMETRIC filter (cdna guide §3)."""
