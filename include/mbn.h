@@ -272,7 +272,8 @@ int mbn_stem_fused_ex(mbn_context *ctx, void *out, const void *image, const void
  * out [batch][out_rows][out_cols][cout]; wd [3][3][cin], wp [cout][cin] as in the separate calls; pad_top/pad_left as in
  * mbn_layer_ext (zero padding; the high side needs none stated). Bit-identical to mbn_depthwise followed by
  * mbn_pointwise. Returns MBN_EUNSUPPORTED unless cin is a multiple of 32 and <= 1024, cout a multiple of 128 and <= 1024, out_cols
- * even and the input under 3.75 GiB — callers then issue the two layer calls instead. */
+ * even and the input under 3.75 GiB — callers then issue the two layer calls instead. Three kernels sit behind it, all with the same bits
+ * (round 6: stride 1 with cin 128 / 256 runs on the wave-private form mbn_f32_dwpw3.hip, everything else on mbn_f32_dwpw2.hip / mbn_f32_dwpw.hip). */
 int mbn_dwpw_fused(mbn_context *ctx, void *out, const void *in, const void *wd, const void *s2, const void *b2,
                    const void *wp, const void *s3, const void *b3, int batch, int in_rows, int in_cols, int out_rows,
                    int out_cols, int cin, int cout, int stride, int pad_top, int pad_left, void *stream);
@@ -561,7 +562,8 @@ const char *mbn_version(void);
  *     mbn_tune_set answers MBN_EUNSUPPORTED for them (mbn_tune_get: 0). mbn_lab_build() tells which library this is.
  * Unknown key => MBN_ENOTFOUND.
  *   pw_tile      force a GEMM tile shape of mbn_pointwise (mbn_f32_pw.hip; with pw_emul: mbn_f32_pw_x6.hip); a shape the build does
- *                not contain => MBN_EUNSUPPORTED from the call. 1 also forces the 128-column tile of mbn_dwpw_fused(_bf16)
+ *                not contain => MBN_EUNSUPPORTED from the call. 1 also forces the 128-column tile of mbn_dwpw_fused(_bf16);
+ *                9 = the short-K resident-filter GEMM (mbn_f32_pw3.hip) wherever eligible, 10 = never (0: where it measured faster; same bits either way)
  *   misc         workgroups per CU of the persistent GEMM grid (1000 = one tile per workgroup); in the split-K kernel 16 / 32 =
  *                force the 16x16 / 32x32 workgroup tile
  *   pw_stage     1 = stage GEMM operands through registers instead of direct-to-LDS loads
