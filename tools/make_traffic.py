@@ -17,7 +17,7 @@ import sys
 def per_dispatch(d, counter):
     f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
     rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter and
-            ("pw_gemm" in r["Kernel_Name"] or "pw_ring" in r["Kernel_Name"] or "pw_stream" in r["Kernel_Name"] or "pw_generic" in r["Kernel_Name"] or "dw3x3" in r["Kernel_Name"] or "dw_generic" in r["Kernel_Name"] or "conv3x3" in r["Kernel_Name"])]
+            ("pw_gemm" in r["Kernel_Name"] or "pw3_f32" in r["Kernel_Name"] or "pw_ring" in r["Kernel_Name"] or "pw_stream" in r["Kernel_Name"] or "pw_generic" in r["Kernel_Name"] or "dw3x3" in r["Kernel_Name"] or "dw_generic" in r["Kernel_Name"] or "conv3x3" in r["Kernel_Name"])]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     def label(n):      # "void (anonymous namespace)::pw_gemm<float, 64, ...>((anonymous namespace)::PwArgs)" -> "pw_gemm<float, 64, ...>"
         n = n.replace("void ", "").replace("(anonymous namespace)::", "")
@@ -39,7 +39,7 @@ def assemble():
     The fp32 section stays at the top level (bench.py's default line), the bf16 sections under their own keys."""
     import datetime
     d, sha = sys.argv[2], sys.argv[3]
-    cmd = "bash tools/r05_traffic.sh %s (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE --kernel-trace over tools/layer_bench.py --iters 3 --warmup 1)" % sha
+    cmd = "bash tools/r06_traffic.sh %s (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE --kernel-trace over tools/layer_bench.py --iters 3 --warmup 1)" % sha
 
     def section(key, workload):
         pw, dw = json.load(open("%s/%s_pw.json" % (d, key))), json.load(open("%s/%s_dw.json" % (d, key)))
