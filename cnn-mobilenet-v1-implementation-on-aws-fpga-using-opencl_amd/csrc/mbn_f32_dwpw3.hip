@@ -79,14 +79,16 @@ __device__ __forceinline__ f4 bn_relu6(f4 a, f4 s, f4 b)
 
 // S = depthwise stride (1, 2), CIN = input channels (64, 128, 256), KS = channels per depthwise half-round and lane group (16: 4 lanes per
 // pixel pair, all 16 pairs at once; 32: 8 lanes per pair, 8 pairs per half-round). ABL: ablation mask (lab; see DwPw3Args::dbg).
-template <int S, int CIN, int KS, int ABL, int SCHED = 0>
+template <int S, int CIN, int KS, int ABL, int SCHED = 0, bool B64 = false>
 __global__ __launch_bounds__(512) void dwpw3_f32(DwPw3Args a)
 {
     constexpr int XC = S + 3;                          // input columns feeding 2 adjacent output pixels
     constexpr int NS = CIN / 16;                       // substeps per tile (32 MFMAs each)
     constexpr int AH = KS / 16;                        // half-rounds per chunk = substeps between a half-round and the MFMAs of its chunk
     constexpr int LPP = KS / 4;                        // lanes per pixel pair
-    constexpr int LDB = CIN + 4;                       // padded filter row (floats)
+    // B64 (lab A/B): B fragments as 8-byte reads, one MFMA group (2 k pairs x 4 blocks) at a time: 16 live registers instead of 32; rows padded to Cin + 2
+    // floats (the 32 lanes of a ds_read_b64 group then fall on 32 different bank pairs)
+    constexpr int LDB = B64 ? CIN + 2 : CIN + 4;       // padded filter row (floats)
     constexpr int ABUF = WT * KS;                      // floats per A buffer; AH buffers per wave (KS 32: by chunk parity)
     static_assert(NS >= 4 && (CIN % 64) == 0 && (KS == 16 || KS == 32), "Cin in multiples of 64");
     __shared__ __attribute__((aligned(16))) float lds[BN3 * LDB + 8 * AH * ABUF + 11 * CIN + 2 * BN3 + 8 * 32];
@@ -138,7 +140,10 @@ __global__ __launch_bounds__(512) void dwpw3_f32(DwPw3Args a)
 #pragma unroll
         for (int i = 0; i < NP; i++) {
             const int p = tid + i * 512, r = p / (CIN / 4), u = p % (CIN / 4);
-            *reinterpret_cast<f4 *>(wp_s + r * LDB + 4 * u) = pc[i];
+            if constexpr (B64) {
+                *reinterpret_cast<f2 *>(wp_s + r * LDB + 4 * u) = f2{ pc[i].x, pc[i].y };
+                *reinterpret_cast<f2 *>(wp_s + r * LDB + 4 * u + 2) = f2{ pc[i].z, pc[i].w };
+            } else *reinterpret_cast<f4 *>(wp_s + r * LDB + 4 * u) = pc[i];
         }
 #pragma unroll
         for (int i = 0; i < 3; i++) {
@@ -281,18 +286,29 @@ __global__ __launch_bounds__(512) void dwpw3_f32(DwPw3Args a)
     };
 
     f16v acc[4];
-    f4 fa[2], fb[2][4];                                // A fragments [g] (g = 0 of the NEXT substep is read behind dw_fin, g = 1 inside the substep), B fragments [g][block]
+    f4 fa[2], fb[B64 ? 1 : 2][B64 ? 1 : 4];            // A fragments [g] (g = 0 of the NEXT substep is read behind dw_fin, g = 1 inside the substep), B fragments [g][block]
+    f2 fbh[B64 ? 2 : 1][B64 ? 4 : 1];                  // B64: B half fragments [group parity][block]
     auto ldfrag_a = [&](const int u, const int g) __attribute__((always_inline)) {
         if (dbg & 128) return;
         const int buf = AH == 2 ? ((u >> 1) & 1) * ABUF : 0, idx = AH == 2 ? 2 * (u & 1) + g : g;
         fa[g] = *reinterpret_cast<const f4 *>(a_w + buf + fra[idx]);
     };
+    // B64: the half fragments of MFMA group G (g = G >> 1, k pairs 2 (G & 1), 2 (G & 1) + 1) of substep u
+    auto ldfrag_bh = [&](const int u, const int G) __attribute__((always_inline)) {
+        if (dbg & 128) return;
+        const int o = u * 16 + (G >> 1) * 8 + (G & 1) * 2;
+        fbh[B64 ? (G & 1) : 0][0] = *reinterpret_cast<const f2 *>(bl01 + o);
+        fbh[B64 ? (G & 1) : 0][B64 ? 1 : 0] = *reinterpret_cast<const f2 *>(bl01 + 32 * LDB + o);
+        fbh[B64 ? (G & 1) : 0][B64 ? 2 : 0] = *reinterpret_cast<const f2 *>(bl23 + o);
+        fbh[B64 ? (G & 1) : 0][B64 ? 3 : 0] = *reinterpret_cast<const f2 *>(bl23 + 32 * LDB + o);
+    };
     auto ldfrag_b = [&](const int u, const int g) __attribute__((always_inline)) {
         if (dbg & 128) return;
+        if constexpr (B64) return;
         fb[g][0] = *reinterpret_cast<const f4 *>(bl01 + u * 16 + g * 8);
-        fb[g][1] = *reinterpret_cast<const f4 *>(bl01 + 32 * LDB + u * 16 + g * 8);
-        fb[g][2] = *reinterpret_cast<const f4 *>(bl23 + u * 16 + g * 8);
-        fb[g][3] = *reinterpret_cast<const f4 *>(bl23 + 32 * LDB + u * 16 + g * 8);
+        fb[g][B64 ? 0 : 1] = *reinterpret_cast<const f4 *>(bl01 + 32 * LDB + u * 16 + g * 8);
+        fb[g][B64 ? 0 : 2] = *reinterpret_cast<const f4 *>(bl23 + u * 16 + g * 8);
+        fb[g][B64 ? 0 : 3] = *reinterpret_cast<const f4 *>(bl23 + 32 * LDB + u * 16 + g * 8);
     };
     // first = the tile's first k pair: the accumulators start from the inline constant 0 (no zeroing between tiles)
     auto mfma8 = [&](const int g, const int s0, const bool first) __attribute__((always_inline)) {
@@ -302,7 +318,7 @@ __global__ __launch_bounds__(512) void dwpw3_f32(DwPw3Args a)
         for (int s = s0; s < s0 + 2; s++)
 #pragma unroll
             for (int t = 0; t < 4; t++)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g][s], fb[g][t][s], (first && s == s0) ? zero : acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g][s], B64 ? fbh[B64 ? ((2 * g + (s0 >> 1)) & 1) : 0][B64 ? t : 0][s & 1] : fb[B64 ? 0 : g][B64 ? 0 : t][s], (first && s == s0) ? zero : acc[t], 0, 0, 0);
     };
     // Accumulator register r of block t: channel n0 + 4 li + t, tile row 8 (r >> 2) + 4 lh + (r & 3) = pixel (r >> 3) of pair 8 ((r >> 2) & 1) + 4 lh + (r & 3).
     // The lane's 8 pairs' output offsets come from po_w (two ds_read_b128); BN of rows r, r + 1 of a channel is one v_pk_fma_f32 (adjacent
@@ -357,6 +373,7 @@ __global__ __launch_bounds__(512) void dwpw3_f32(DwPw3Args a)
     for (int dy = 0; dy < 3; dy++) ldx_row(AH, dy);
     ldfrag_a(0, 0);
     ldfrag_b(0, 0);
+    if constexpr (B64) ldfrag_bh(0, 0);
     ldw_row(AH, 0);
     bool pendE = false;
 
@@ -366,7 +383,7 @@ __global__ __launch_bounds__(512) void dwpw3_f32(DwPw3Args a)
     for (;;) {
         const bool have_next = it + 1 < ntile;
         const unsigned p0N = have_next ? (unsigned)tile_at(it + 1) * 16u : p0M;
-        if (pendE) {                                   // the previous tile's 16 stores, ahead of this tile's first MFMA
+        if (SCHED != 3 && pendE) {                     // the previous tile's 16 stores, ahead of this tile's first MFMA
             epilogue((it - 1) & 1);
             pendE = false;
         }
@@ -376,6 +393,46 @@ __global__ __launch_bounds__(512) void dwpw3_f32(DwPw3Args a)
             const int ud = (u + AH) % NS, ul = (u + AH + 1) % NS;
             // the load cursor enters the next tile (no next tile: stale offsets, unused results)
             if (u == NS - AH - 1 && have_next && !(dbg & 256)) set_offsets_tile(p0N, (it + 1) & 1);
+            if constexpr (SCHED == 3) {
+                // SCHED 3 (lab A/B): in a tile's FIRST substep the whole depthwise part and its window loads are issued AHEAD of the previous tile's stores, the 32
+                // MFMAs behind them. vmcnt retires in order: a load issued behind the 16 stores is not seen complete before they are, and in the pinned form the
+                // first substep's loads (consumed one substep later) sit right behind them.
+                if (u == 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    ldfrag_a(u, 1);
+                    ldfrag_b(u, 1);
+#pragma unroll
+                    for (int dy = 0; dy < 3; dy++) {
+                        dw_row(ud, dy);
+                        if (!(dbg & 1)) ldx_row(ul, dy);
+                    }
+                    dw_fin(ud);                        // (this substep's fragments are in registers: the A tile may be overwritten; the sums and scale / shift die here, ahead of the epilogue's temporaries)
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (pendE) {
+                        epilogue((it - 1) & 1);
+                        pendE = false;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (B64) ldfrag_bh(u, 1);
+                    mfma8(0, 0, true);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (B64) ldfrag_bh(u, 2);
+                    mfma8(0, 2, false);
+                    __builtin_amdgcn_sched_barrier(0);
+                    ldfrag_b((u + 1) % NS, 0);
+                    if constexpr (B64) ldfrag_bh(u, 3);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma8(1, 0, false);
+                    __builtin_amdgcn_sched_barrier(0);
+                    ldfrag_a((u + 1) % NS, 0);
+                    if constexpr (B64) ldfrag_bh((u + 1) % NS, 0);
+                    ldw_row(ul, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma8(1, 2, false);
+                    __builtin_amdgcn_sched_barrier(0);
+                    continue;
+                }
+            }
             // SCHED (lab A/B, exp2): 0 = the four pinned groups below; 1 = one scheduling region per substep, the compiler's own order; 2 = one region with
             // the interleave requested through sched_group_barrier: after every MFMA two VALU and one memory / LDS instruction
 #define SB() do { if constexpr (SCHED == 0) __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -383,12 +440,14 @@ __global__ __launch_bounds__(512) void dwpw3_f32(DwPw3Args a)
             // group 0
             ldfrag_a(u, 1);
             ldfrag_b(u, 1);
+            if constexpr (B64) ldfrag_bh(u, 1);
             dw_row(ud, 0);
             if (!(dbg & 1)) ldx_row(ul, 0);
             SB();
             mfma8(0, 0, u == 0);
             SB();
             // group 1
+            if constexpr (B64) ldfrag_bh(u, 2);
             dw_row(ud, 1);
             if (!(dbg & 1)) ldx_row(ul, 1);
             SB();
@@ -396,6 +455,7 @@ __global__ __launch_bounds__(512) void dwpw3_f32(DwPw3Args a)
             SB();
             // group 2
             ldfrag_b((u + 1) % NS, 0);                 // B fragments g = 0 of the next substep (fb[0] has been consumed)
+            if constexpr (B64) ldfrag_bh(u, 3);
             dw_row(ud, 2);
             if (!(dbg & 1)) ldx_row(ul, 2);
             SB();
@@ -404,6 +464,7 @@ __global__ __launch_bounds__(512) void dwpw3_f32(DwPw3Args a)
             // group 3
             dw_fin(ud);
             ldfrag_a((u + 1) % NS, 0);
+            if constexpr (B64) ldfrag_bh((u + 1) % NS, 0);
             ldw_row(ul, 0);
             SB();
             mfma8(1, 2, false);
@@ -520,13 +581,26 @@ int mbn_launch_f32_dwpw3(mbn_context *ctx, hipStream_t stream, float *out, const
     }
 #endif
 #ifdef MBN_LAB
-    if (stride == 1 && (g_mbn_tune.exp2 == 1 || g_mbn_tune.exp2 == 2) && !a.dbg && cin >= 128) {
+    if (stride == 1 && g_mbn_tune.exp2 == 5 && !a.dbg && cin >= 128) {             // lab A/B: 8-byte B fragment reads + the first substep's loads ahead of the stores
+        if (cin == 128) hipLaunchKernelGGL((dwpw3_f32<1, 128, 32, 0, 3, true>), dim3((unsigned)grid), dim3(512), 0, stream, a);
+        else hipLaunchKernelGGL((dwpw3_f32<1, 256, 16, 0, 3, true>), dim3((unsigned)grid), dim3(512), 0, stream, a);
+        return MBN_OK;
+    }
+    if (stride == 1 && g_mbn_tune.exp2 == 4 && !a.dbg && cin >= 128) {             // lab A/B: 8-byte B fragment reads (16 VGPRs fewer)
+        if (cin == 128) hipLaunchKernelGGL((dwpw3_f32<1, 128, 32, 0, 0, true>), dim3((unsigned)grid), dim3(512), 0, stream, a);
+        else hipLaunchKernelGGL((dwpw3_f32<1, 256, 16, 0, 0, true>), dim3((unsigned)grid), dim3(512), 0, stream, a);
+        return MBN_OK;
+    }
+    if (stride == 1 && g_mbn_tune.exp2 >= 1 && g_mbn_tune.exp2 <= 3 && !a.dbg && cin >= 128) {
+        const int sc = g_mbn_tune.exp2;
         if (cin == 128) {
-            if (g_mbn_tune.exp2 == 1) hipLaunchKernelGGL((dwpw3_f32<1, 128, 32, 0, 1>), dim3((unsigned)grid), dim3(512), 0, stream, a);
-            else hipLaunchKernelGGL((dwpw3_f32<1, 128, 32, 0, 2>), dim3((unsigned)grid), dim3(512), 0, stream, a);
+            if (sc == 1) hipLaunchKernelGGL((dwpw3_f32<1, 128, 32, 0, 1>), dim3((unsigned)grid), dim3(512), 0, stream, a);
+            else if (sc == 2) hipLaunchKernelGGL((dwpw3_f32<1, 128, 32, 0, 2>), dim3((unsigned)grid), dim3(512), 0, stream, a);
+            else hipLaunchKernelGGL((dwpw3_f32<1, 128, 32, 0, 3>), dim3((unsigned)grid), dim3(512), 0, stream, a);
         } else {
-            if (g_mbn_tune.exp2 == 1) hipLaunchKernelGGL((dwpw3_f32<1, 256, 16, 0, 1>), dim3((unsigned)grid), dim3(512), 0, stream, a);
-            else hipLaunchKernelGGL((dwpw3_f32<1, 256, 16, 0, 2>), dim3((unsigned)grid), dim3(512), 0, stream, a);
+            if (sc == 1) hipLaunchKernelGGL((dwpw3_f32<1, 256, 16, 0, 1>), dim3((unsigned)grid), dim3(512), 0, stream, a);
+            else if (sc == 2) hipLaunchKernelGGL((dwpw3_f32<1, 256, 16, 0, 2>), dim3((unsigned)grid), dim3(512), 0, stream, a);
+            else hipLaunchKernelGGL((dwpw3_f32<1, 256, 16, 0, 3>), dim3((unsigned)grid), dim3(512), 0, stream, a);
         }
         return MBN_OK;
     }

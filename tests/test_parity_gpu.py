@@ -378,6 +378,7 @@ def test_f32_pointwise(pkg, orc, ctx, shape):
 PW3_SHAPES = [  # (M, Cin, Cout) inside mbn_f32_pw3.hip's envelope: the short-K layers 5 / 7 / 9 / 11 / 13 at small batch, ragged M, several tiles per wave
     (2 * 56 * 56, 64, 128), (56 * 56 + 7, 128, 128), (2 * 28 * 28, 128, 256), (28 * 28, 256, 256), (2 * 14 * 14, 256, 512), (33, 64, 384),
     (40 * 56 * 56, 64, 128), (70 * 28 * 28, 128, 256), (90 * 14 * 14 + 5, 256, 128),
+    (2 * 14 * 14, 512, 512), (3 * 49 + 1, 512, 1024), (130 * 14 * 14, 512, 64), (300 * 14 * 14, 512, 512),      # K = 512: 64-channel slices, 12 waves per workgroup
 ]
 
 
