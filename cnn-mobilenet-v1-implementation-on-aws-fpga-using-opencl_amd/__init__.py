@@ -43,6 +43,11 @@ class MbnError(RuntimeError):
         super().__init__("mbn error %d (%s) %s" % (code, _strerror(code), what))
 
 
+class BlockParams(C.Structure):
+    """mbn_block_params (include/mbn.h): one depthwise + pointwise block of mbn_blocks_resident_bf16"""
+    _fields_ = [("wd", C.c_void_p), ("s2", C.c_void_p), ("b2", C.c_void_p), ("wp_bf16", C.c_void_p), ("s3", C.c_void_p), ("b3", C.c_void_p)]
+
+
 class LayerExt(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("batch", C.c_int32), ("dtype", C.c_int32), ("layout", C.c_int32),
                 ("act", C.c_int32), ("pad_top", C.c_int32), ("pad_left", C.c_int32), ("in_rows", C.c_int32),
@@ -199,6 +204,7 @@ def load():
         lib.mbn_net_set_input_u8.argtypes = [vp, ci]
         lib.mbn_dwpw_fused.argtypes = [vp] + [vp] * 8 + [ci] * 10 + [vp]
         lib.mbn_dwpw_fused_bf16.argtypes = [vp] + [vp] * 8 + [ci] * 10 + [vp]
+        lib.mbn_blocks_resident_bf16.argtypes = [vp, vp, vp, C.POINTER(BlockParams), ci, ci, ci, ci, ci, vp]
         lib.mbn_softmax_topk_f32.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, vp]
         lib.mbn_classifier_tail.argtypes = [vp] * 9 + [ci] * 6 + [vp]
         lib.mbn_graph_begin.argtypes = [vp, vp]

@@ -879,6 +879,23 @@ int mbn_dwpw_fused(mbn_context *ctx, void *out, const void *in, const void *wd, 
                                          in_rows, in_cols, out_rows, out_cols, cin, cout, stride, pad_top, pad_left));
 }
 
+int mbn_blocks_resident_bf16(mbn_context *ctx, void *out, const void *in, const mbn_block_params *blocks, int nblocks, int batch,
+                             int rows, int cols, int channels, void *stream)
+{
+    if (!ctx || !out || !in || !blocks || batch <= 0) return MBN_EINVAL;
+    if (!mbn_bf16_res_eligible(rows, cols, channels, nblocks)) return MBN_EUNSUPPORTED;
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    const double act = 2.0 * batch * rows * cols * channels;
+    MBN_SPANS(ctx, { in, act, "resident blocks input" }, { out, act, "resident blocks output" });
+    for (int i = 0; i < nblocks; i++) {
+        if (!blocks[i].wd || !blocks[i].s2 || !blocks[i].b2 || !blocks[i].wp_bf16 || !blocks[i].s3 || !blocks[i].b3) return MBN_EINVAL;
+        MBN_SPANS(ctx, { blocks[i].wd, 36.0 * channels, "resident blocks depthwise filter" }, { blocks[i].wp_bf16, 2.0 * channels * channels, "resident blocks pointwise filter" },
+                  { blocks[i].s2, 4.0 * channels, "resident blocks scale" }, { blocks[i].b3, 4.0 * channels, "resident blocks shift" });
+    }
+    Scope sc(ctx, s);
+    return sc.finish(mbn_launch_bf16_res_blocks(ctx, s, out, in, blocks, nblocks, batch, rows, cols, channels));
+}
+
 int mbn_dwpw_fused_bf16(mbn_context *ctx, void *out, const void *in, const void *wd, const void *s2, const void *b2,
                         const void *wp_bf16, const void *s3, const void *b3, int batch, int in_rows, int in_cols, int out_rows,
                         int out_cols, int cin, int cout, int stride, int pad_top, int pad_left, void *stream)

@@ -1,0 +1,245 @@
+// mbn_bf16_res.hip — a RUN of depthwise 3x3 (stride 1) -> pointwise 1x1 blocks on a small map in ONE launch, bf16 mode, the activations
+// RESIDENT in LDS from the first block's input to the last block's output (round 6).
+// Replaces the launch pairs `depthwise` + `pointwise` (kernel.cl:62-92 + 94-114) of consecutive blocks with equal shapes — the five 256 -> 256
+// blocks on the 10 x 10 map of the 0.5x160 network (layers 14-23 of the sequence MobileNet.c:322-2599) — which as five fused launches took
+// 5 x 25 us for work whose HBM floor is 5 x 9 us: at 100 pixels per image a launch is mostly its prologue, its tail round and the gap to the next
+// launch. An image's whole map is 100 x 256 bf16 = 51 KB: a workgroup keeps it in LDS through all the blocks, and only the filters (128 KB per
+// block, bf16) come from the L2, as MFMA operands straight into registers.
+//
+// One workgroup = 8 waves = one image at a time (persistent over images). Two LDS images of the map, both [pixel][C + 8] bf16 (528-byte rows):
+//   X: the block's input with a one-pixel ZERO border ((H + 2) x (W + 2) pixels): the depthwise window reads need no edge logic;
+//   Y: the depthwise output = the pointwise GEMM's activation operand (H x W pixels, padded to 128 rows).
+// Per block: (1) depthwise: a lane owns 8 channels (its 9 taps + scale / shift in registers for the whole block) and walks pixels 16 apart:
+//   9 ds_read_b128 of X, widen, 72 FMAs (fp32), BN + ReLU6, round to bf16, one ds_write_b128 into Y; barrier;
+//   (2) pointwise, transposed: wave w owns output channels 32 w .. 32 w + 31 as the ROWS of v_mfma_f32_32x32x16_bf16 (its filter rows are the
+//   A operand: 16 registers-quads loaded from global memory per block, prefetched under the depthwise phase), the pixels are the columns (B operand:
+//   ds_read_b128 of Y, one per MFMA, conflict-free on the 528-byte rows); C/D puts 4 consecutive output channels of ONE pixel into a lane:
+//   BN + ReLU6, round, one ds_write_b64 into X's interior (the next block's input); barrier.
+// Same arithmetic as the separate bf16 launches (fp32 products of bf16 operands, fp32 sums, every layer output rounded to bf16 RNE) in another
+// summation order for the pointwise part: within the bf16 tolerance of the parity tests, like mbn_bf16_dwpw2.hip.
+// Envelope: C = 256 in and out, stride 1, TF-SAME padding (pad 1), H * W <= 128, (H + 2) * (W + 2) <= 144, 1 ... 8 blocks.
+#include "mbn_internal.h"
+#include "mbn_epilogue.h"
+
+namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f8 __attribute__((ext_vector_type(8)));
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+typedef mbn_f16v f16v;
+
+constexpr int RES_MAXBLK = 8;
+constexpr int XPIX = 144, YPIX = 128;          // pixel rows of the two LDS images
+
+struct ResArgs {
+    __bf16 *out;
+    const __bf16 *in;
+    int batch, h, w, nblk;
+    const float *wd[RES_MAXBLK], *s2[RES_MAXBLK], *b2[RES_MAXBLK], *s3[RES_MAXBLK], *b3[RES_MAXBLK];
+    const __bf16 *wp[RES_MAXBLK];
+};
+
+__device__ __forceinline__ f8 widen8(u4v p)
+{
+    f8 r;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        r[2 * i] = __builtin_bit_cast(float, p[i] << 16);
+        r[2 * i + 1] = __builtin_bit_cast(float, p[i] & 0xffff0000u);
+    }
+    return r;
+}
+__device__ __forceinline__ f8 ld8g(const float *p)
+{
+    const f4 a = *reinterpret_cast<const f4 *>(p), b = *reinterpret_cast<const f4 *>(p + 4);
+    return f8{ a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w };
+}
+__device__ __forceinline__ float relu6(float v) { return fminf(fmaxf(v, 0.f), 6.f); }
+
+template <int C>
+__global__ __launch_bounds__(512) void res_blocks_bf16(ResArgs a)
+{
+    static_assert(C == 256, "8 waves x 32 output channels");
+    constexpr int RS = C + 8;                          // LDS row stride in bf16 (528 bytes: 16-byte aligned, 33 sixteen-byte units: conflict-free operand reads)
+    constexpr int RSB = RS * 2;                        // ... in bytes
+    constexpr int G = C / 8;                           // 8-channel groups per pixel (32)
+    constexpr int PSTEP = 512 / G;                     // pixels covered by the workgroup per depthwise round (16)
+    constexpr int NIT = YPIX / PSTEP;                  // depthwise rounds (8: pixels prow, prow + 16, ... < H * W)
+    constexpr int KG = C / 16;                         // MFMA k steps per block (16)
+    __shared__ __attribute__((aligned(16))) __bf16 x_s[XPIX * RS];
+    __shared__ __attribute__((aligned(16))) __bf16 y_s[YPIX * RS];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int P = a.h * a.w, WB = a.w + 2;
+    char *const xb = reinterpret_cast<char *>(x_s), *const yb = reinterpret_cast<char *>(y_s);
+
+    // zero X once: the border is never written again
+    for (int i = tid; i < XPIX * RS / 8; i += 512) reinterpret_cast<u4v *>(x_s)[i] = u4v{ 0u, 0u, 0u, 0u };
+
+    // ---- depthwise role: channel group cg (fixed), pixels prow + 16 k
+    const int cg = tid % G, prow = tid / G;
+    unsigned xo[NIT];                                  // byte offset of the window origin (bordered coordinates (y, x)) of pixel prow + 16 k, + this lane's channels
+    {
+        const float inv_w = 1.0f / (float)a.w;
+#pragma unroll
+        for (int k = 0; k < NIT; k++) {
+            const int q = prow + PSTEP * k;
+            const int y = (int)__builtin_fmaf((float)q, inv_w, 0.5f * inv_w), x = q - y * a.w;      // exact for these sizes (q < 128)
+            xo[k] = (unsigned)((y * WB + x) * RSB + cg * 16);
+        }
+    }
+    const unsigned yo = (unsigned)(prow * RSB + cg * 16);               // + k * 16 * RSB
+    const unsigned ctr = (unsigned)((WB + 1) * RSB);                    // window origin -> centre pixel
+    // ---- pointwise role: output channels 32 wave + li (A operand rows), pixels 32 b + li (B operand columns)
+    const unsigned yfrag = (unsigned)(li * RSB + lh * 16);              // + b * 32 * RSB + g * 32
+    unsigned xi[4];                                                       // X interior byte offset of pixel 32 b + li (+ this lane's 4 lh channels), or a dump row past the map
+    bool pok[4];
+    {
+        const float inv_w = 1.0f / (float)a.w;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int q = 32 * b + li;
+            const int y = (int)__builtin_fmaf((float)q, inv_w, 0.5f * inv_w), x = q - y * a.w;
+            pok[b] = q < P;
+            xi[b] = (unsigned)(((y + 1) * WB + x + 1) * RSB + (32 * wave_u + 4 * lh) * 2);
+        }
+    }
+
+    for (int n = blockIdx.x; n < a.batch; n += gridDim.x) {
+        __syncthreads();                                                  // (the previous image's output has left X; first pass: the zeroing is done)
+        // ---- image -> X interior: 16-byte pieces, the depthwise role's own (pixel, channel group) items
+        {
+            const __bf16 *src = a.in + (size_t)n * P * C;
+            u4v pc[NIT];
+#pragma unroll
+            for (int k = 0; k < NIT; k++) {
+                const int q = prow + PSTEP * k;
+                pc[k] = q < P ? *reinterpret_cast<const u4v *>(src + (size_t)q * C + cg * 8) : u4v{ 0u, 0u, 0u, 0u };
+            }
+#pragma unroll
+            for (int k = 0; k < NIT; k++)
+                if (prow + PSTEP * k < P) *reinterpret_cast<u4v *>(xb + xo[k] + ctr) = pc[k];
+        }
+        u4v wfr[KG];                                                      // this wave's filter rows of the coming block: k = 16 g + 8 lh .. + 7 of output channel 32 wave + li
+        {
+            const __bf16 *wrow = a.wp[0] + (size_t)(32 * wave_u + li) * C + 8 * lh;
+#pragma unroll
+            for (int g = 0; g < KG; g++) wfr[g] = *reinterpret_cast<const u4v *>(wrow + 16 * g);
+        }
+        __syncthreads();
+
+        for (int blk = 0; blk < a.nblk; blk++) {
+            // ---- (1) depthwise 3x3 + BN + ReLU6: X -> Y
+            {
+                f8 tap[9], sc, sh;
+                const float *wdp = a.wd[blk] + cg * 8;
+#pragma unroll
+                for (int t = 0; t < 9; t++) tap[t] = ld8g(wdp + t * C);
+                sc = ld8g(a.s2[blk] + cg * 8);
+                sh = ld8g(a.b2[blk] + cg * 8);
+#pragma unroll
+                for (int k = 0; k < NIT; k++) {
+                    if (prow + PSTEP * k < P) {                           // (wave-uniform up to the last partial round: 16 pixels per round, 2 per wave)
+                        f8 acc;
+#pragma unroll
+                        for (int i = 0; i < 8; i++) acc[i] = 0.f;
+#pragma unroll
+                        for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+                            for (int dx = 0; dx < 3; dx++) {
+                                const f8 xv = widen8(*reinterpret_cast<const u4v *>(xb + xo[k] + (unsigned)((dy * WB + dx) * RSB)));
+                                acc = __builtin_elementwise_fma(xv, tap[dy * 3 + dx], acc);
+                            }
+                        bf8 o;
+#pragma unroll
+                        for (int i = 0; i < 8; i++) o[i] = (__bf16)relu6(fmaf(acc[i], sc[i], sh[i]));
+                        *reinterpret_cast<bf8 *>(yb + yo + (unsigned)(k * PSTEP * RSB)) = o;
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- (2) pointwise 1x1 + BN + ReLU6: Y x filter -> X interior. D[channel][pixel] = sum_k W[channel][k] * Y[pixel][k]
+            {
+                f16v acc[4];
+#pragma unroll
+                for (int b = 0; b < 4; b++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) acc[b][r] = 0.f;
+#pragma unroll
+                for (int g = 0; g < KG; g++) {
+                    u4v yf[4];
+#pragma unroll
+                    for (int b = 0; b < 4; b++) yf[b] = *reinterpret_cast<const u4v *>(yb + yfrag + (unsigned)(b * 32 * RSB + g * 32));
+#pragma unroll
+                    for (int b = 0; b < 4; b++)
+                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, wfr[g]), __builtin_bit_cast(bf8, yf[b]), acc[b], 0, 0, 0);
+                }
+                // the next block's filter rows: requested now, needed behind the next depthwise phase
+                if (blk + 1 < a.nblk) {
+                    const __bf16 *wrow = a.wp[blk + 1] + (size_t)(32 * wave_u + li) * C + 8 * lh;
+#pragma unroll
+                    for (int g = 0; g < KG; g++) wfr[g] = *reinterpret_cast<const u4v *>(wrow + 16 * g);
+                }
+                // C/D: register r of block b = output channel 32 wave + 8 (r >> 2) + 4 lh + (r & 3) of pixel 32 b + li
+                const float *s3p = a.s3[blk] + 32 * wave_u + 4 * lh, *b3p = a.b3[blk] + 32 * wave_u + 4 * lh;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const f4 sc = *reinterpret_cast<const f4 *>(s3p + 8 * j), sh = *reinterpret_cast<const f4 *>(b3p + 8 * j);
+#pragma unroll
+                    for (int b = 0; b < 4; b++) {
+                        const bf4 o = bf4{ (__bf16)relu6(fmaf(acc[b][4 * j], sc.x, sh.x)), (__bf16)relu6(fmaf(acc[b][4 * j + 1], sc.y, sh.y)),
+                                           (__bf16)relu6(fmaf(acc[b][4 * j + 2], sc.z, sh.z)), (__bf16)relu6(fmaf(acc[b][4 * j + 3], sc.w, sh.w)) };
+                        if (pok[b]) *reinterpret_cast<bf4 *>(xb + xi[b] + (unsigned)(16 * j)) = o;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        // ---- X interior -> output
+        {
+            __bf16 *dst = a.out + (size_t)n * P * C;
+#pragma unroll
+            for (int k = 0; k < NIT; k++) {
+                const int q = prow + PSTEP * k;
+                if (q < P) *reinterpret_cast<u4v *>(dst + (size_t)q * C + cg * 8) = *reinterpret_cast<const u4v *>(xb + xo[k] + ctr);
+            }
+        }
+    }
+}
+
+}   // namespace
+
+// 1 when a run of blocks can stay resident: C = 256, stride 1 with pad 1 (TF-SAME), a map of at most 128 pixels whose bordered form fits 144
+int mbn_bf16_res_eligible(int rows, int cols, int channels, int nblocks)
+{
+    return channels == 256 && rows >= 1 && cols >= 1 && rows * cols <= YPIX && (rows + 2) * (cols + 2) <= XPIX && nblocks >= 1 && nblocks <= RES_MAXBLK;
+}
+
+int mbn_launch_bf16_res_blocks(mbn_context *ctx, hipStream_t stream, void *out, const void *in, const mbn_block_params *blocks, int nblocks, int batch,
+                               int rows, int cols, int channels)
+{
+    if (!mbn_bf16_res_eligible(rows, cols, channels, nblocks)) return MBN_EUNSUPPORTED;
+    if (!out || !in || !blocks || batch <= 0) return MBN_EINVAL;
+    if (((uintptr_t)out % 16) || ((uintptr_t)in % 16)) return MBN_EUNSUPPORTED;
+    ResArgs a;
+    a.out = (__bf16 *)out; a.in = (const __bf16 *)in;
+    a.batch = batch; a.h = rows; a.w = cols; a.nblk = nblocks;
+    for (int i = 0; i < nblocks; i++) {
+        const mbn_block_params &b = blocks[i];
+        const void *ptrs[] = { b.wd, b.s2, b.b2, b.wp_bf16, b.s3, b.b3 };
+        for (const void *p : ptrs)
+            if (!p || ((uintptr_t)p % 16)) return p ? MBN_EUNSUPPORTED : MBN_EINVAL;
+        a.wd[i] = (const float *)b.wd; a.s2[i] = (const float *)b.s2; a.b2[i] = (const float *)b.b2;
+        a.wp[i] = (const __bf16 *)b.wp_bf16; a.s3[i] = (const float *)b.s3; a.b3[i] = (const float *)b.b3;
+    }
+    for (int i = nblocks; i < RES_MAXBLK; i++) { a.wd[i] = a.s2[i] = a.b2[i] = a.s3[i] = a.b3[i] = nullptr; a.wp[i] = nullptr; }
+    long grid = ctx->num_cus;
+    if (grid > batch) grid = batch;
+    hipLaunchKernelGGL((res_blocks_bf16<256>), dim3((unsigned)grid), dim3(512), 0, stream, a);
+    return MBN_OK;
+}

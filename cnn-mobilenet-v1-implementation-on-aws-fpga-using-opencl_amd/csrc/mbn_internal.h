@@ -175,6 +175,10 @@ int mbn_launch_f32_dwpw2(mbn_context *ctx, hipStream_t stream, float *out, const
 // Cin <= 256, Cout <= 256, at least 128 pixels per CU. Same bits as pw_gemm, so the rule may depend on M.
 #define MBN_PW3_DEFAULT(m, cin, n, cus) ((cin) <= 256 && (n) <= 256 && (m) >= 128L * (cus))
 int mbn_launch_f32_pw3(const mbn_call &c, float *out, const float *in, const float *filt, long m, int cin, int op_size);
+// a run of equal bf16 blocks with the activations resident in LDS (mbn_bf16_res.hip, round 6)
+int mbn_bf16_res_eligible(int rows, int cols, int channels, int nblocks);
+int mbn_launch_bf16_res_blocks(mbn_context *ctx, hipStream_t stream, void *out, const void *in, const mbn_block_params *blocks, int nblocks, int batch,
+                               int rows, int cols, int channels);
 // wave-private form of the fp32 block (mbn_f32_dwpw3.hip, round 6): the default for stride-1 blocks with Cin >= 128 (blocks 6-7 and 10-11 of the
 // 1.0x network: -9...-12 % and -4...-6 % against dwpw2 in alternating runs, profiles/r06/f_*; equal on 8-9, 8 % slower on 4-5: those stay on dwpw2)
 #define MBN_DWPW3_DEFAULT(stride, cin) ((stride) == 1 && (cin) >= 128)

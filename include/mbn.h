@@ -278,6 +278,21 @@ int mbn_dwpw_fused(mbn_context *ctx, void *out, const void *in, const void *wd, 
                    const void *wp, const void *s3, const void *b3, int batch, int in_rows, int in_cols, int out_rows,
                    int out_cols, int cin, int cout, int stride, int pad_top, int pad_left, void *stream);
 
+/* A RUN of equal fused blocks with the activations resident on chip (round 6; bf16 mode): `nblocks` consecutive depthwise 3x3 (stride 1, zero
+ * padding 1) + pointwise 1x1 pairs of the sequence (MobileNet.c:322-2599; kernel.cl:62-92 + 94-114) with `channels` channels in and out on a
+ * rows x cols map, each stage followed by its folded-BN scale/shift and ReLU6, in ONE launch: an image's map stays in LDS from the first block's input to
+ * the last block's output, only the filters come from memory. in / out: bf16 NHWC [batch][rows][cols][channels]; per block: wd [3][3][channels],
+ * s2, b2 [channels] fp32, wp_bf16 [channels][channels] bf16, s3, b3 [channels] fp32, as in mbn_dwpw_fused_bf16. Same arithmetic as the separate bf16
+ * launches within the bf16 tolerance. Returns MBN_EUNSUPPORTED unless channels == 256, rows * cols <= 128, (rows + 2) * (cols + 2) <= 144 and
+ * 1 <= nblocks <= 8 (the five 256 -> 256 blocks on the 10 x 10 map of the 0.5x160 network) — callers then issue the blocks one by one. */
+typedef struct mbn_block_params {
+    const void *wd, *s2, *b2;       /* depthwise filter, scale, shift (fp32) */
+    const void *wp_bf16;            /* pointwise filter [cout][cin], bf16 */
+    const void *s3, *b3;            /* pointwise scale, shift (fp32) */
+} mbn_block_params;
+int mbn_blocks_resident_bf16(mbn_context *ctx, void *out, const void *in, const mbn_block_params *blocks, int nblocks, int batch,
+                             int rows, int cols, int channels, void *stream);
+
 /* Classifier tail on device, fp32 (replaces the host loop MobileNet.c:2771-2792):
  * probs[n][k] = softmax(logits[n][:]) and argmax[n] (0-based). probs or argmax may be NULL. */
 int mbn_softmax_f32(mbn_context *ctx, void *probs, void *argmax_i32, const void *logits, int batch,

@@ -1535,6 +1535,62 @@ def test_bf16_dwpw_fused(pkg, orc, ctx, shape):
     _bf16_dwpw_fused_body(pkg, orc, ctx, shape)
 
 
+@pytest.mark.parametrize("shape", [(3, 10, 10, 5), (600, 10, 10, 5), (2, 8, 8, 1), (5, 7, 9, 3), (1, 10, 10, 8), (4, 6, 6, 2)])
+def test_bf16_blocks_resident(pkg, orc, ctx, shape):
+    """Round 6: mbn_blocks_resident_bf16 (mbn_bf16_res.hip): a run of 256 -> 256 depthwise + pointwise blocks on a small map in one launch, the map
+    resident in LDS — against the oracle's bf16 emulation of the chain (every layer output rounded to bf16) and against the same blocks issued one by
+    one through mbn_dwpw_fused_bf16 (layers 14-23 of the 0.5x160 network: MobileNet.c:322-2599 pairs; kernel.cl:62-92 + 94-114). bf16 tolerance per
+    block, compounding over the run; odd map sides, one image per several passes of the grid (600 images > one workgroup per CU)."""
+    n, h, w, nblk = shape
+    c = 256
+    rng = np.random.default_rng(n + 7 * h + 13 * w + nblk)
+    x = orc.bf16_round(rng.uniform(0, 4, (n, h, w, c)).astype(np.float32))
+    params, dev = [], []
+    for _ in range(nblk):
+        wd = rng.normal(0, 0.5, (3, 3, c)).astype(np.float32)
+        wp = orc.bf16_round(rng.normal(0, (2.0 / c) ** 0.5, (c, c)).astype(np.float32))
+        s2, s3 = rng.uniform(0.5, 1.5, c).astype(np.float32), rng.uniform(0.5, 1.5, c).astype(np.float32)
+        b2, b3 = rng.normal(0, 0.1, c).astype(np.float32), rng.normal(0, 0.1, c).astype(np.float32)
+        params.append((wd, s2, b2, wp, s3, b3))
+        dev.append([ctx.to_device(wd), ctx.to_device(s2), ctx.to_device(b2), _bf16_dev(pkg, ctx, wp), ctx.to_device(s3), ctx.to_device(b3)])
+    nref = min(n, 3)                                  # the oracle chain on the first images (and the last one) only: it is the slow part
+    sel = list(range(nref)) + ([n - 1] if n > nref else [])
+    want = x[sel].copy()
+    for wd, s2, b2, wp, s3, b3 in params:
+        mid = orc.bf16_round(orc.f32_depthwise(want, wd, s2, b2, 1, 2, pad_top=1, pad_left=1))
+        want = orc.bf16_round(orc.f32_pointwise(mid.reshape(-1, c), wp, s3, b3, 2).reshape(want.shape))
+    d_x = _bf16_dev(pkg, ctx, x)
+    d_o, d_p, d_q = ctx.alloc(x.size * 2 + 64), ctx.alloc(x.size * 2), ctx.alloc(x.size * 2)
+    ctx.lib.mbn_memset(ctx.h, d_o.ptr, 0xFF, x.size * 2 + 64)
+    arr = (pkg.BlockParams * nblk)()
+    for i, d in enumerate(dev):
+        arr[i].wd, arr[i].s2, arr[i].b2, arr[i].wp_bf16, arr[i].s3, arr[i].b3 = (t.ptr for t in d)
+    rc = ctx.lib.mbn_blocks_resident_bf16(ctx.h, d_o.ptr, d_x.ptr, arr, nblk, n, h, w, c, None)
+    assert rc == 0, rc
+    src, dst = d_x, d_p
+    for d in dev:                                      # the same run, block by block
+        rc = ctx.lib.mbn_dwpw_fused_bf16(ctx.h, dst.ptr, src.ptr, d[0].ptr, d[1].ptr, d[2].ptr, d[3].ptr, d[4].ptr, d[5].ptr, n, h, w, h, w, c, c, 1, 1, 1, None)
+        if rc == pkg.EUNSUPPORTED:                     # odd widths are outside the block kernel's envelope: the oracle alone checks those
+            src = None
+            break
+        assert rc == 0, rc
+        src, dst = dst, (d_q if dst is d_p else d_p)
+    ctx.sync()
+    got = _bf16_get(pkg, d_o, (n, h, w, c))
+    scale = max(float(np.abs(want).max()), 1e-3)
+    err = float(np.abs(got[sel] - want).max()) / scale
+    assert err <= TOL_BF16 * (1 + 0.5 * (nblk - 1)), "resident blocks %s vs oracle: %g" % (shape, err)
+    if src is not None:
+        ref = _bf16_get(pkg, src, (n, h, w, c))
+        err2 = float(np.abs(got - ref).max()) / max(float(np.abs(ref).max()), 1e-3)
+        assert err2 <= TOL_BF16 * (1 + 0.5 * (nblk - 1)), "resident blocks %s vs block-by-block: %g" % (shape, err2)
+    tail = d_o.download((x.size + 32,), np.uint16)[x.size:]
+    assert (tail == 0xFFFF).all(), "resident blocks stored past the output"
+    # outside the envelope: MBN_EUNSUPPORTED, never a launch
+    assert ctx.lib.mbn_blocks_resident_bf16(ctx.h, d_o.ptr, d_x.ptr, arr, nblk, n, 12, 12, c, None) == pkg.EUNSUPPORTED
+    assert ctx.lib.mbn_blocks_resident_bf16(ctx.h, d_o.ptr, d_x.ptr, arr, nblk, n, h, w, 128, None) == pkg.EUNSUPPORTED
+
+
 @pytest.mark.parametrize("shape", [(2, 112, 64, 128, 2), (2, 56, 128, 128, 1), (2, 56, 128, 256, 2), (2, 28, 256, 256, 1), (3, 14, 64, 128, 1)])
 def test_bf16_dwpw_fused_16x16x32_form(pkg, orc, ctx, shape):
     """LAB (misc = 32): the same block kernel with its pointwise products on v_mfma_f32_16x16x32_bf16 (round 4; measured equal to the shipped
