@@ -9,8 +9,12 @@
 // One workgroup = 8 waves = one image at a time (persistent over images). Two LDS images of the map, both [pixel][C + 8] bf16 (528-byte rows):
 //   X: the block's input with a one-pixel ZERO border ((H + 2) x (W + 2) pixels): the depthwise window reads need no edge logic;
 //   Y: the depthwise output = the pointwise GEMM's activation operand (H x W pixels, padded to 128 rows).
-// Per block: (1) depthwise: a lane owns 8 channels (its 9 taps + scale / shift in registers for the whole block) and walks pixels 16 apart:
-//   9 ds_read_b128 of X, widen, 72 FMAs (fp32), BN + ReLU6, round to bf16, one ds_write_b128 into Y; barrier;
+// Per block: (1) depthwise as a COLUMN MARCH: a lane owns one column x 8 channels (its 9 taps + scale / shift in registers for the whole block, requested
+//   while the previous block's GEMM ran) and walks down the rows; every input row is read and widened ONCE (3 ds_read_b128) and feeds the three output
+//   rows it belongs to (three running sums, same dy-major fma chain as the separate kernels): 24 widening instructions per output pixel group instead of
+//   72 — the first form of this kernel (9 reads + 72 widenings per output) was exactly as fast as five separate launches, both bound by that VALU work.
+//   Waves 0-3 take two columns each over the whole height, waves 4-7 (the partners on the same SIMDs) a quarter of the rows of the remaining columns;
+//   BN + ReLU6, round to bf16, one ds_write_b128 into Y per output; barrier;
 //   (2) pointwise, transposed: wave w owns output channels 32 w .. 32 w + 31 as the ROWS of v_mfma_f32_32x32x16_bf16 (its filter rows are the
 //   A operand: 16 registers-quads loaded from global memory per block, prefetched under the depthwise phase), the pixels are the columns (B operand:
 //   ds_read_b128 of Y, one per MFMA, conflict-free on the 528-byte rows); C/D puts 4 consecutive output channels of ONE pixel into a lane:
@@ -38,6 +42,7 @@ struct ResArgs {
     __bf16 *out;
     const __bf16 *in;
     int batch, h, w, nblk;
+    int dbg;                // lab ablations (exp0 = 900 + bits): 1 no depthwise march, 2 no MFMA loop, 4 no epilogue, 8 no tap / filter prefetch loads, 16 no image load / store (timing only)
     const float *wd[RES_MAXBLK], *s2[RES_MAXBLK], *b2[RES_MAXBLK], *s3[RES_MAXBLK], *b3[RES_MAXBLK];
     const __bf16 *wp[RES_MAXBLK];
 };
@@ -71,6 +76,7 @@ __global__ __launch_bounds__(512) void res_blocks_bf16(ResArgs a)
     constexpr int KG = C / 16;                         // MFMA k steps per block (16)
     __shared__ __attribute__((aligned(16))) __bf16 x_s[XPIX * RS];
     __shared__ __attribute__((aligned(16))) __bf16 y_s[YPIX * RS];
+    __shared__ __attribute__((aligned(16))) float sb3_s[RES_MAXBLK * 2 * C];       // pointwise scale | shift of every block (the epilogue reads them per block: LDS, not a memory round trip)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -80,40 +86,47 @@ __global__ __launch_bounds__(512) void res_blocks_bf16(ResArgs a)
 
     // zero X once: the border is never written again
     for (int i = tid; i < XPIX * RS / 8; i += 512) reinterpret_cast<u4v *>(x_s)[i] = u4v{ 0u, 0u, 0u, 0u };
-
-    // ---- depthwise role: channel group cg (fixed), pixels prow + 16 k
-    const int cg = tid % G, prow = tid / G;
-    unsigned xo[NIT];                                  // byte offset of the window origin (bordered coordinates (y, x)) of pixel prow + 16 k, + this lane's channels
-    {
-        const float inv_w = 1.0f / (float)a.w;
-#pragma unroll
-        for (int k = 0; k < NIT; k++) {
-            const int q = prow + PSTEP * k;
-            const int y = (int)__builtin_fmaf((float)q, inv_w, 0.5f * inv_w), x = q - y * a.w;      // exact for these sizes (q < 128)
-            xo[k] = (unsigned)((y * WB + x) * RSB + cg * 16);
-        }
+    for (int i = tid; i < a.nblk * C; i += 512) {
+        const int blk = i / C, ch = i % C;
+        sb3_s[blk * 2 * C + ch] = a.s3[blk][ch];
+        sb3_s[blk * 2 * C + C + ch] = a.b3[blk][ch];
     }
-    const unsigned yo = (unsigned)(prow * RSB + cg * 16);               // + k * 16 * RSB
-    const unsigned ctr = (unsigned)((WB + 1) * RSB);                    // window origin -> centre pixel
+
+    // ---- image load / store role: channel group cg, pixels prow + 16 k (offsets recomputed where used: nothing of this lives through the blocks)
+    const int cg = tid % G, prow = tid / G;
+    const float inv_w = 1.0f / (float)a.w;
+    auto xint = [&](int q) __attribute__((always_inline)) {              // X interior byte offset of pixel q (exact quotient for q < 128)
+        const int y = (int)__builtin_fmaf((float)q, inv_w, 0.5f * inv_w), x = q - y * a.w;
+        return (unsigned)(((y + 1) * WB + x + 1) * RSB);
+    };
     // ---- pointwise role: output channels 32 wave + li (A operand rows), pixels 32 b + li (B operand columns)
     const unsigned yfrag = (unsigned)(li * RSB + lh * 16);              // + b * 32 * RSB + g * 32
-    unsigned xi[4];                                                       // X interior byte offset of pixel 32 b + li (+ this lane's 4 lh channels), or a dump row past the map
-    bool pok[4];
+
+    // ---- depthwise march role: column pair jobs (see the header); lane = (column of the pair, channel group)
+    const int cgm = lane & 31;
+    const int CP = (a.w + 1) / 2, RQ = (a.h + 3) / 4;
+    f8 tap[9], sc, sh;                                                    // taps / scale / shift of the block the next depthwise phase works on
     {
-        const float inv_w = 1.0f / (float)a.w;
+        const float *wdp = a.wd[0] + cgm * 8;
 #pragma unroll
-        for (int b = 0; b < 4; b++) {
-            const int q = 32 * b + li;
-            const int y = (int)__builtin_fmaf((float)q, inv_w, 0.5f * inv_w), x = q - y * a.w;
-            pok[b] = q < P;
-            xi[b] = (unsigned)(((y + 1) * WB + x + 1) * RSB + (32 * wave_u + 4 * lh) * 2);
-        }
+        for (int t = 0; t < 9; t++) tap[t] = ld8g(wdp + t * C);
+        sc = ld8g(a.s2[0] + cgm * 8);
+        sh = ld8g(a.b2[0] + cgm * 8);
+    }
+
+    u4v wfr[KG];                                                          // this wave's filter rows of the coming block: k = 16 g + 8 lh .. + 7 of output channel 32 wave + li
+    {
+        const __bf16 *wrow = a.wp[0] + (size_t)(32 * wave_u + li) * C + 8 * lh;
+#pragma unroll
+        for (int g = 0; g < KG / 2; g++) wfr[g] = *reinterpret_cast<const u4v *>(wrow + 16 * g);
+#pragma unroll
+        for (int g = KG / 2; g < KG; g++) wfr[g] = u4v{ 0u, 0u, 0u, 0u };
     }
 
     for (int n = blockIdx.x; n < a.batch; n += gridDim.x) {
         __syncthreads();                                                  // (the previous image's output has left X; first pass: the zeroing is done)
-        // ---- image -> X interior: 16-byte pieces, the depthwise role's own (pixel, channel group) items
-        {
+        // ---- image -> X interior: 16-byte pieces
+        if (!(a.dbg & 16)) {
             const __bf16 *src = a.in + (size_t)n * P * C;
             u4v pc[NIT];
 #pragma unroll
@@ -122,45 +135,65 @@ __global__ __launch_bounds__(512) void res_blocks_bf16(ResArgs a)
                 pc[k] = q < P ? *reinterpret_cast<const u4v *>(src + (size_t)q * C + cg * 8) : u4v{ 0u, 0u, 0u, 0u };
             }
 #pragma unroll
-            for (int k = 0; k < NIT; k++)
-                if (prow + PSTEP * k < P) *reinterpret_cast<u4v *>(xb + xo[k] + ctr) = pc[k];
-        }
-        u4v wfr[KG];                                                      // this wave's filter rows of the coming block: k = 16 g + 8 lh .. + 7 of output channel 32 wave + li
-        {
-            const __bf16 *wrow = a.wp[0] + (size_t)(32 * wave_u + li) * C + 8 * lh;
-#pragma unroll
-            for (int g = 0; g < KG; g++) wfr[g] = *reinterpret_cast<const u4v *>(wrow + 16 * g);
+            for (int k = 0; k < NIT; k++) {
+                const int q = prow + PSTEP * k;
+                if (q < P) *reinterpret_cast<u4v *>(xb + xint(q) + cg * 16) = pc[k];
+            }
         }
         __syncthreads();
 
         for (int blk = 0; blk < a.nblk; blk++) {
-            // ---- (1) depthwise 3x3 + BN + ReLU6: X -> Y
-            {
-                f8 tap[9], sc, sh;
-                const float *wdp = a.wd[blk] + cg * 8;
+            // ---- (1) depthwise 3x3 + BN + ReLU6: X -> Y, column march (taps / scale / shift of this block are in registers)
+            if (!(a.dbg & 1))
+            for (int cpj = (wave_u < 4 ? wave_u : 4); cpj < CP; cpj += (wave_u < 4 ? CP : 1)) {
+                const int col = 2 * cpj + (lane >> 5);
+                const int r0 = wave_u < 4 ? 0 : (wave_u - 4) * RQ;
+                const int nr = wave_u < 4 ? a.h : min(RQ, a.h - r0);
+                if (nr <= 0) break;
+                const bool cok = col < a.w;
+                const unsigned colx = (unsigned)(min(col, a.w - 1));                      // (a column past the map reads the last one: valid LDS, never written out)
+                unsigned xa = (unsigned)((r0 * WB + colx) * RSB + cgm * 16);              // bordered row r0 + i, bordered columns colx .. colx + 2
+                unsigned ya = (unsigned)(((r0 - 2) * a.w + (int)colx) * RSB + cgm * 16);  // output row r0 + i - 2
+                f8 s0, s1, s2;
 #pragma unroll
-                for (int t = 0; t < 9; t++) tap[t] = ld8g(wdp + t * C);
-                sc = ld8g(a.s2[blk] + cg * 8);
-                sh = ld8g(a.b2[blk] + cg * 8);
-#pragma unroll
-                for (int k = 0; k < NIT; k++) {
-                    if (prow + PSTEP * k < P) {                           // (wave-uniform up to the last partial round: 16 pixels per round, 2 per wave)
-                        f8 acc;
-#pragma unroll
-                        for (int i = 0; i < 8; i++) acc[i] = 0.f;
-#pragma unroll
-                        for (int dy = 0; dy < 3; dy++)
-#pragma unroll
-                            for (int dx = 0; dx < 3; dx++) {
-                                const f8 xv = widen8(*reinterpret_cast<const u4v *>(xb + xo[k] + (unsigned)((dy * WB + dx) * RSB)));
-                                acc = __builtin_elementwise_fma(xv, tap[dy * 3 + dx], acc);
-                            }
-                        bf8 o;
-#pragma unroll
-                        for (int i = 0; i < 8; i++) o[i] = (__bf16)relu6(fmaf(acc[i], sc[i], sh[i]));
-                        *reinterpret_cast<bf8 *>(yb + yo + (unsigned)(k * PSTEP * RSB)) = o;
-                    }
+                for (int i = 0; i < 8; i++) s0[i] = s1[i] = s2[i] = 0.f;
+                // input row i of the job: dy = 0 for output i (starts its sum), dy = 1 for output i - 1, dy = 2 for output i - 2 (completes it)
+#define RES_DW_ROW(I, SA, SB, SC)                                                                                             \
+                if ((I) < nr + 2) {                                                                                           \
+                    const f8 x0 = widen8(*reinterpret_cast<const u4v *>(xb + xa)), x1 = widen8(*reinterpret_cast<const u4v *>(xb + xa + RSB)), \
+                             x2 = widen8(*reinterpret_cast<const u4v *>(xb + xa + 2 * RSB));                                    \
+                    f8 z;                                                                                                     \
+                    _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) z[i_] = 0.f;                                             \
+                    SA = __builtin_elementwise_fma(x0, tap[0], z);                                                            \
+                    SA = __builtin_elementwise_fma(x1, tap[1], SA);                                                           \
+                    SA = __builtin_elementwise_fma(x2, tap[2], SA);                                                           \
+                    SB = __builtin_elementwise_fma(x0, tap[3], SB);                                                           \
+                    SB = __builtin_elementwise_fma(x1, tap[4], SB);                                                           \
+                    SB = __builtin_elementwise_fma(x2, tap[5], SB);                                                           \
+                    SC = __builtin_elementwise_fma(x0, tap[6], SC);                                                           \
+                    SC = __builtin_elementwise_fma(x1, tap[7], SC);                                                           \
+                    SC = __builtin_elementwise_fma(x2, tap[8], SC);                                                           \
+                    if ((I) >= 2 && cok) {                                                                                    \
+                        bf8 o;                                                                                                \
+                        _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) o[i_] = (__bf16)relu6(fmaf(SC[i_], sc[i_], sh[i_])); \
+                        *reinterpret_cast<bf8 *>(yb + ya) = o;                                                                \
+                    }                                                                                                         \
+                    xa += (unsigned)(WB * RSB);                                                                               \
+                    ya += (unsigned)(a.w * RSB);                                                                              \
                 }
+                for (int i0 = 0; i0 < nr + 2; i0 += 3) {
+                    RES_DW_ROW(i0, s0, s2, s1)
+                    RES_DW_ROW(i0 + 1, s1, s0, s2)
+                    RES_DW_ROW(i0 + 2, s2, s1, s0)
+                }
+#undef RES_DW_ROW
+            }
+            // the second half of THIS block's filter rows: requested now (the taps' registers are free until the prefetch behind the MFMAs), used from k step 8 on —
+            // eight k steps of MFMAs on both waves of the SIMD cover the L2 round trip
+            if (!(a.dbg & 8)) {
+                const __bf16 *wrow = a.wp[blk] + (size_t)(32 * wave_u + li) * C + 8 * lh;
+#pragma unroll
+                for (int g = KG / 2; g < KG; g++) wfr[g] = *reinterpret_cast<const u4v *>(wrow + 16 * g);
             }
             __syncthreads();
             // ---- (2) pointwise 1x1 + BN + ReLU6: Y x filter -> X interior. D[channel][pixel] = sum_k W[channel][k] * Y[pixel][k]
@@ -170,6 +203,7 @@ __global__ __launch_bounds__(512) void res_blocks_bf16(ResArgs a)
                 for (int b = 0; b < 4; b++)
 #pragma unroll
                     for (int r = 0; r < 16; r++) acc[b][r] = 0.f;
+                if (!(a.dbg & 2))
 #pragma unroll
                 for (int g = 0; g < KG; g++) {
                     u4v yf[4];
@@ -179,14 +213,25 @@ __global__ __launch_bounds__(512) void res_blocks_bf16(ResArgs a)
                     for (int b = 0; b < 4; b++)
                         acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, wfr[g]), __builtin_bit_cast(bf8, yf[b]), acc[b], 0, 0, 0);
                 }
-                // the next block's filter rows: requested now, needed behind the next depthwise phase
-                if (blk + 1 < a.nblk) {
-                    const __bf16 *wrow = a.wp[blk + 1] + (size_t)(32 * wave_u + li) * C + 8 * lh;
+                // the next block's filter rows and depthwise taps (the next image's first block after the last one): requested now — the accumulators are the only
+                // other large live set — they fly under the epilogue and the barrier
+                if (!(a.dbg & 8)) {
+                    const int nb = blk + 1 < a.nblk ? blk + 1 : 0;
+                    const __bf16 *wrow = a.wp[nb] + (size_t)(32 * wave_u + li) * C + 8 * lh;
 #pragma unroll
-                    for (int g = 0; g < KG; g++) wfr[g] = *reinterpret_cast<const u4v *>(wrow + 16 * g);
+                    for (int g = 0; g < KG / 2; g++) wfr[g] = *reinterpret_cast<const u4v *>(wrow + 16 * g);       // (the first half; the second behind the next depthwise phase: registers)
+                    const float *wdp = a.wd[nb] + cgm * 8;
+#pragma unroll
+                    for (int t = 0; t < 9; t++) tap[t] = ld8g(wdp + t * C);
+                    sc = ld8g(a.s2[nb] + cgm * 8);
+                    sh = ld8g(a.b2[nb] + cgm * 8);
                 }
                 // C/D: register r of block b = output channel 32 wave + 8 (r >> 2) + 4 lh + (r & 3) of pixel 32 b + li
-                const float *s3p = a.s3[blk] + 32 * wave_u + 4 * lh, *b3p = a.b3[blk] + 32 * wave_u + 4 * lh;
+                unsigned xi[4];
+#pragma unroll
+                for (int b = 0; b < 4; b++) xi[b] = xint(min(32 * b + li, P - 1)) + (unsigned)((32 * wave_u + 4 * lh) * 2);
+                const float *s3p = sb3_s + blk * 2 * C + 32 * wave_u + 4 * lh, *b3p = s3p + C;
+                if (!(a.dbg & 4))
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const f4 sc = *reinterpret_cast<const f4 *>(s3p + 8 * j), sh = *reinterpret_cast<const f4 *>(b3p + 8 * j);
@@ -194,19 +239,19 @@ __global__ __launch_bounds__(512) void res_blocks_bf16(ResArgs a)
                     for (int b = 0; b < 4; b++) {
                         const bf4 o = bf4{ (__bf16)relu6(fmaf(acc[b][4 * j], sc.x, sh.x)), (__bf16)relu6(fmaf(acc[b][4 * j + 1], sc.y, sh.y)),
                                            (__bf16)relu6(fmaf(acc[b][4 * j + 2], sc.z, sh.z)), (__bf16)relu6(fmaf(acc[b][4 * j + 3], sc.w, sh.w)) };
-                        if (pok[b]) *reinterpret_cast<bf4 *>(xb + xi[b] + (unsigned)(16 * j)) = o;
+                        if (32 * b + li < P) *reinterpret_cast<bf4 *>(xb + xi[b] + (unsigned)(16 * j)) = o;
                     }
                 }
             }
             __syncthreads();
         }
         // ---- X interior -> output
-        {
+        if (!(a.dbg & 16)) {
             __bf16 *dst = a.out + (size_t)n * P * C;
 #pragma unroll
             for (int k = 0; k < NIT; k++) {
                 const int q = prow + PSTEP * k;
-                if (q < P) *reinterpret_cast<u4v *>(dst + (size_t)q * C + cg * 8) = *reinterpret_cast<const u4v *>(xb + xo[k] + ctr);
+                if (q < P) *reinterpret_cast<u4v *>(dst + (size_t)q * C + cg * 8) = *reinterpret_cast<const u4v *>(xb + xint(q) + cg * 16);
             }
         }
     }
@@ -229,6 +274,7 @@ int mbn_launch_bf16_res_blocks(mbn_context *ctx, hipStream_t stream, void *out, 
     ResArgs a;
     a.out = (__bf16 *)out; a.in = (const __bf16 *)in;
     a.batch = batch; a.h = rows; a.w = cols; a.nblk = nblocks;
+    a.dbg = g_mbn_tune.exp0 >= 900 ? g_mbn_tune.exp0 - 900 : 0;
     for (int i = 0; i < nblocks; i++) {
         const mbn_block_params &b = blocks[i];
         const void *ptrs[] = { b.wd, b.s2, b.b2, b.wp_bf16, b.s3, b.b3 };

@@ -11,6 +11,7 @@ ap.add_argument("--batch", type=int, default=512)
 ap.add_argument("--reps", type=int, default=30)
 ap.add_argument("--blocks", type=int, default=5)
 ap.add_argument("--side", type=int, default=10)
+ap.add_argument("--tune", action="append", default=[])
 args = ap.parse_args()
 pkg = import_package(); lib = pkg.load(); ctx = pkg.Context(0)
 n, h, c, nb = args.batch, args.side, 256, args.blocks
@@ -29,7 +30,11 @@ for i, d in enumerate(dev):
     arr[i].wd, arr[i].s2, arr[i].b2, arr[i].wp_bf16, arr[i].s3, arr[i].b3 = (t.ptr for t in d)
 d_o, d_p, d_q = ctx.alloc(x.size * 2), ctx.alloc(x.size * 2), ctx.alloc(x.size * 2)
 def resident():
+    for kv in args.tune:
+        lib.mbn_tune_set(kv.split("=")[0].encode(), int(kv.split("=")[1]))
     assert lib.mbn_blocks_resident_bf16(ctx.h, d_o.ptr, d_x.ptr, arr, nb, n, h, h, c, None) == 0
+    for kv in args.tune:
+        lib.mbn_tune_set(kv.split("=")[0].encode(), 0)
 def one_by_one():
     src, dst = d_x, d_p
     for d in dev:
