@@ -102,13 +102,13 @@ def stage_table(plan, pkg, launches, layer_ms, batch, act_bytes, mfma_peak):
         return fl, by
     kind_name = {pkg.L_CONV: "conv1", pkg.L_DW: "depthwise", pkg.L_PW: "pointwise", pkg.L_POOL: "pool", pkg.L_FC: "fc"}
     stage_of = ["stem_fused" if len(idx) == 3 else "tail_fused" if len(idx) == 2 and plan.layer[idx[0]].kind == pkg.L_POOL else
-                "block_fused" if len(idx) == 2 else kind_name[plan.layer[idx[0]].kind] for idx in launches]
+                "block_fused" if len(idx) == 2 else "blocks_resident" if len(idx) > 3 else kind_name[plan.layer[idx[0]].kind] for idx in launches]
     stages, per_layer = {}, []
     for j, idx in enumerate(launches):
         f, b = launch_work(idx)
         per_layer.append({"layers": [i + 1 for i in idx], "stage": stage_of[j], "ms": round(float(layer_ms[j]), 5),
                           "GBps": round(b / layer_ms[j] / 1e6, 1), "TFLOPs": round(f / layer_ms[j] / 1e9, 2)})
-    for name in ["stem_fused", "block_fused", "conv1", "depthwise", "pointwise", "pool", "fc", "tail_fused"]:
+    for name in ["stem_fused", "block_fused", "blocks_resident", "conv1", "depthwise", "pointwise", "pool", "fc", "tail_fused"]:
         js = [j for j in range(len(launches)) if stage_of[j] == name]
         if not js:
             continue
@@ -239,6 +239,7 @@ def parse_args(argv=None):
                          "configs are measured in the same process — configs[4] (bf16 1.0x224 and 0.5x160, batch 512) and configs[1] (batch 1)")
     ap.add_argument("--no-fuse-stem", action="store_true", help="run layers 1-3 as three launches instead of mbn_stem_fused")
     ap.add_argument("--fuse-tail", action="store_true", help="1...4 images: pool and FC as one launch (mbn_pool_fc; off by default: measured slower)")
+    ap.add_argument("--no-fuse-resident", action="store_true", help="bf16: the runs of equal small-map blocks (layers 14-23 at 0.5x160) as one fused launch per block instead of one resident launch (A/B)")
     ap.add_argument("--fuse-blocks", type=lambda v: int(v, 0), default=None,
                     help="mask for mbn_net_set_fuse_blocks (bit L = fuse depthwise layer L with pointwise L+1); default: library's")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -485,6 +486,8 @@ def run_one(args, env):
         net.set_fuse_stem(False)
     if args.fuse_tail:
         net.set_fuse_tail(True)
+    if args.no_fuse_resident:
+        net.set_fuse_resident(False)
     if args.fuse_blocks is not None:
         net.set_fuse_blocks(args.fuse_blocks)
     if args.graph:

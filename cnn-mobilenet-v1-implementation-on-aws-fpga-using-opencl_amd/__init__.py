@@ -202,6 +202,7 @@ def load():
         lib.mbn_stem_fused_u8.argtypes = [vp] + [vp] * 11 + [ci, ci, ci, ci, vp]
         lib.mbn_stem_fused_ex.argtypes = [vp] + [vp] * 11 + [ci, ci, ci, ci, ci, vp]
         lib.mbn_net_set_input_u8.argtypes = [vp, ci]
+        lib.mbn_net_set_fuse_resident.argtypes = [vp, ci]
         lib.mbn_dwpw_fused.argtypes = [vp] + [vp] * 8 + [ci] * 10 + [vp]
         lib.mbn_dwpw_fused_bf16.argtypes = [vp] + [vp] * 8 + [ci] * 10 + [vp]
         lib.mbn_blocks_resident_bf16.argtypes = [vp, vp, vp, C.POINTER(BlockParams), ci, ci, ci, ci, ci, vp]
@@ -495,6 +496,10 @@ class Net:
 
     def set_fuse_tail(self, enabled=True):
         _chk(self.ctx.lib.mbn_net_set_fuse_tail(self.h, int(enabled)))
+
+    def set_fuse_resident(self, enabled=True):
+        """Runs of equal small-map bf16 blocks as one launch with the map resident in LDS (default on)."""
+        _chk(self.ctx.lib.mbn_net_set_fuse_resident(self.h, int(enabled)))
 
     def get_fuse_blocks(self) -> int:
         m = C.c_uint()

@@ -48,6 +48,7 @@ struct mbn_net {
     void *poolfc_ws;           /* workspace of mbn_pool_fc (1...4 images: pool + FC in one launch), allocated and zeroed at creation */
     size_t poolfc_ws_bytes;
     int fuse_tail;             /* mbn_net_set_fuse_tail (default 0) */
+    int fuse_resident;         /* mbn_net_set_fuse_resident (default 1): runs of equal bf16 blocks on a small map as one launch, the map resident in LDS */
     void *last_out[MBN_MAX_LAYERS];
 };
 
@@ -75,6 +76,7 @@ static int net_alloc_common(mbn_context *ctx, const mbn_plan *plan, int max_batc
     int rc = mbn_alloc(ctx, bytes, &net->act[0]);
     if (rc == MBN_OK) rc = mbn_alloc(ctx, bytes, &net->act[1]);
     net->fuse_tail = 0;            /* measured slower than the two launches (mbn.h: mbn_net_set_fuse_tail): opt-in */
+    net->fuse_resident = 1;
     if (rc == MBN_OK && plan->n_layers >= 2 && plan->layer[plan->n_layers - 2].kind == MBN_L_POOL &&
         plan->layer[plan->n_layers - 1].kind == MBN_L_FC) {
         const mbn_layer_desc *fc = &plan->layer[plan->n_layers - 1];
@@ -264,6 +266,24 @@ static int block_fusable(const mbn_net *net, int i, int count, int last_layer)
     return 1;
 }
 
+/* Blocks starting at layer index i (0-based; depthwise, pointwise, depthwise, ...) that can run as ONE launch with the map resident in LDS
+ * (mbn_blocks_resident_bf16, round 6): bf16, each of them fusable under the mask in force, stride 1 with pad 1, 256 channels in and out, equal small maps.
+ * Returns the number of blocks (2 ... 8) or 0. The five 256 -> 256 blocks on the 10 x 10 map of the 0.5x160 network (layers 14-23). */
+static int resident_run(const mbn_net *net, int i, int count, int last_layer)
+{
+    if (net->dtype != MBN_DT_BF16 || !net->fuse_resident || net->keep) return 0;
+    int k = 0;
+    while (k < 8 && block_fusable(net, i + 2 * k, count, last_layer)) {
+        const mbn_layer_desc *d = &net->plan.layer[i + 2 * k], *p = &net->plan.layer[i + 2 * k + 1], *d0 = &net->plan.layer[i];
+        if (d->stride != 1 || d->pad_top != 1 || d->pad_left != 1 || d->in_ch != 256 || p->out_ch != 256 || d->out_rows != d->in_rows ||
+            d->out_cols != d->in_cols || d->in_rows != d0->in_rows || d->in_cols != d0->in_cols || d->in_rows * d->in_cols > 128 ||
+            (d->in_rows + 2) * (d->in_cols + 2) > 144)
+            break;
+        k++;
+    }
+    return k >= 2 ? k : 0;
+}
+
 /* layers i+1 (pool) and i+2 (FC), 0-based index i, as one launch: fp32, 1...4 images, nothing kept, the last two layers of the call */
 static int tail_fusable(const mbn_net *net, int i, int count, int last_layer)
 {
@@ -309,6 +329,14 @@ int mbn_net_set_fuse_tail(mbn_net *net, int enabled)
     return MBN_OK;
 }
 
+int mbn_net_set_fuse_resident(mbn_net *net, int enabled)
+{
+    if (!net) return MBN_EINVAL;
+    if (net->fuse_resident != (enabled != 0)) drop_graph(net);
+    net->fuse_resident = enabled != 0;
+    return MBN_OK;
+}
+
 int mbn_net_reset_fuse_blocks(mbn_net *net)
 {
     if (!net) return MBN_EINVAL;
@@ -336,6 +364,7 @@ int mbn_net_launches(const mbn_net *net, int batch, int last_layer, int *first_l
     while (i < last_layer) {
         int span = 1;
         if (i == 0 && stem_fusable(net, last_layer)) span = 3;
+        else if (resident_run(net, i, sub, last_layer)) span = 2 * resident_run(net, i, sub, last_layer);
         else if (block_fusable(net, i, sub, last_layer)) span = 2;
         else if (tail_fusable(net, i, sub, last_layer)) span = 2;
         if (first_layer && n_layers && n < capacity) { first_layer[n] = i + 1; n_layers[n] = span; }
@@ -464,6 +493,36 @@ static int forward_range(mbn_net *net, const void *images, void *logits, int fir
     }
     for (int i = i0; i < last_layer; i++) {
         const mbn_layer_desc *l = &net->plan.layer[i];
+        const int rr = layer_ms ? 0 : resident_run(net, i, count, last_layer);
+        if (rr) {
+            /* rr blocks in one launch, the map resident in LDS from the first block's input to the last block's output */
+            mbn_block_params bp[8];
+            for (int k = 0; k < rr; k++) {
+                const mbn_layer_desc *d = &net->plan.layer[i + 2 * k], *p = &net->plan.layer[i + 2 * k + 1];
+                bp[k].wd = blob_at(net, d->w_offset); bp[k].s2 = blob_at(net, d->scale_offset); bp[k].b2 = blob_at(net, d->shift_offset);
+                bp[k].wp_bf16 = net->bf16_filt[i + 2 * k + 1]; bp[k].s3 = blob_at(net, p->scale_offset); bp[k].b3 = blob_at(net, p->shift_offset);
+            }
+            const int lastl = i + 2 * rr - 1;                      /* index of the run's last (pointwise) layer */
+            const mbn_layer_desc *lp = &net->plan.layer[lastl];
+            const size_t per_img2 = (size_t)lp->out_rows * lp->out_cols * lp->out_ch * 2;
+            char *dst2 = (lastl == last_layer - 1) ? (char *)logits + (size_t)first * per_img2 : (char *)net->act[which] + slot;
+            int rc = mbn_blocks_resident_bf16(net->ctx, dst2, src, bp, rr, count, l->in_rows, l->in_cols, l->in_ch, stream);
+            if (rc == MBN_OK) {
+                if (lastl != last_layer - 1) which ^= 1;
+                if (first == 0) {
+                    for (int k = i; k < lastl; k++) net->last_out[k] = NULL;
+                    net->last_out[lastl] = dst2;
+                }
+                src = dst2;
+                if (next_stream && stagger > i && stagger <= lastl + 1) {
+                    rc = mbn_stream_wait(net->ctx, next_stream, stream);
+                    if (rc != MBN_OK) return rc;
+                }
+                i = lastl;
+                continue;
+            }
+            if (rc != MBN_EUNSUPPORTED) return rc;
+        }
         if (!layer_ms && block_fusable(net, i, count, last_layer)) {
             /* depthwise + pointwise in one kernel; the depthwise output stays in LDS */
             const mbn_layer_desc *lp = &net->plan.layer[i + 1];

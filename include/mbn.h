@@ -505,6 +505,10 @@ int  mbn_net_reset_fuse_blocks(mbn_net *net);
  * a forward of one image 0.1371 against 0.1348 ms (profiles/r03/p_pool_fc_one_launch.txt). The pooled values are identical either
  * way; the FC sums in another (fixed) order. */
 int  mbn_net_set_fuse_tail(mbn_net *net, int enabled);
+/* Runs of equal bf16 blocks on a small map (256 channels, stride 1, at most 128 pixels: the five 10 x 10 blocks of the 0.5x160 network) as ONE launch with
+ * the map resident in LDS (mbn_blocks_resident_bf16). Default 1; 0 = one fused launch per block as before round 6. bf16 mode only; logits within the
+ * bf16 tolerance either way (the per-block arithmetic is the same). */
+int  mbn_net_set_fuse_resident(mbn_net *net, int enabled);
 /* The launches the next forward(batch, last_layer) issues per (sub-)batch: launch j covers n_layers[j] layers starting
  * at the 1-based layer first_layer[j] (3 = fused stem, 2 = fused block or fused pool + FC, 1 = single layer). *count = number of
  * launches; the arrays (may be NULL) receive at most `capacity` entries. */

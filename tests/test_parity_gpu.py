@@ -1886,6 +1886,19 @@ def test_headline_bf16_batch512_vs_oracle(pkg, orc, ctx, tmp_path, cfg):
     net.forward(d_in.ptr, d_small.ptr, 16)
     ctx.sync()
     assert np.array_equal(d_small.download((16, 1000), np.float32), got[:16])
+    # round 6: at 0.5x160 the five 256 -> 256 blocks on the 10 x 10 map (layers 14-23) are ONE launch with the map resident in LDS (mbn_blocks_resident_bf16);
+    # switched off they are five fused launches again, and the logits are the same bits (each block's arithmetic is the same)
+    spans = [c for _, c in net.launches(n)]
+    if alpha == 0.5:
+        assert 10 in spans, spans
+        net.set_fuse_resident(False)
+        assert 10 not in [c for _, c in net.launches(n)]
+        net.forward(d_in.ptr, d_out.ptr, n)
+        ctx.sync()
+        assert np.array_equal(d_out.download((n, 1000), np.float32), got)
+        net.set_fuse_resident(True)
+    else:
+        assert max(spans) <= 3, spans
     net.destroy()
 
 
