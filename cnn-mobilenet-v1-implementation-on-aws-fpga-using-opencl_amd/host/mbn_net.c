@@ -276,7 +276,7 @@ static int resident_run(const mbn_net *net, int i, int count, int last_layer)
     while (k < 8 && block_fusable(net, i + 2 * k, count, last_layer)) {
         const mbn_layer_desc *d = &net->plan.layer[i + 2 * k], *p = &net->plan.layer[i + 2 * k + 1], *d0 = &net->plan.layer[i];
         if (d->stride != 1 || d->pad_top != 1 || d->pad_left != 1 || d->in_ch != 256 || p->out_ch != 256 || d->out_rows != d->in_rows ||
-            d->out_cols != d->in_cols || d->in_rows != d0->in_rows || d->in_cols != d0->in_cols || d->in_rows * d->in_cols > 128 ||
+            d->out_cols != d->in_cols || d->in_rows != d0->in_rows || d->in_cols != d0->in_cols || d->in_rows * d->in_cols > 104 ||
             (d->in_rows + 2) * (d->in_cols + 2) > 144)
             break;
         k++;

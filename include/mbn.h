@@ -283,7 +283,7 @@ int mbn_dwpw_fused(mbn_context *ctx, void *out, const void *in, const void *wd, 
  * rows x cols map, each stage followed by its folded-BN scale/shift and ReLU6, in ONE launch: an image's map stays in LDS from the first block's input to
  * the last block's output, only the filters come from memory. in / out: bf16 NHWC [batch][rows][cols][channels]; per block: wd [3][3][channels],
  * s2, b2 [channels] fp32, wp_bf16 [channels][channels] bf16, s3, b3 [channels] fp32, as in mbn_dwpw_fused_bf16. Same arithmetic as the separate bf16
- * launches within the bf16 tolerance. Returns MBN_EUNSUPPORTED unless channels == 256, rows * cols <= 128, (rows + 2) * (cols + 2) <= 144 and
+ * launches within the bf16 tolerance. Returns MBN_EUNSUPPORTED unless channels == 256, rows * cols <= 104, (rows + 2) * (cols + 2) <= 144 and
  * 1 <= nblocks <= 8 (the five 256 -> 256 blocks on the 10 x 10 map of the 0.5x160 network) — callers then issue the blocks one by one. */
 typedef struct mbn_block_params {
     const void *wd, *s2, *b2;       /* depthwise filter, scale, shift (fp32) */
@@ -505,7 +505,7 @@ int  mbn_net_reset_fuse_blocks(mbn_net *net);
  * a forward of one image 0.1371 against 0.1348 ms (profiles/r03/p_pool_fc_one_launch.txt). The pooled values are identical either
  * way; the FC sums in another (fixed) order. */
 int  mbn_net_set_fuse_tail(mbn_net *net, int enabled);
-/* Runs of equal bf16 blocks on a small map (256 channels, stride 1, at most 128 pixels: the five 10 x 10 blocks of the 0.5x160 network) as ONE launch with
+/* Runs of equal bf16 blocks on a small map (256 channels, stride 1, at most 10 x 10 pixels: the five 10 x 10 blocks of the 0.5x160 network) as ONE launch with
  * the map resident in LDS (mbn_blocks_resident_bf16). Default 1; 0 = one fused launch per block as before round 6. bf16 mode only; logits within the
  * bf16 tolerance either way (the per-block arithmetic is the same). */
 int  mbn_net_set_fuse_resident(mbn_net *net, int enabled);
