@@ -4,7 +4,7 @@ set -o pipefail
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 O=gpurun_out/r06w; mkdir -p $O
 timeout -k 10 300 python3 tools/res_bench.py | tee $O/res_bench.txt || exit 1
-for bits in 1 2 8; do
+for bits in 1 2 4 8 16 3 11 15; do
   echo -n "dbg $bits: "; MBN_LAB=1 timeout -k 10 120 python3 tools/res_bench.py --tune exp0=$((900+bits)) | tail -n 1 || exit 1
 done | tee $O/res_ablate.txt
 for rep in 1 2; do
