@@ -635,13 +635,20 @@ int mbn_launch_f32_pointwise(const mbn_call &c, void *out, const void *in, const
         }
     }
 #endif
+#ifdef MBN_LAB
+    // LAB ONLY (round 6; measured equal to slower than the M16 streaming form below: layer 15 0.060-0.065 against 0.063 ms, layer 25 0.039 against 0.035,
+    // profiles/r06/u_*): K = 512 with the filter in registers for the whole launch (mbn_bf16_pw_rf.hip), only the activations pass the LDS. Same bits as the
+    // M16 streaming form. pw_ring = 8 selects it wherever eligible.
+    if (bf && ring_mode == 8 && g_mbn_tune.pw_tile == 0 && mbn_launch_bf16_pw_rf(c, out, in, filt, m, cin, op_size) == MBN_OK)
+        return MBN_OK;
+#endif
     // K >= 256: the streaming kernel with its products on v_mfma_f32_16x16x32_bf16 — the shape the chip holds a 16 % higher clock under: layers 15 / 25 / 27 at
     // batch 512 -4.6 % / -3.5 % / -10.7 % against pw_gemm<bf16> (profiles/r03/x_bf16_mfma_shape.txt). It sums 32 products per instruction, so its bits are
     // not those of the 32x32x16 kernels: it is taken for these layers at EVERY M (the choice depends on K and N alone), which keeps an image's result
     // independent of the batch. Round 4 (profiles/r04/c_bf16_mfma_shape_pointwise.txt, batch 512): K = 256 joins — 1.0x224 layer 13 0.0368 (pw_gemm) -> 0.0363 ms,
     // 0.5x160 layers 15-23 (256 -> 256) 0.0191 (32x32x16 streaming form) -> 0.0173, layer 25 (256 -> 512) 0.0122 (pw_gemm) -> 0.0108; for K <= 128 the 16x16x32
     // form is 4-16 % SLOWER than the 32x32x16 streaming form (two k-groups of 32 leave a 64-deep k-tile nothing to overlap) and stays off. Lab: pw_ring = 1 never.
-    if (bf && ring_mode == 0 && cin >= 256 && g_mbn_tune.pw_tile == 0 && mbn_launch_bf16_pw_stream(c, out, in, filt, m, cin, op_size, true) == MBN_OK)
+    if (bf && (ring_mode == 0 || ring_mode == 5 || ring_mode == 8) && cin >= 256 && g_mbn_tune.pw_tile == 0 && mbn_launch_bf16_pw_stream(c, out, in, filt, m, cin, op_size, true) == MBN_OK)
         return MBN_OK;
     // measured per layer at batch 512 (profiles/r03/b_bf16_stream_gemm.txt, same call, against pw_gemm<bf16>): K = 64 0.179 -> 0.116 ms,
     // K = 128 0.080 -> 0.076, K = 256 with N = 256 0.114 -> 0.100; K = 256 with N = 512 and every K >= 512 layer 0-5 % SLOWER (there the

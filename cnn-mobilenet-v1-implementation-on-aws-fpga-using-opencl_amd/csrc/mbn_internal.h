@@ -142,6 +142,7 @@ int mbn_launch_bf16_pw_ring(const mbn_call &c, void *out, const void *in, const 
 int mbn_launch_bf16_pw_wide(const mbn_call &c, void *out, const void *in, const void *fpk, long m, int cin, int op_size);
 int mbn_launch_pack_filter_bf16(mbn_context *ctx, hipStream_t s, void *dst, const void *src, int n, int k);
 int mbn_bf16_pw_wide_eligible(long m, int cin, int op_size);
+int mbn_launch_bf16_pw_rf(const mbn_call &c, void *out, const void *in, const void *filt, long m, int cin, int op_size);          // lab build only (round 6): K = 512, filter in registers
 int mbn_launch_bf16_pw_stream(const mbn_call &c, void *out, const void *in, const void *filt, long m, int cin, int op_size, bool m16 = false);
 int mbn_launch_bf16_pw_big(const mbn_call &c, void *out, const void *in, const void *filt, long m, int cin, int op_size, long *rows_done);
 int mbn_launch_f32_pool(const mbn_call &c, void *out, const void *in, int rows, int cols, int fs, int channels);

@@ -2292,6 +2292,62 @@ def test_bf16_pointwise_stream_kernel_on_16x16x32_mfma(pkg, orc, ctx, shape):
             b.free()
 
 
+@pytest.mark.parametrize("shape", [(100352, 512, 512), (25088 + 5, 512, 1024), (31, 512, 256), (32 * 8 * 16 * 3 + 1, 512, 512), (7 * 32 + 3, 512, 768),
+                                   (2 * 196, 512, 512), (65536 + 33, 512, 256)])
+def test_bf16_pointwise_register_filter_kernel(pkg, orc, ctx, shape):
+    """mbn_bf16_pw_rf.hip (round 6): K = 512 with the wave's filter rows in registers for the whole launch and only the activations through a four-stage
+    LDS ring (one LDS-DMA per pixel row, counted vmcnt, out-of-range dummy DMA past the end). Against the oracle's bf16 emulation (sampled rows on the big
+    shapes: first and last tiles included), no store past the output (ragged last tile: rows past M are dropped by the buffer range), repeatable, exact
+    small integers through an asymmetric filter (A / B lane maps k = 32 g + 8 q, the 16 x 16 C/D map, every channel slice: N / 256 = 1, 2, 3, 4), fewer tiles
+    than pixel streams, tile counts that end on every stage of the ring — and bit for bit the M16 streaming kernel it replaces on these layers (same
+    instruction, same k order; pw_ring = 8 selects it, 5 the streaming kernel). LAB build only: measured equal to slower, not in the shipped library."""
+    _tune_lab(ctx, b"pw_ring", 8)          # lab build only (skips on the shipped library): the kernel is measured, not taken
+    m, cin, cout = shape
+    rng = np.random.default_rng(m + cin + cout)
+    x = orc.bf16_round(rng.uniform(-1, 1, (m, cin)))
+    f = orc.bf16_round(rng.normal(0, (2.0 / cin) ** 0.5, (cout, cin)))
+    sc, sh = rng.uniform(0.5, 1.5, cout).astype(np.float32), rng.normal(0, 0.1, cout).astype(np.float32)
+    d_x, d_f, d_sc, d_sh = _bf16_dev(pkg, ctx, x), _bf16_dev(pkg, ctx, f), ctx.to_device(sc), ctx.to_device(sh)
+    d_o = ctx.alloc(m * cout * 2 + 64)
+    ext = pkg.make_ext(dtype=pkg.DT_BF16, act=2, scale=d_sc.ptr, shift=d_sh.ptr)
+    try:
+        ctx.lib.mbn_memset(ctx.h, d_o.ptr, 0xFF, m * cout * 2 + 64)
+        ctx.pointwise(d_o.ptr, d_x.ptr, d_f.ptr, m, 1, cin, cout, ext)
+        ctx.sync()
+        raw = d_o.download((m * cout + 32,), np.uint16)
+        assert np.all(raw[m * cout:] == 0xFFFF), "stores past the output"
+        got = _bf16_get(pkg, d_o, (m, cout))
+        rows = np.arange(m) if m * cin * cout <= 2e9 else np.unique(np.concatenate([np.arange(0, 300), np.arange(m - 300, m), rng.integers(0, m, 1500)]))
+        assert_close(got[rows], orc.bf16_round(orc.f32_pointwise(x[rows], f, sc, sh, 2)), TOL_BF16, "register filter %s vs oracle" % (shape,))
+        ctx.pointwise(d_o.ptr, d_x.ptr, d_f.ptr, m, 1, cin, cout, ext)
+        ctx.sync()
+        assert np.array_equal(got, _bf16_get(pkg, d_o, (m, cout))), "not repeatable"
+        if _lab(ctx):
+            assert ctx.lib.mbn_tune_set(b"pw_ring", 5) == 0      # the M16 streaming kernel these layers ran on before
+            ctx.pointwise(d_o.ptr, d_x.ptr, d_f.ptr, m, 1, cin, cout, ext)
+            ctx.sync()
+            ref = _bf16_get(pkg, d_o, (m, cout))
+            assert np.array_equal(got, ref), "not the streaming kernel's bits: %d of %d differ" % (int(np.sum(got != ref)), got.size)
+            assert ctx.lib.mbn_tune_set(b"pw_ring", 8) == 0
+        xi = rng.integers(-3, 4, (m, cin)).astype(np.float32)
+        fi = rng.integers(-2, 3, (cout, cin)).astype(np.float32)
+        fi[:, 0] = np.arange(cout) % 5
+        fi[:, cin - 1] = np.arange(cout) % 3
+        one, zero = ctx.to_device(np.ones(cout, np.float32)), ctx.to_device(np.zeros(cout, np.float32))
+        d_x.upload(pkg.f32_to_bf16_bits(xi)); d_f.upload(pkg.f32_to_bf16_bits(fi))
+        ctx.pointwise(d_o.ptr, d_x.ptr, d_f.ptr, m, 1, cin, cout, pkg.make_ext(dtype=pkg.DT_BF16, act=2, scale=one.ptr, shift=zero.ptr))
+        ctx.sync()
+        goti = _bf16_get(pkg, d_o, (m, cout))
+        for lo in (0, max(0, m - 4096)):
+            want = np.clip(xi[lo:lo + 4096].astype(np.float64) @ fi.astype(np.float64).T, 0, 6)
+            assert np.array_equal(goti[lo:lo + 4096].astype(np.float64), orc.bf16_round(want.astype(np.float32)).astype(np.float64)), "exact integers %s" % (shape,)
+        one.free(); zero.free()
+    finally:
+        ctx.lib.mbn_tune_set(b"pw_ring", 0)
+        for b in (d_x, d_f, d_sc, d_sh, d_o):
+            b.free()
+
+
 @pytest.mark.parametrize("shape", [(100352, 512, 512), (100352 + 77, 256, 512), (66000, 128, 256), (131072 + 300, 1024, 256), (40000, 512, 1024)])
 def test_bf16_pointwise_big_tile_kernel(pkg, orc, ctx, shape):
     """The 256 x 256 form of mbn_bf16_pw_stream.hip (16 waves, two LDS slots per operand, one workgroup per CU) for whole rounds of the
