@@ -219,7 +219,7 @@ def parse_args(argv=None):
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="storage type of activations and pointwise filters (arithmetic is fp32 either way)")
     ap.add_argument("--streams", type=int, default=0,
-                    help="0 (default) = 2 in fp32 at batch >= 64, 1 otherwise. n > 1: pipeline each step over n sub-batches on "
+                    help="0 (default) = 2 in fp32 at batch >= 64 and in bf16 for the big configurations (1.0x224 at batch 512), 1 otherwise. n > 1: pipeline each step over n sub-batches on "
                          "separate HIP streams (mbn_net_set_streams, bit-identical logits): the HBM-bound depthwise kernels of one "
                          "sub-batch overlap the MFMA-bound GEMMs of the other. The untimed steps whose kernels are timed one by one "
                          "(--profile-steps) run on ONE stream, so the per-kernel HIP-event durations behind `roofline` and "
@@ -255,7 +255,10 @@ def parse_args(argv=None):
     ap.add_argument("--record", default="", help="path of the full record (default: gpurun_out/bench_full_<workload>.json under the repo)")
     args = ap.parse_args(argv)
     if args.streams <= 0:
-        args.streams = 2 if (args.dtype == "f32" and args.batch >= 64 and not args.graph) else 1
+        # bf16 (round 6, profiles/r06/v_bf16_streams.txt): two streams +3.2 % at 1.0x224 batch 512 (282-284 k -> 291-293 k), equal at 0.5x160 (its step is
+        # 0.5 ms of short launches), three lose 8-20 %: two from 1e7 batch * alpha^2 * res^2 up (1.0x224 at batch 512: 2.6e7; 0.5x160: 3.3e6)
+        heavy = args.dtype == "f32" or args.batch * args.alpha * args.alpha * args.res * args.res >= 1e7
+        args.streams = 2 if (heavy and args.batch >= 64 and not args.graph) else 1
     args.profile_steps = max(1, args.profile_steps)
     return args
 
@@ -434,7 +437,7 @@ def configs_alt(args, env):
     carries [value, roofline frac, parity ok] of each, the side file all of it."""
     import copy
     res = {}
-    for name, kw in (("bf16_1.0x224_b512", dict(dtype="bf16", alpha=1.0, res=224, batch=512, streams=1)),
+    for name, kw in (("bf16_1.0x224_b512", dict(dtype="bf16", alpha=1.0, res=224, batch=512, streams=2)),
                      ("bf16_0.5x160_b512", dict(dtype="bf16", alpha=0.5, res=160, batch=512, streams=1)),
                      ("f32_1.0x224_b1", dict(dtype="f32", alpha=1.0, res=224, batch=1, streams=1))):
         a = copy.copy(args)
