@@ -1535,12 +1535,14 @@ def test_bf16_dwpw_fused(pkg, orc, ctx, shape):
     _bf16_dwpw_fused_body(pkg, orc, ctx, shape)
 
 
-@pytest.mark.parametrize("shape", [(3, 10, 10, 5), (600, 10, 10, 5), (2, 8, 8, 1), (5, 7, 9, 3), (1, 10, 10, 8), (4, 6, 6, 2)])
+@pytest.mark.parametrize("shape", [(3, 10, 10, 5), (600, 10, 10, 5), (2, 8, 8, 1), (5, 7, 9, 3), (1, 10, 10, 8), (4, 6, 6, 2), (3, 2, 16, 2), (2, 10, 9, 2), (2, 1, 1, 3),
+                                   (2, 6, 16, 2)])
 def test_bf16_blocks_resident(pkg, orc, ctx, shape):
     """Round 6: mbn_blocks_resident_bf16 (mbn_bf16_res.hip): a run of 256 -> 256 depthwise + pointwise blocks on a small map in one launch, the map
     resident in LDS — against the oracle's bf16 emulation of the chain (every layer output rounded to bf16) and against the same blocks issued one by
     one through mbn_dwpw_fused_bf16 (layers 14-23 of the 0.5x160 network: MobileNet.c:322-2599 pairs; kernel.cl:62-92 + 94-114). bf16 tolerance per
-    block, compounding over the run; odd map sides, one image per several passes of the grid (600 images > one workgroup per CU)."""
+    block, compounding over the run; odd map sides, one image per several passes of the grid (600 images > one workgroup per CU), wide short maps (16 columns: eight
+    column pairs, the quarter-row jobs of waves 4-7 on four of them), a single pixel, the widest bordered map that fits (8 x 18 = 144 pixels)."""
     n, h, w, nblk = shape
     c = 256
     rng = np.random.default_rng(n + 7 * h + 13 * w + nblk)
