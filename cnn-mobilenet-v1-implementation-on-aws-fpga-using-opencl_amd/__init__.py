@@ -206,6 +206,7 @@ def load():
         lib.mbn_dwpw_fused.argtypes = [vp] + [vp] * 8 + [ci] * 10 + [vp]
         lib.mbn_dwpw_fused_bf16.argtypes = [vp] + [vp] * 8 + [ci] * 10 + [vp]
         lib.mbn_blocks_resident_bf16.argtypes = [vp, vp, vp, C.POINTER(BlockParams), ci, ci, ci, ci, ci, vp]
+        lib.mbn_tail_resident_bf16.argtypes = [vp, vp, vp, C.POINTER(BlockParams), ci, ci, ci, ci, ci, vp]
         lib.mbn_softmax_topk_f32.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, vp]
         lib.mbn_classifier_tail.argtypes = [vp] * 9 + [ci] * 6 + [vp]
         lib.mbn_graph_begin.argtypes = [vp, vp]

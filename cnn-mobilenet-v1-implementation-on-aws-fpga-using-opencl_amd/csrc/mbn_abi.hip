@@ -896,6 +896,24 @@ int mbn_blocks_resident_bf16(mbn_context *ctx, void *out, const void *in, const 
     return sc.finish(mbn_launch_bf16_res_blocks(ctx, s, out, in, blocks, nblocks, batch, rows, cols, channels));
 }
 
+int mbn_tail_resident_bf16(mbn_context *ctx, void *out, const void *in, const mbn_block_params *blocks, int batch, int rows, int cols, int c0, int c1,
+                           void *stream)
+{
+    if (!ctx || !out || !in || !blocks || batch <= 0) return MBN_EINVAL;
+    if (!mbn_bf16_tail_eligible(rows, cols, c0, c1)) return MBN_EUNSUPPORTED;
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    MBN_SPANS(ctx, { in, 2.0 * batch * rows * cols * c0, "resident tail input" }, { out, 2.0 * batch * c1, "resident tail output" });
+    for (int i = 0; i < 2; i++) {
+        if (!blocks[i].wd || !blocks[i].s2 || !blocks[i].b2 || !blocks[i].wp_bf16 || !blocks[i].s3 || !blocks[i].b3) return MBN_EINVAL;
+        const int ci = i ? c1 : c0;
+        MBN_SPANS(ctx, { blocks[i].wd, 36.0 * ci, "resident tail depthwise filter" }, { blocks[i].wp_bf16, 2.0 * ci * c1, "resident tail pointwise filter" },
+                  { blocks[i].s2, 4.0 * ci, "resident tail scale" }, { blocks[i].b2, 4.0 * ci, "resident tail shift" },
+                  { blocks[i].s3, 4.0 * c1, "resident tail scale" }, { blocks[i].b3, 4.0 * c1, "resident tail shift" });
+    }
+    Scope sc(ctx, s);
+    return sc.finish(mbn_launch_bf16_tail(ctx, s, out, in, blocks, batch, rows, cols, c0, c1));
+}
+
 int mbn_dwpw_fused_bf16(mbn_context *ctx, void *out, const void *in, const void *wd, const void *s2, const void *b2,
                         const void *wp_bf16, const void *s3, const void *b3, int batch, int in_rows, int in_cols, int out_rows,
                         int out_cols, int cin, int cout, int stride, int pad_top, int pad_left, void *stream)

@@ -178,6 +178,8 @@ int mbn_launch_f32_dwpw2(mbn_context *ctx, hipStream_t stream, float *out, const
 int mbn_launch_f32_pw3(const mbn_call &c, float *out, const float *in, const float *filt, long m, int cin, int op_size);
 // a run of equal bf16 blocks with the activations resident in LDS (mbn_bf16_res.hip, round 6)
 int mbn_bf16_res_eligible(int rows, int cols, int channels, int nblocks);
+int mbn_bf16_tail_eligible(int rows, int cols, int c0, int c1);                      // round 6: the last two blocks + the pool in one launch (mbn_bf16_tail.hip)
+int mbn_launch_bf16_tail(mbn_context *ctx, hipStream_t stream, void *out, const void *in, const mbn_block_params *blocks, int batch, int rows, int cols, int c0, int c1);
 int mbn_launch_bf16_res_blocks(mbn_context *ctx, hipStream_t stream, void *out, const void *in, const mbn_block_params *blocks, int nblocks, int batch,
                                int rows, int cols, int channels);
 // wave-private form of the fp32 block (mbn_f32_dwpw3.hip, round 6): the default for stride-1 blocks with Cin >= 128 (blocks 6-7 and 10-11 of the

@@ -284,6 +284,30 @@ static int resident_run(const mbn_net *net, int i, int count, int last_layer)
     return k >= 2 ? k : 0;
 }
 
+/* Layers i+1 ... i+5 (0-based index i) are the network's last two blocks and the global pool in the shape mbn_tail_resident_bf16 takes (round 6): bf16, nothing
+ * kept, resident launches enabled, both blocks enabled in the mask in force; depthwise stride 2 without top / left padding on an even map of at most 10 x 10 x 256,
+ * pointwise 256 -> 512, depthwise stride 1 with pad 1, pointwise 512 -> 512, pool over the whole map (layers 24-28 of the 0.5x160 network). */
+static int tail_run(const mbn_net *net, int i, int count, int last_layer)
+{
+    (void)count;
+    if (net->dtype != MBN_DT_BF16 || !net->fuse_resident || net->keep || i + 5 > last_layer || i + 5 > net->plan.n_layers || i + 4 >= 32) return 0;
+    const mbn_layer_desc *d0 = &net->plan.layer[i], *p0 = &net->plan.layer[i + 1], *d1 = &net->plan.layer[i + 2], *p1 = &net->plan.layer[i + 3],
+                         *po = &net->plan.layer[i + 4];
+    if (d0->kind != MBN_L_DW || p0->kind != MBN_L_PW || d1->kind != MBN_L_DW || p1->kind != MBN_L_PW || po->kind != MBN_L_POOL) return 0;
+    if (!net->bf16_filt[i + 1] || !net->bf16_filt[i + 3]) return 0;
+    const unsigned mask = fuse_mask(net);
+    if (!((mask >> (i + 1)) & 1u) || !((mask >> (i + 3)) & 1u)) return 0;
+    if (((uintptr_t)net->dev_blob % 16) != 0) return 0;
+    if (d0->stride != 2 || d0->pad_top != 0 || d0->pad_left != 0 || d0->in_ch != 256 || p0->out_ch != 512 || (d0->in_rows & 1) || (d0->in_cols & 1) ||
+        d0->in_rows > 10 || d0->in_cols > 10 || d0->out_rows != d0->in_rows / 2 || d0->out_cols != d0->in_cols / 2)
+        return 0;
+    if (d1->stride != 1 || d1->pad_top != 1 || d1->pad_left != 1 || d1->in_ch != 512 || p1->out_ch != 512 || d1->out_rows != d0->out_rows ||
+        d1->out_cols != d0->out_cols)
+        return 0;
+    if (po->in_rows != d0->out_rows || po->in_cols != d0->out_cols || po->out_ch != 512) return 0;
+    return 1;
+}
+
 /* layers i+1 (pool) and i+2 (FC), 0-based index i, as one launch: fp32, 1...4 images, nothing kept, the last two layers of the call */
 static int tail_fusable(const mbn_net *net, int i, int count, int last_layer)
 {
@@ -365,6 +389,7 @@ int mbn_net_launches(const mbn_net *net, int batch, int last_layer, int *first_l
         int span = 1;
         if (i == 0 && stem_fusable(net, last_layer)) span = 3;
         else if (resident_run(net, i, sub, last_layer)) span = 2 * resident_run(net, i, sub, last_layer);
+        else if (tail_run(net, i, sub, last_layer)) span = 5;
         else if (block_fusable(net, i, sub, last_layer)) span = 2;
         else if (tail_fusable(net, i, sub, last_layer)) span = 2;
         if (first_layer && n_layers && n < capacity) { first_layer[n] = i + 1; n_layers[n] = span; }
@@ -507,6 +532,35 @@ static int forward_range(mbn_net *net, const void *images, void *logits, int fir
             const size_t per_img2 = (size_t)lp->out_rows * lp->out_cols * lp->out_ch * 2;
             char *dst2 = (lastl == last_layer - 1) ? (char *)logits + (size_t)first * per_img2 : (char *)net->act[which] + slot;
             int rc = mbn_blocks_resident_bf16(net->ctx, dst2, src, bp, rr, count, l->in_rows, l->in_cols, l->in_ch, stream);
+            if (rc == MBN_OK) {
+                if (lastl != last_layer - 1) which ^= 1;
+                if (first == 0) {
+                    for (int k = i; k < lastl; k++) net->last_out[k] = NULL;
+                    net->last_out[lastl] = dst2;
+                }
+                src = dst2;
+                if (next_stream && stagger > i && stagger <= lastl + 1) {
+                    rc = mbn_stream_wait(net->ctx, next_stream, stream);
+                    if (rc != MBN_OK) return rc;
+                }
+                i = lastl;
+                continue;
+            }
+            if (rc != MBN_EUNSUPPORTED) return rc;
+        }
+        if (!layer_ms && tail_run(net, i, count, last_layer)) {
+            /* the last two blocks and the pool in one launch, an image's maps resident in LDS */
+            mbn_block_params bp[2];
+            for (int k = 0; k < 2; k++) {
+                const mbn_layer_desc *d = &net->plan.layer[i + 2 * k], *p = &net->plan.layer[i + 2 * k + 1];
+                bp[k].wd = blob_at(net, d->w_offset); bp[k].s2 = blob_at(net, d->scale_offset); bp[k].b2 = blob_at(net, d->shift_offset);
+                bp[k].wp_bf16 = net->bf16_filt[i + 2 * k + 1]; bp[k].s3 = blob_at(net, p->scale_offset); bp[k].b3 = blob_at(net, p->shift_offset);
+            }
+            const int lastl = i + 4;                               /* the pool */
+            const mbn_layer_desc *lp = &net->plan.layer[lastl];
+            const size_t per_img2 = (size_t)lp->out_ch * 2;
+            char *dst2 = (lastl == last_layer - 1) ? (char *)logits + (size_t)first * per_img2 : (char *)net->act[which] + slot;
+            int rc = mbn_tail_resident_bf16(net->ctx, dst2, src, bp, count, l->in_rows, l->in_cols, l->in_ch, lp->out_ch, stream);
             if (rc == MBN_OK) {
                 if (lastl != last_layer - 1) which ^= 1;
                 if (first == 0) {

@@ -293,6 +293,17 @@ typedef struct mbn_block_params {
 int mbn_blocks_resident_bf16(mbn_context *ctx, void *out, const void *in, const mbn_block_params *blocks, int nblocks, int batch,
                              int rows, int cols, int channels, void *stream);
 
+/* The network's last two blocks and the global average pool in ONE launch with an image's maps resident on chip (round 6; bf16 mode): depthwise 3x3
+ * stride 2 on c0 channels -> pointwise c0 -> c1 -> depthwise 3x3 stride 1 -> pointwise c1 -> c1 -> average over the whole map (layers 24-28 of the
+ * sequence: MobileNet.c:322-2599 pairs + the `pool` launch :2601-2679; kernel.cl:62-92, 94-114, 116-132), every stage with its folded-BN scale / shift
+ * and ReLU6 and rounded to bf16 as the separate launches store it. in: bf16 NHWC [batch][rows][cols][c0]; out: bf16 [batch][c1] (what mbn_pool writes:
+ * the FC layer's input); blocks[0] / blocks[1]: the parameters of the two blocks as in mbn_dwpw_fused_bf16 (blocks[0].wp_bf16 is [c1][c0]).
+ * Same arithmetic as the five separate bf16 launches within the bf16 tolerance (depthwise sums and the pool's sum bit for bit; the pointwise sums
+ * group their products by 16 instead of 32). Returns MBN_EUNSUPPORTED unless c0 == 256, c1 == 512 and rows, cols are even and <= 10 (the 0.5x160
+ * network: 10 x 10 x 256 -> 5 x 5 x 512 -> 512) — callers then issue the layers one by one. */
+int mbn_tail_resident_bf16(mbn_context *ctx, void *out, const void *in, const mbn_block_params *blocks, int batch, int rows, int cols, int c0, int c1,
+                           void *stream);
+
 /* Classifier tail on device, fp32 (replaces the host loop MobileNet.c:2771-2792):
  * probs[n][k] = softmax(logits[n][:]) and argmax[n] (0-based). probs or argmax may be NULL. */
 int mbn_softmax_f32(mbn_context *ctx, void *probs, void *argmax_i32, const void *logits, int batch,
@@ -506,8 +517,8 @@ int  mbn_net_reset_fuse_blocks(mbn_net *net);
  * way; the FC sums in another (fixed) order. */
 int  mbn_net_set_fuse_tail(mbn_net *net, int enabled);
 /* Runs of equal bf16 blocks on a small map (256 channels, stride 1, at most 10 x 10 pixels: the five 10 x 10 blocks of the 0.5x160 network) as ONE launch with
- * the map resident in LDS (mbn_blocks_resident_bf16). Default 1; 0 = one fused launch per block as before round 6. bf16 mode only; logits within the
- * bf16 tolerance either way (the per-block arithmetic is the same). */
+ * the map resident in LDS (mbn_blocks_resident_bf16), and the 0.5x160 network's last two blocks + pool as another (mbn_tail_resident_bf16). Default 1; 0 = one fused
+ * launch per block / one launch per layer as before round 6. bf16 mode only; logits within the bf16 tolerance either way (the arithmetic is the same). */
 int  mbn_net_set_fuse_resident(mbn_net *net, int enabled);
 /* The launches the next forward(batch, last_layer) issues per (sub-)batch: launch j covers n_layers[j] layers starting
  * at the 1-based layer first_layer[j] (3 = fused stem, 2 = fused block or fused pool + FC, 1 = single layer). *count = number of

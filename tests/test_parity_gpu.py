@@ -1593,6 +1593,84 @@ def test_bf16_blocks_resident(pkg, orc, ctx, shape):
     assert ctx.lib.mbn_blocks_resident_bf16(ctx.h, d_o.ptr, d_x.ptr, arr, nblk, n, h, w, 128, None) == pkg.EUNSUPPORTED
 
 
+@pytest.mark.parametrize("shape", [(3, 10, 10), (600, 10, 10), (2, 8, 8), (5, 6, 10), (1, 2, 2), (4, 10, 4)])
+def test_bf16_tail_resident(pkg, orc, ctx, shape):
+    """Round 6: mbn_tail_resident_bf16 (mbn_bf16_tail.hip): depthwise stride 2 (256 ch) -> pointwise 256 -> 512 -> depthwise stride 1 -> pointwise 512 -> 512 ->
+    global average pool in one launch, an image's maps resident in LDS (layers 24-28 of the 0.5x160 network: MobileNet.c:322-2599 pairs + the pool launch
+    :2601-2679; kernel.cl:62-92, 94-114, 116-132) — against the oracle's bf16 emulation of the five layers (every layer output rounded to bf16) and against the
+    same five layers issued one by one through mbn_depthwise / mbn_pointwise / mbn_pool. bf16 tolerance compounding over the four conv layers; ragged
+    batches (600 images > one workgroup per CU), non-square and tiny maps; nothing stored past the output; outside the envelope MBN_EUNSUPPORTED."""
+    n, h, w = shape
+    c0, c1 = 256, 512
+    h1, w1 = h // 2, w // 2
+    rng = np.random.default_rng(n + 7 * h + 13 * w)
+    x = orc.bf16_round(rng.uniform(0, 4, (n, h, w, c0)).astype(np.float32))
+    P = []
+    for ci in (c0, c1):
+        wd = rng.normal(0, 0.5, (3, 3, ci)).astype(np.float32)
+        wp = orc.bf16_round(rng.normal(0, (2.0 / ci) ** 0.5, (c1, ci)).astype(np.float32))
+        s2, s3 = rng.uniform(0.5, 1.5, ci).astype(np.float32), rng.uniform(0.5, 1.5, c1).astype(np.float32)
+        b2, b3 = rng.normal(0, 0.1, ci).astype(np.float32), rng.normal(0, 0.1, c1).astype(np.float32)
+        P.append((wd, s2, b2, wp, s3, b3))
+    dev = [[ctx.to_device(p[0]), ctx.to_device(p[1]), ctx.to_device(p[2]), _bf16_dev(pkg, ctx, p[3]), ctx.to_device(p[4]), ctx.to_device(p[5])] for p in P]
+    sel = list(range(min(n, 3))) + ([n - 1] if n > 3 else [])
+    t = x[sel]
+    t = orc.bf16_round(orc.f32_depthwise(t, P[0][0], P[0][1], P[0][2], 2, 2, pad_top=0, pad_left=0))
+    assert t.shape[1:3] == (h1, w1)
+    t = orc.bf16_round(orc.f32_pointwise(t.reshape(-1, c0), P[0][3], P[0][4], P[0][5], 2).reshape(len(sel), h1, w1, c1))
+    t = orc.bf16_round(orc.f32_depthwise(t, P[1][0], P[1][1], P[1][2], 1, 2, pad_top=1, pad_left=1))
+    t = orc.bf16_round(orc.f32_pointwise(t.reshape(-1, c1), P[1][3], P[1][4], P[1][5], 2).reshape(len(sel), h1, w1, c1))
+    if h1 == w1:
+        want = orc.bf16_round(orc.f32_pool(t).reshape(len(sel), c1))
+    else:                                              # the oracle's pool window is square (kernel.cl:116-132): the whole-map mean by hand, same left-to-right fp32 sum
+        acc = np.zeros((len(sel), c1), np.float32)
+        for px in t.reshape(len(sel), h1 * w1, c1).transpose(1, 0, 2):
+            acc = (acc + px).astype(np.float32)
+        want = orc.bf16_round((acc / np.float32(h1 * w1)).astype(np.float32))
+    d_x = _bf16_dev(pkg, ctx, x)
+    d_o = ctx.alloc(n * c1 * 2 + 64)
+    ctx.lib.mbn_memset(ctx.h, d_o.ptr, 0xFF, n * c1 * 2 + 64)
+    arr = (pkg.BlockParams * 2)()
+    for i, d in enumerate(dev):
+        arr[i].wd, arr[i].s2, arr[i].b2, arr[i].wp_bf16, arr[i].s3, arr[i].b3 = (q.ptr for q in d)
+    rc = ctx.lib.mbn_tail_resident_bf16(ctx.h, d_o.ptr, d_x.ptr, arr, n, h, w, c0, c1, None)
+    assert rc == 0, rc
+    ctx.sync()
+    got = _bf16_get(pkg, d_o, (n, c1))
+    scale = max(float(np.abs(want).max()), 1e-3)
+    err = float(np.abs(got[sel] - want).max()) / scale
+    assert err <= TOL_BF16 * 2.5, "resident tail %s vs oracle: %g" % (shape, err)
+    tail = d_o.download((n * c1 + 32,), np.uint16)[n * c1:]
+    assert (tail == 0xFFFF).all(), "resident tail stored past the output"
+    # the same five layers one by one (square maps: mbn_pool's window is filtersize x filtersize)
+    d_a, d_b = ctx.alloc(n * h * w * c1 * 2), ctx.alloc(n * h * w * c1 * 2)
+    if h1 != w1:
+        for d in dev:
+            for q in d:
+                q.free()
+        for q in (d_x, d_o, d_a, d_b):
+            q.free()
+        return
+    e = lambda d, **kw: pkg.make_ext(batch=n, dtype=pkg.DT_BF16, act=2, scale=d[0].ptr, shift=d[1].ptr, **kw)
+    ctx.depthwise(d_a.ptr, d_x.ptr, dev[0][0].ptr, h1, w1, 3, 2, c0, e(dev[0][1:3], pad_top=0, pad_left=0, in_rows=h, in_cols=w))
+    ctx.pointwise(d_b.ptr, d_a.ptr, dev[0][3].ptr, h1, w1, c0, c1, e(dev[0][4:6]))
+    ctx.depthwise(d_a.ptr, d_b.ptr, dev[1][0].ptr, h1, w1, 3, 1, c1, e(dev[1][1:3], pad_top=1, pad_left=1, in_rows=h1, in_cols=w1))
+    ctx.pointwise(d_b.ptr, d_a.ptr, dev[1][3].ptr, h1, w1, c1, c1, e(dev[1][4:6]))
+    ctx.pool(d_a.ptr, d_b.ptr, h1, w1, h1, c1, pkg.make_ext(batch=n, dtype=pkg.DT_BF16, act=0))
+    ctx.sync()
+    ref = _bf16_get(pkg, d_a, (n, c1))
+    err2 = float(np.abs(got - ref).max()) / max(float(np.abs(ref).max()), 1e-3)
+    assert err2 <= TOL_BF16 * 2.5, "resident tail %s vs the five launches: %g" % (shape, err2)
+    assert ctx.lib.mbn_tail_resident_bf16(ctx.h, d_o.ptr, d_x.ptr, arr, n, 12, 12, c0, c1, None) == pkg.EUNSUPPORTED
+    assert ctx.lib.mbn_tail_resident_bf16(ctx.h, d_o.ptr, d_x.ptr, arr, n, 9, 10, c0, c1, None) == pkg.EUNSUPPORTED
+    assert ctx.lib.mbn_tail_resident_bf16(ctx.h, d_o.ptr, d_x.ptr, arr, n, h, w, 128, 256, None) == pkg.EUNSUPPORTED
+    for d in dev:
+        for q in d:
+            q.free()
+    for q in (d_x, d_o, d_a, d_b):
+        q.free()
+
+
 @pytest.mark.parametrize("shape", [(2, 112, 64, 128, 2), (2, 56, 128, 128, 1), (2, 56, 128, 256, 2), (2, 28, 256, 256, 1), (3, 14, 64, 128, 1)])
 def test_bf16_dwpw_fused_16x16x32_form(pkg, orc, ctx, shape):
     """LAB (misc = 32): the same block kernel with its pointwise products on v_mfma_f32_16x16x32_bf16 (round 4; measured equal to the shipped
@@ -1889,12 +1967,12 @@ def test_headline_bf16_batch512_vs_oracle(pkg, orc, ctx, tmp_path, cfg):
     ctx.sync()
     assert np.array_equal(d_small.download((16, 1000), np.float32), got[:16])
     # round 6: at 0.5x160 the five 256 -> 256 blocks on the 10 x 10 map (layers 14-23) are ONE launch with the map resident in LDS (mbn_blocks_resident_bf16);
-    # switched off they are five fused launches again, and the logits are the same bits (each block's arithmetic is the same)
+    # and layers 24-28 another (mbn_tail_resident_bf16); switched off they are launches per block / layer again, and the logits are the same bits (same arithmetic)
     spans = [c for _, c in net.launches(n)]
     if alpha == 0.5:
-        assert 10 in spans, spans
+        assert 10 in spans and spans[-2:] == [5, 1], spans            # ... and layers 24-28 (two blocks + the pool) one resident launch, then the FC layer
         net.set_fuse_resident(False)
-        assert 10 not in [c for _, c in net.launches(n)]
+        assert max(c for _, c in net.launches(n)) <= 3
         net.forward(d_in.ptr, d_out.ptr, n)
         ctx.sync()
         assert np.array_equal(d_out.download((n, 1000), np.float32), got)

@@ -147,6 +147,7 @@ if __name__ == "__main__":
         subprocess.check_call(["bash", os.path.join(ROOT, "tools", "isa.sh"), "mbn_f32_dwpw3"], stdout=subprocess.DEVNULL, env=env)
         subprocess.check_call(["bash", os.path.join(ROOT, "tools", "isa.sh"), "mbn_f32_pw3"], stdout=subprocess.DEVNULL, env=env)
         subprocess.check_call(["bash", os.path.join(ROOT, "tools", "isa.sh"), "mbn_bf16_res"], stdout=subprocess.DEVNULL, env=env)
+        subprocess.check_call(["bash", os.path.join(ROOT, "tools", "isa.sh"), "mbn_bf16_tail"], stdout=subprocess.DEVNULL, env=env)
     seen, bad = check(path)
     if len(sys.argv) <= 1:
         s2, b2 = check(os.path.join(tmp, "mbn_f32_dwpw2.s"), "dwpw2_f32", dwpw2_nst)
@@ -159,7 +160,8 @@ if __name__ == "__main__":
         print("%d bf16 fused block kernels with counted waits checked" % s3)
         bad += b3
         for f, st, loop_only in (("mbn_f32_dwpw2.s", "dwpw2_f32", False), ("mbn_bf16_dwpw2.s", "dwpw2_bf16", False), ("mbn_f32_dwpw3.s", "dwpw3_f32", True),
-                                  ("mbn_f32_pw3.s", "pw3_f32", True), ("mbn_bf16_res.s", "res_blocks_bf16", False)):
+                                  ("mbn_f32_pw3.s", "pw3_f32", True), ("mbn_bf16_res.s", "res_blocks_bf16", False),
+                                  ("mbn_bf16_tail.s", "tail_bf16", False)):
             s4, b4 = check_spills(os.path.join(tmp, f), st, loop_only)
             print("%d %s kernels checked for scratch use" % (s4, st))
             bad += b4

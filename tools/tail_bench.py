@@ -1,44 +1,56 @@
 #!/usr/bin/env python3
-"""Classifier tail (MobileNet.c:2601-2792) at 1...4 images: three launches (mbn_classifier_tail: pool, FC, softmax + top-k), two (mbn_pool_fc +
-mbn_softmax_topk_f32) and one (mbn_classifier_tail_fused). GPU time per tail = wall time of 2000 back-to-back tails on one stream / 2000."""
-import os
-import sys
-import time
+"""Layers 24-28 of the 0.5x160 network at batch 512 (bf16): one resident launch (mbn_tail_resident_bf16) against the five launches (depthwise, pointwise,
+depthwise, pointwise, pool), interleaved in one process; ms from the library's event pool.   usage: tail_bench.py [--batch 512] [--reps 30] [--side 10]"""
+import argparse, os, sys
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-from mbn_amd import import_package
-pkg = import_package()
-lib = pkg.load()
-rng = np.random.default_rng(3)
-ch, classes, h, k = 1024, 1000, 7, 5
-with pkg.Context(0) as ctx:
-    w = rng.normal(0, (1.0 / ch) ** 0.5, (classes, ch)).astype(np.float32)
-    b = rng.normal(0, 0.5, classes).astype(np.float32)
-    d_w, d_b = ctx.to_device(w), ctx.to_device(b)
-    nb = lib.mbn_pool_fc_workspace_bytes(ch, classes)
-    d_ws = ctx.alloc(nb)
-    lib.mbn_memset(ctx.h, d_ws.ptr, 0, nb)
-    print("#### tools/tail_bench.py: classifier tail, 7x7x1024 -> 1000 classes, top-5; microseconds of GPU time per tail (2000 back-to-back, one stream)")
-    for n in (1, 2, 4):
-        x = rng.uniform(0, 6, (n, h, h, ch)).astype(np.float32)
-        d_x = ctx.to_device(x)
-        d_lg, d_pool, d_p, d_i, d_v = ctx.alloc(n * classes * 4), ctx.alloc(n * ch * 4), ctx.alloc(n * classes * 4), ctx.alloc(n * 8 * 4), ctx.alloc(n * 8 * 4)
-        forms = {
-            "3 launches (pool, FC, softmax+top-k)": lambda: lib.mbn_classifier_tail(ctx.h, d_i.ptr, d_v.ptr, None, d_lg.ptr, d_pool.ptr, d_x.ptr, d_w.ptr, d_b.ptr, n, h, h, ch, classes, k, None),
-            "2 launches (pool+FC, softmax+top-k)": lambda: (lib.mbn_pool_fc(ctx.h, d_lg.ptr, d_x.ptr, d_w.ptr, d_b.ptr, n, h, h, ch, classes, d_ws.ptr, nb, None),
-                                                            lib.mbn_softmax_topk_f32(ctx.h, None, d_i.ptr, d_v.ptr, d_lg.ptr, n, classes, k, None)),
-            "1 launch (mbn_classifier_tail_fused)": lambda: lib.mbn_classifier_tail_fused(ctx.h, d_i.ptr, d_v.ptr, None, d_lg.ptr, d_x.ptr, d_w.ptr, d_b.ptr, n, h, h, ch, classes, k, d_ws.ptr, nb, None),
-        }
-        res = {}
-        for rep in range(3):
-            for name, fn in forms.items():
-                for _ in range(200):
-                    fn()
-                ctx.sync()
-                t0 = time.perf_counter()
-                for _ in range(2000):
-                    fn()
-                ctx.sync()
-                res.setdefault(name, []).append((time.perf_counter() - t0) / 2000 * 1e6)
-        for name, v in res.items():
-            print("  %d image(s)  %-40s %6.2f us  (runs: %s)" % (n, name, float(np.median(v)), " ".join("%.2f" % t for t in v)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from mbn_amd import import_package  # noqa: E402
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=512)
+ap.add_argument("--reps", type=int, default=30)
+ap.add_argument("--side", type=int, default=10)
+ap.add_argument("--tune", action="append", default=[])
+args = ap.parse_args()
+pkg = import_package(); lib = pkg.load(); ctx = pkg.Context(0)
+n, h, c0, c1 = args.batch, args.side, 256, 512
+h1 = h // 2
+rng = np.random.default_rng(0)
+x = rng.uniform(0, 4, (n, h, h, c0)).astype(np.float32)
+d_x = ctx.to_device(pkg.f32_to_bf16_bits(x))
+dev = []
+for ci in (c0, c1):
+    wd = rng.normal(0, 0.5, (3, 3, ci)).astype(np.float32)
+    wp = rng.normal(0, (2.0 / ci) ** 0.5, (c1, ci)).astype(np.float32)
+    s2, s3 = rng.uniform(0.5, 1.5, ci).astype(np.float32), rng.uniform(0.5, 1.5, c1).astype(np.float32)
+    b2, b3 = rng.normal(0, 0.1, ci).astype(np.float32), rng.normal(0, 0.1, c1).astype(np.float32)
+    dev.append([ctx.to_device(wd), ctx.to_device(s2), ctx.to_device(b2), ctx.to_device(pkg.f32_to_bf16_bits(wp)), ctx.to_device(s3), ctx.to_device(b3)])
+arr = (pkg.BlockParams * 2)()
+for i, d in enumerate(dev):
+    arr[i].wd, arr[i].s2, arr[i].b2, arr[i].wp_bf16, arr[i].s3, arr[i].b3 = (t.ptr for t in d)
+d_o, d_a, d_b = ctx.alloc(n * c1 * 2), ctx.alloc(n * h * h * c1 * 2), ctx.alloc(n * h * h * c1 * 2)
+e = lambda d, **kw: pkg.make_ext(batch=n, dtype=pkg.DT_BF16, act=2, scale=d[0].ptr, shift=d[1].ptr, **kw)
+def resident():
+    for kv in args.tune:
+        lib.mbn_tune_set(kv.split("=")[0].encode(), int(kv.split("=")[1]))
+    rc = lib.mbn_tail_resident_bf16(ctx.h, d_o.ptr, d_x.ptr, arr, n, h, h, c0, c1, None)
+    for kv in args.tune:
+        lib.mbn_tune_set(kv.split("=")[0].encode(), 0)
+    assert rc == 0
+def one_by_one():
+    ctx.depthwise(d_a.ptr, d_x.ptr, dev[0][0].ptr, h1, h1, 3, 2, c0, e(dev[0][1:3], pad_top=0, pad_left=0, in_rows=h, in_cols=h))
+    ctx.pointwise(d_b.ptr, d_a.ptr, dev[0][3].ptr, h1, h1, c0, c1, e(dev[0][4:6]))
+    ctx.depthwise(d_a.ptr, d_b.ptr, dev[1][0].ptr, h1, h1, 3, 1, c1, e(dev[1][1:3], pad_top=1, pad_left=1, in_rows=h1, in_cols=h1))
+    ctx.pointwise(d_b.ptr, d_a.ptr, dev[1][3].ptr, h1, h1, c1, c1, e(dev[1][4:6]))
+    ctx.pool(d_a.ptr, d_b.ptr, h1, h1, h1, c1, pkg.make_ext(batch=n, dtype=pkg.DT_BF16, act=0))
+for _ in range(3):
+    resident(); one_by_one()
+ctx.sync()
+ctx.profile_begin(6 * args.reps)
+for _ in range(args.reps):
+    resident(); one_by_one()
+ms = np.asarray(ctx.profile_end(6 * args.reps)).reshape(args.reps, 6)
+a = pkg.bf16_bits_to_f32(d_o.download((n, c1), np.uint16)); b = pkg.bf16_bits_to_f32(d_a.download((n, c1), np.uint16))
+print("batch %d, %dx%dx%d -> %d pooled, bf16: resident launch %.4f ms (min %.4f); five launches %.4f ms (sum of medians; each %s); max rel diff %.2e"
+      % (n, h, h, c0, c1, np.median(ms[:, 0]), ms[:, 0].min(), np.median(ms[:, 1:], axis=0).sum(), np.round(np.median(ms[:, 1:], axis=0), 4).tolist(),
+         float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-6))))
