@@ -577,6 +577,45 @@ def run_one(args, env):
         if multi:
             net.set_streams(args.streams, free_running=True)
 
+    # ---- the one-launch-per-layer pass (north_star's per-stage targets), UNTIMED, right behind the per-kernel pass of the default configuration: the
+    # chip is in the state those launches were timed in (round 6: it used to run behind the 1.5 s power sampler and the pw_emul pass, on a chip that
+    # had been loaded for seconds — the same GEMM launch held 2.06-2.13 GHz there against 2.24-2.28 in the default pass)
+    unfused_raw = None
+    if world == 1 and profile and not args.no_unfused_stages:
+        if multi:
+            net.set_streams(1)
+        net.set_fuse_stem(False)
+        net.set_fuse_blocks(0)
+        net.set_fuse_tail(False)
+        ul = [list(range(f - 1, f - 1 + c)) for f, c in net.launches(args.batch)]
+        for _ in range(2):
+            net.forward(d_in.ptr, d_out.ptr, args.batch)
+        reps = 5
+        # round 6 (the same pw_gemm launch read 8 % longer in this pass than in the default one, unexplained): the core
+        # clock held inside the GEMM launches of THIS pass, read the same way as the default pass's `held_clock_ghz`
+        u_clock_on = (not bf16) and lib.mbn_tune_set(b"pw_clock", 1) == 0
+        if u_clock_on:
+            ctx.pw_clock(reset=True)
+        ctx.profile_begin(len(ul) * reps)
+        for _ in range(reps):
+            net.forward(d_in.ptr, d_out.ptr, args.batch)
+        ums = np.asarray(ctx.profile_end(len(ul) * reps), dtype=np.float64).reshape(reps, len(ul)).mean(axis=0)
+        u_ghz = None
+        if u_clock_on:
+            g_, n_ = ctx.pw_clock(reset=True)
+            lib.mbn_tune_set(b"pw_clock", 0)
+            u_ghz = round(g_, 3) if n_ > 0 else None
+        ums = np.maximum(ums - ov_null_us * 1e-3, 1e-6)
+        unfused_raw = (ul, ums, u_ghz, reps)
+        net.set_fuse_stem(not args.no_fuse_stem)
+        net.set_fuse_tail(args.fuse_tail)
+        if args.fuse_blocks is not None:
+            net.set_fuse_blocks(args.fuse_blocks)
+        else:
+            net.reset_fuse_blocks()          # back to the default WITH its default-only rules (an explicit mask would switch them off)
+        if multi:
+            net.set_streams(args.streams, free_running=True)
+
     power = None
     if world == 1 and not args.no_power and not args.graph:
         try:
@@ -748,30 +787,7 @@ def run_one(args, env):
         if world == 1 and profile and not args.no_unfused_stages:
             # all 13 depthwise + 13 pointwise stages as their own launches (the metric names per-stage numbers; the timed
             # configuration above folds layers 1-11 into fused launches). UNTIMED: outside the region `value` comes from.
-            if multi:
-                net.set_streams(1)
-            net.set_fuse_stem(False)
-            net.set_fuse_blocks(0)
-            net.set_fuse_tail(False)
-            ul = [list(range(f - 1, f - 1 + c)) for f, c in net.launches(args.batch)]
-            for _ in range(2):
-                net.forward(d_in.ptr, d_out.ptr, args.batch)
-            reps = 5
-            # round 6 (the same pw_gemm launch read 8 % longer in this pass than in the default one, unexplained): the core
-            # clock held inside the GEMM launches of THIS pass, read the same way as the default pass's `held_clock_ghz`
-            u_clock_on = (not bf16) and lib.mbn_tune_set(b"pw_clock", 1) == 0
-            if u_clock_on:
-                ctx.pw_clock(reset=True)
-            ctx.profile_begin(len(ul) * reps)
-            for _ in range(reps):
-                net.forward(d_in.ptr, d_out.ptr, args.batch)
-            ums = np.asarray(ctx.profile_end(len(ul) * reps), dtype=np.float64).reshape(reps, len(ul)).mean(axis=0)
-            u_ghz = None
-            if u_clock_on:
-                g_, n_ = ctx.pw_clock(reset=True)
-                lib.mbn_tune_set(b"pw_clock", 0)
-                u_ghz = round(g_, 3) if n_ > 0 else None
-            ums = np.maximum(ums - ov_null_us * 1e-3, 1e-6)
+            ul, ums, u_ghz, reps = unfused_raw
             ust, ulayers, _ = stage_table(plan, pkg, ul, ums, args.batch, act_bytes, mfma_peak)
             out["unfused_stages"] = {"note": "untimed: %d forwards with one launch per layer (mbn_net_set_fuse_stem(0), "
                                              "mbn_net_set_fuse_blocks(0)); same batch, same buffers" % reps,
@@ -787,12 +803,6 @@ def run_one(args, env):
                     out["roofline"]["blocks_ms"] = stages["block_fused"]["ms"]
                 if "stem_fused" in stages:
                     out["roofline"]["stem_ms"] = stages["stem_fused"]["ms"]
-            net.set_fuse_stem(not args.no_fuse_stem)
-            net.set_fuse_tail(args.fuse_tail)
-            if args.fuse_blocks is not None:
-                net.set_fuse_blocks(args.fuse_blocks)
-            else:
-                net.reset_fuse_blocks()          # back to the default WITH its default-only rules (an explicit mask would switch them off)
         if alt is not None:
             out["pw_emul_alt"] = alt
         if args.pw_emul and not bf16:
