@@ -8,7 +8,8 @@
 //
 // One workgroup = 8 waves = one image at a time (persistent over images). Two LDS images of the map, both [pixel][C + 8] bf16 (528-byte rows):
 //   X: the block's input with a one-pixel ZERO border ((H + 2) x (W + 2) pixels): the depthwise window reads need no edge logic;
-//   Y: the depthwise output = the pointwise GEMM's activation operand (H x W pixels, padded to 128 rows).
+//   Y: the depthwise output = the pointwise GEMM's activation operand (H x W pixels in 104 rows; the GEMM's four 32-pixel column blocks read on into the constants behind
+//      it — inside the allocation, those columns are never stored).
 // Per block: (1) depthwise as a COLUMN MARCH: a lane owns one column x 8 channels (its 9 taps + scale / shift in registers for the whole block, read from an LDS
 //   copy that the workgroup fetched once while the previous block's GEMM ran) and walks down the rows; every input row is read and widened ONCE (3 ds_read_b128) and feeds the three output
 //   rows it belongs to (three running sums, same dy-major fma chain as the separate kernels): 24 widening instructions per output pixel group instead of
